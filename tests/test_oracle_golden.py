@@ -1,0 +1,158 @@
+"""The CPU oracle (oracle/polyblur_ref.py) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import polyblur_ref as ref
+
+KW = dict(c=0.362, b=0.468, alpha=6, beta=1)
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+@pytest.mark.parametrize("name", ["stages_A.npz", "stages_B.npz", "stages_C.npz"])
+def test_stage_functions(golden, name):
+    g = golden(name)
+    x = g["x"]
+    B = x.shape[0]
+    gx, gy = ref.spectral_gradients(x)
+    assert maxabs(gx, g["grad_x"]) < 2e-6 and maxabs(gy, g["grad_y"]) < 2e-6
+    gx1, gy1 = ref.spectral_gradients_1d(x)
+    assert maxabs(gx1, g["grad_x"]) < 3e-6 and maxabs(gy1, g["grad_y"]) < 3e-6
+    gray = x.mean(axis=1, keepdims=True, dtype=np.float32) if x.shape[1] == 3 else x
+    assert maxabs(gray, g["gray"]) < 1e-7
+    norm, lo, hi = ref.range_normalize(gray, 0.0)
+    assert maxabs(norm, g["normalized"]) < 3e-7
+    ngx, ngy = ref.spectral_gradients(norm)
+    assert maxabs(ngx, g["norm_grad_x"]) < 3e-6
+    mags = ref.directional_maxima(ngx, ngy)
+    assert maxabs(mags, g["mags"]) < 3e-6
+    thetas, ith = ref.angle_grids()
+    m_n, m_o, theta, interp, i_min = ref.dominant_direction(g["mags"], thetas, ith)
+    assert maxabs(interp, g["interp"]) < 1e-6
+    assert maxabs(m_n, g["m_normal"]) < 1e-6 and maxabs(m_o, g["m_ortho"]) < 1e-6
+    assert np.array_equal(theta, g["theta"])
+    sigma, rho = ref.gaussian_std_from_magnitudes(g["m_normal"], g["m_ortho"], 0.362, 0.468)
+    assert maxabs(sigma, g["sigma"]) < 1e-6 and maxabs(rho, g["rho"]) < 1e-6
+    ker = ref.gaussian_kernel_2d(g["theta"], g["sigma"], g["rho"])
+    assert maxabs(ker, g["kernel"]) < 2e-8
+    sg, rh, th = g["kwide_params"].T
+    kwide = ref.gaussian_kernel_2d(th, sg, rh)
+    assert maxabs(kwide, g["kwide"]) < 2e-8
+    xp = ref.replicate_pad(x, 12)
+    for kname in ("kest", "kwide"):
+        k = g["kernel" if kname == "kest" else "kwide"][:, None]
+        assert maxabs(ref.polynomial_deconvolution(xp, k, 6.0, 1.0, "fft"), g["poly_fft_" + kname]) < 1e-5
+        assert maxabs(ref.inverse_filtering_rank3(x, k, 6.0, 1.0, method="fft"), g["inv_fft_" + kname]) < 1e-5
+        if B == 1:
+            assert maxabs(ref.polynomial_deconvolution(xp, k, 6.0, 1.0, "direct"), g["poly_direct_" + kname]) < 1e-5
+    if B == 1:
+        k = g["kwide"][:, None]
+        assert maxabs(ref.circular_convolve(xp, k), g["conv_fft_kwide"]) < 2e-6
+        assert maxabs(ref.correlate_same_zero(xp, k), g["conv_direct_kwide"]) < 2e-6
+        assert maxabs(ref.edgetaper_weights(k, xp.shape[-2:]), g["taper_alpha_kwide"]) < 2e-6
+        assert maxabs(ref.edgetaper(xp, k, method="fft"), g["taper_fft_kwide"]) < 3e-6
+        assert maxabs(ref.edgetaper(xp, k, method="direct"), g["taper_direct_kwide"]) < 3e-6
+        y = ref.inverse_filtering_rank3(x, k, 6.0, 1.0, method="fft")
+        assert maxabs(ref.halo_masking(x, y, (g["grad_x"], g["grad_y"])), g["halo_kwide"]) < 1e-5
+    assert maxabs(ref.bilateral_filter(x), g["bilateral"]) < 2e-6
+    assert maxabs(ref.recursive_filter(x, 2.0, 0.8, 1), g["rf_n1"]) < 2e-6
+    assert maxabs(ref.recursive_filter(x, 60, 0.4, 3), g["rf_n3"]) < 5e-6
+
+
+def test_kernel_grid(golden):
+    g = golden("kernel_grid.npz")
+    k = ref.gaussian_kernel_2d(g["theta"], g["sigma"], g["rho"])
+    assert maxabs(k, g["kernels"]) < 3e-7      # centre tap ~1 at sigma=0.3: 1-2 ulp
+    assert np.allclose(k.sum(axis=(-2, -1)), 1.0, atol=1e-6)
+
+
+def check_iterations(g, prefix, infos, n, tol_img=None):
+    for it in range(n):
+        p = "%s/it%d/" % (prefix, it)
+        assert maxabs(infos[it]["mags"], g[p + "mags"]) < 2e-5, (it, "mags")
+        assert np.array_equal(infos[it]["theta"], g[p + "theta"]), (it, "theta")
+        assert maxabs(infos[it]["sigma"], g[p + "sigma"]) < 5e-5, (it, "sigma")
+        assert maxabs(infos[it]["rho"], g[p + "rho"]) < 5e-5, (it, "rho")
+        assert maxabs(infos[it]["kernel"], g[p + "kernel"]) < 2e-5, (it, "kernel")
+
+
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_pipeline_peacock(golden, method):
+    from PIL import Image
+    import os
+    g = golden("pipeline_peacock.npz")
+    img = np.asarray(Image.open(os.path.join(os.path.dirname(__file__), "golden", "peacock_defocus.png")))
+    img = img[..., :3].astype(np.float32) / 255.0
+    if method == "direct":
+        # 27 dense 25x25 correlations at 500x700x3 in NumPy: keep the CPU suite short by
+        # checking a crop that still contains every border mode's interior behaviour
+        x = np.ascontiguousarray(np.moveaxis(img, 2, 0)[None])
+        out, infos = ref.polyblur_deblurring(x, n_iter=1, method="direct", return_info=True, **KW)
+        check_iterations(g, method, infos, 1)
+        assert maxabs(out[..., 100:164, 200:264], g["direct/it0_image_crop"]) < 2e-5
+        return
+    out, infos = ref.polyblur_deblurring(img, n_iter=3, method=method, return_info=True, **KW)
+    assert out.shape == img.shape and out.dtype == np.float32
+    check_iterations(g, method, infos, 3)
+    gold = np.moveaxis(g["fft/out"][0], 0, 2)
+    assert maxabs(out, gold) < 2e-5
+    assert abs(float(out.mean()) - 0.3341835) < 1e-5           # SURVEY Appendix A sanity value
+    assert maxabs(infos[0]["image"][..., 100:164, 200:264], g["fft/it0_image_crop"]) < 1e-5
+
+
+@pytest.mark.parametrize("variant,opts", [
+    ("plain", {}), ("edgetaping", dict(edgetaping=True)), ("remove_halo", dict(remove_halo=True)),
+    ("prefiltering", dict(prefiltering=True)), ("discard_saturation", dict(discard_saturation=True)),
+    ("q1e-4", dict(q=1e-4)), ("all", dict(edgetaping=True, remove_halo=True, prefiltering=True))])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_pipeline_variants(golden, variant, opts, method):
+    g = golden("pipeline_variants.npz")
+    n = 3 if method == "fft" else 1
+    out, infos = ref.polyblur_deblurring(g["x"], n_iter=n, method=method, return_info=True, **KW, **opts)
+    check_iterations(g, "%s/%s" % (variant, method), infos, n)
+    if method == "fft":
+        assert maxabs(out, g["%s/%s/out" % (variant, method)]) < 3e-5
+
+
+def test_pipeline_misc(golden):
+    g = golden("pipeline_variants.npz")
+    out, infos = ref.polyblur_deblurring(g["x_sat"], n_iter=2, discard_saturation=True, return_info=True, **KW)
+    check_iterations(g, "sat/fft", infos, 2)
+    assert maxabs(out, g["sat/fft/out"]) < 3e-5
+    xg = np.ascontiguousarray(g["x"][:, 1:2])
+    out, infos = ref.polyblur_deblurring(xg, n_iter=2, return_info=True, **KW)
+    check_iterations(g, "gray/fft", infos, 2)
+    assert maxabs(out, g["gray/fft/out"]) < 3e-5
+    assert maxabs(ref.polyblur_deblurring(g["x"]), g["defaults/functional"]) < 2e-5
+    assert maxabs(ref.PolyblurDeblurring()(g["x"]), g["defaults/module"]) < 2e-5
+    assert maxabs(ref.PolyblurDeblurring()(g["x"], n_iter=2, alpha=6, beta=1), g["module_n2"]) < 2e-5
+    hw = ref.polyblur_deblurring(g["x"][0, 1], n_iter=1, **KW)
+    assert hw.shape == g["gray_ndarray_hw"].shape and maxabs(hw, g["gray_ndarray_hw"]) < 2e-5
+
+
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_pipeline_strongblur(golden, method):
+    g = golden("pipeline_strongblur.npz")
+    n = 3 if method == "fft" else 1
+    out, infos = ref.polyblur_deblurring(g["x"], n_iter=n, method=method, return_info=True, **KW)
+    check_iterations(g, method, infos, n)
+    if method == "fft":
+        assert maxabs(out, g["fft/out"]) < 3e-5
+
+
+def test_pipeline_batch(golden):
+    g = golden("pipeline_batch.npz")
+    out, infos = ref.polyblur_deblurring(g["x"], n_iter=3, return_info=True, **KW)
+    check_iterations(g, "fft", infos, 3)
+    assert maxabs(out, g["fft/out"]) < 3e-5
+    assert maxabs(g["fft/out"], g["fft/out_single"]) < 1e-6     # images are independent
+
+
+def test_pipeline_fp16_rounded_inputs(golden):
+    g = golden("pipeline_fp16in.npz")
+    out, infos = ref.polyblur_deblurring(g["x"], n_iter=3, return_info=True, **KW)
+    check_iterations(g, "fft", infos, 3)
+    assert maxabs(out, g["fft/out"]) < 3e-5
