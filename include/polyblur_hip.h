@@ -1,0 +1,188 @@
+/*
+ * polyblur_hip.h -- C ABI of libpolyblur_hip.so, the MI355X (gfx950) Polyblur engine.
+ *
+ * Drop-in boundary for the hot path of teboli/polyblur (reference @ /root/reference):
+ * the reference has no C ABI of its own -- its Python calls ATen ops, and its three
+ * side-car pybind11 modules take torch::Tensor (RF.cpp:43-46,97-99,
+ * separable_gaussian2d.cpp:186-191,252-255).  Each entry point below names the
+ * reference function(s) (file:line) it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no torch / pybind types; every image pointer is a DEVICE pointer to a
+ *     contiguous NCHW array (the reference's (B,C,H,W) tensors); `float *host_*`
+ *     arguments are HOST pointers and make the call synchronise the stream;
+ *   - all other calls are asynchronous on the context's stream;
+ *   - the caller owns every buffer; inputs are never written; scratch memory lives in
+ *     the context; a context is single-stream and not thread-safe (one per host
+ *     thread / GPU);
+ *   - return value: PB_OK (0) or a negative pb_status; pb_last_error_string() gives
+ *     the text for the most recent failure on that context.
+ */
+#ifndef POLYBLUR_HIP_H
+#define POLYBLUR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PB_VERSION 100           /* major*10000 + minor*100 + patch */
+#define PB_KSIZE 25              /* kernel support of the reference (ker_size=25, deblurring.py:23) */
+#define PB_KRAD 12
+#define PB_MAX_ANGLES 13         /* n_angles + 1 <= 13 */
+#define PB_MAX_INTERP 64         /* n_interpolated_angles <= 64 */
+
+typedef struct pb_ctx pb_ctx;
+
+typedef enum pb_status {
+    PB_OK = 0,
+    PB_ERR_BADARG = -1,
+    PB_ERR_UNSUPPORTED = -2,
+    PB_ERR_HIP = -3,
+    PB_ERR_NOMEM = -4
+} pb_status;
+
+typedef enum pb_dtype { PB_F32 = 0, PB_F16 = 1 } pb_dtype;
+
+/* Outer boundary of the three reblurring convolutions on the replicate-padded domain:
+ * PB_WRAP == reference method='fft'  (circular, deblurring.py:141-169, filters.py:31-35)
+ * PB_ZERO == reference method='direct' (zero 'same' padding, filters.py:45-49).        */
+typedef enum pb_boundary { PB_WRAP = 0, PB_ZERO = 1 } pb_boundary;
+
+typedef enum pb_prefilter { PB_PREFILTER_NONE = 0, PB_PREFILTER_BILATERAL = 1,
+                            PB_PREFILTER_DOMAIN_TRANSFORM = 2 } pb_prefilter;
+
+/* Kernel-support policy: PB_SUPPORT_FULL evaluates all 25 taps per axis like the
+ * reference; PB_SUPPORT_ADAPTIVE drops taps whose marginal mass is < 1e-8 (support
+ * radius rounded up to 4, 8 or 12) -- results agree to fp32 rounding.                  */
+typedef enum pb_support { PB_SUPPORT_FULL = 0, PB_SUPPORT_ADAPTIVE = 1,
+                          /* test/bench flag, OR-ed in: never take the rank-1 (separable) path */
+                          PB_SUPPORT_FORCE_GENERAL = 16 } pb_support;
+
+/* Keyword arguments of polyblur_deblurring() (deblurring.py:23-25). */
+typedef struct pb_options {
+    int32_t n_iter;
+    float c, b;                 /* affine blur model (blur_estimation.py:171-185) */
+    float alpha, beta;          /* polynomial parameters (deblurring.py:133-135) */
+    float sigma_s, sigma_r;     /* domain-transform prefilter (deblurring.py:107) */
+    float q;                    /* normalisation quantile; only q == 0 is implemented */
+    int32_t n_angles;           /* 6 */
+    int32_t n_interpolated_angles; /* 30 */
+    int32_t remove_halo;
+    int32_t edgetaping;
+    int32_t prefilter;          /* pb_prefilter; reference prefiltering=True == BILATERAL */
+    int32_t discard_saturation;
+    int32_t boundary;           /* pb_boundary */
+    int32_t support;            /* pb_support */
+    float force_theta_deg;      /* < 0: estimate (default); >= 0: bench knob, overrides the
+                                   estimated direction so that every kernel is rank-1 */
+} pb_options;
+
+/* Per-image, per-iteration estimation record (device or host copy). Mirrors the values the
+ * reference computes in blur_estimation.py:59-73. */
+typedef struct pb_blur_info {
+    float gray_min, gray_max;           /* blur_estimation.py:107-108 */
+    float mags[PB_MAX_ANGLES];          /* :122-134 */
+    float interp[PB_MAX_INTERP];        /* :138-148 */
+    int32_t i_min;                      /* :160 */
+    float theta;                        /* radians, :167 */
+    float sigma, rho;                   /* :171-185 */
+    int32_t separable;                  /* 1 if the 25x25 kernel is rank-1 (theta % 90 == 0 or sigma == rho) */
+    int32_t radius;                     /* support radius class actually evaluated: 4, 8 or 12 */
+    float kernel[PB_KSIZE * PB_KSIZE];  /* :211-232, row-major [y][x] */
+    float kx[PB_KSIZE], ky[PB_KSIZE];   /* marginals kx[j] = sum_i k[i][j], ky[i] = sum_j k[i][j];
+                                           the exact rank-1 factors when `separable` */
+    float acorr_y[PB_KSIZE], acorr_x[PB_KSIZE]; /* autocorrelation of ky / kx at lags 0..24: the closed
+                                           form of edgetaper_alpha's 1-D FFTs (edgetaper.py:11-21) */
+} pb_blur_info;
+
+/* ---- context ------------------------------------------------------------------------- */
+int pb_version(void);
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the
+ * device's default stream. */
+int pb_create(pb_ctx **out, int device, void *stream);
+int pb_destroy(pb_ctx *ctx);
+int pb_set_stream(pb_ctx *ctx, void *stream);
+int pb_synchronize(pb_ctx *ctx);
+const char *pb_last_error_string(pb_ctx *ctx);
+void pb_default_options(pb_options *opt);        /* the functional API's defaults, deblurring.py:23-25 */
+/* bytes of scratch the context currently holds (for the HBM-footprint report) */
+size_t pb_workspace_bytes(pb_ctx *ctx);
+
+/* ---- plain device-memory helpers so a host without torch can drive the engine ------- */
+int pb_malloc(pb_ctx *ctx, void **dptr, size_t bytes);
+int pb_free(pb_ctx *ctx, void *dptr);
+int pb_memcpy_h2d(pb_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronous */
+int pb_memcpy_d2h(pb_ctx *ctx, void *dst, const void *src, size_t bytes);   /* synchronous */
+
+/* ---- whole pipeline: polyblur_deblurring (deblurring.py:23-96) ------------------------
+ * in/out: (B,C,H,W) of `dtype`; out may not alias in.  host_info (optional) receives
+ * n_iter*B records, iteration-major.                                                    */
+int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype,
+                      int B, int C, int H, int W, const pb_options *opt,
+                      pb_blur_info *host_info);
+
+/* ---- stage entry points (each is also what the pipeline calls) ----------------------- */
+
+/* gaussian_blur_estimation (blur_estimation.py:18-79): gray -> normalise -> spectral
+ * gradients -> directional maxima -> direction -> (sigma, rho) -> 25x25 kernel.
+ * Writes B records to dev_info (device memory).                                         */
+int pb_estimate_blur(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W,
+                     const pb_options *opt, pb_blur_info *dev_info);
+
+/* create_gaussian_filter (blur_estimation.py:211-232) + support analysis, for caller-
+ * supplied parameters: fills kernel/separable/radius of B device records from host arrays. */
+int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *host_rho,
+                    const float *host_theta_rad, int support, pb_blur_info *dev_info);
+/* Same, but the caller supplies arbitrary 25x25 taps (host, B*625 floats). */
+int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_blur_info *dev_info);
+
+/* filters.fourier_gradients (filters.py:159-186) on P = B*C planes of H x W float32.
+ * gx or gy may be NULL.                                                                  */
+int pb_fourier_gradients(pb_ctx *ctx, const float *planes, int P, int H, int W,
+                         float *gx, float *gy);
+
+/* inverse_filtering_rank3 (deblurring.py:211-239): replicate pad -> [edgetaper] ->
+ * polynomial (three fused separable / general Gaussian stencil passes) -> crop ->
+ * [halo masking with grad0 = gradients of the original image] -> clamp.
+ * grad0_x/grad0_y: (B,C,H,W) float32, required iff remove_halo.                          */
+int pb_inverse_filter(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
+                      const pb_blur_info *dev_info, float alpha, float beta, int boundary,
+                      int edgetaping, int remove_halo, const float *grad0_x, const float *grad0_y);
+
+/* filters.convolve2d on an already padded (B,C,Hp,Wp) float32 image: one reblurring pass
+ * out = K * in with the given outer boundary (filters.py:14-37).                          */
+int pb_convolve2d(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp, int Wp,
+                  const pb_blur_info *dev_info, int boundary);
+
+/* edgetaper.edgetaper (edgetaper.py:26-33) on a padded float32 image, per-image maximum. */
+int pb_edgetaper(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp, int Wp,
+                 const pb_blur_info *dev_info, int boundary);
+
+/* halo_masking (deblurring.py:193-208), bug-compatible.  All (B,C,H,W) float32.           */
+int pb_halo_mask(pb_ctx *ctx, const float *x, const float *y, const float *grad0_x,
+                 const float *grad0_y, float *out, int B, int C, int H, int W);
+
+/* domain_transform.recursive_filter (domain_transform.py:6-63; native twin RF.cpp:43-92).
+ * joint may be NULL (filter guided by itself).                                           */
+int pb_dt_recursive_filter(pb_ctx *ctx, const void *in, const void *joint, void *out, int dtype,
+                           int B, int C, int H, int W, float sigma_s, float sigma_r, int num_iterations);
+
+/* filters.bilateral_filter (filters.py:107-148), 5x5, sigma_spatial=5, sigma_color=0.1. */
+int pb_bilateral5(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W);
+
+/* ---- timing hooks used by bench.py ------------------------------------------------------
+ * Runs only the polynomial inner loop (three stencil passes, the SURVEY 8d "inner loop")
+ * `reps` times on resident data and returns the average milliseconds per repetition
+ * measured with hipEvents on the context's stream.                                       */
+int pb_time_inner_loop(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
+                       const pb_blur_info *dev_info, float alpha, float beta, int boundary,
+                       int reps, float *host_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYBLUR_HIP_H */

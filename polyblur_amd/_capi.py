@@ -1,0 +1,124 @@
+"""ctypes binding of include/polyblur_hip.h (libpolyblur_hip.so).
+
+This is the whole Python<->native boundary: plain pointers and sizes, no torch types.
+The library is loaded lazily; a missing library or a missing GPU raises -- there is no
+CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+PB_KSIZE = 25
+PB_MAX_ANGLES = 13
+PB_MAX_INTERP = 64
+
+PB_F32, PB_F16 = 0, 1
+PB_WRAP, PB_ZERO = 0, 1
+PB_PREFILTER_NONE, PB_PREFILTER_BILATERAL, PB_PREFILTER_DOMAIN_TRANSFORM = 0, 1, 2
+PB_SUPPORT_FULL, PB_SUPPORT_ADAPTIVE = 0, 1
+
+STATUS = {0: "PB_OK", -1: "PB_ERR_BADARG", -2: "PB_ERR_UNSUPPORTED", -3: "PB_ERR_HIP", -4: "PB_ERR_NOMEM"}
+
+# every symbol include/polyblur_hip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "pb_version", "pb_create", "pb_destroy", "pb_set_stream", "pb_synchronize", "pb_last_error_string",
+    "pb_default_options", "pb_workspace_bytes", "pb_malloc", "pb_free", "pb_memcpy_h2d", "pb_memcpy_d2h",
+    "pb_polyblur_batch", "pb_estimate_blur", "pb_make_kernels", "pb_set_kernels", "pb_fourier_gradients",
+    "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
+    "pb_bilateral5", "pb_time_inner_loop",
+]
+
+
+class pb_options(C.Structure):
+    _fields_ = [
+        ("n_iter", C.c_int32), ("c", C.c_float), ("b", C.c_float), ("alpha", C.c_float), ("beta", C.c_float),
+        ("sigma_s", C.c_float), ("sigma_r", C.c_float), ("q", C.c_float), ("n_angles", C.c_int32),
+        ("n_interpolated_angles", C.c_int32), ("remove_halo", C.c_int32), ("edgetaping", C.c_int32),
+        ("prefilter", C.c_int32), ("discard_saturation", C.c_int32), ("boundary", C.c_int32),
+        ("support", C.c_int32), ("force_theta_deg", C.c_float),
+    ]
+
+
+class pb_blur_info(C.Structure):
+    _fields_ = [
+        ("gray_min", C.c_float), ("gray_max", C.c_float), ("mags", C.c_float * PB_MAX_ANGLES),
+        ("interp", C.c_float * PB_MAX_INTERP), ("i_min", C.c_int32), ("theta", C.c_float),
+        ("sigma", C.c_float), ("rho", C.c_float), ("separable", C.c_int32), ("radius", C.c_int32),
+        ("kernel", C.c_float * (PB_KSIZE * PB_KSIZE)), ("kx", C.c_float * PB_KSIZE), ("ky", C.c_float * PB_KSIZE),
+        ("acorr_y", C.c_float * PB_KSIZE), ("acorr_x", C.c_float * PB_KSIZE),
+    ]
+
+
+INFO_DTYPE = np.dtype([
+    ("gray_min", "<f4"), ("gray_max", "<f4"), ("mags", "<f4", (PB_MAX_ANGLES,)), ("interp", "<f4", (PB_MAX_INTERP,)),
+    ("i_min", "<i4"), ("theta", "<f4"), ("sigma", "<f4"), ("rho", "<f4"), ("separable", "<i4"), ("radius", "<i4"),
+    ("kernel", "<f4", (PB_KSIZE, PB_KSIZE)), ("kx", "<f4", (PB_KSIZE,)), ("ky", "<f4", (PB_KSIZE,)),
+    ("acorr_y", "<f4", (PB_KSIZE,)), ("acorr_x", "<f4", (PB_KSIZE,)),
+])
+assert INFO_DTYPE.itemsize == C.sizeof(pb_blur_info)
+
+
+class PolyblurHipError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def library_path() -> str:
+    env = os.environ.get("POLYBLUR_HIP_LIB")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpolyblur_hip.so")
+
+
+def load_library():
+    """dlopen libpolyblur_hip.so and declare the prototypes.  Raises if it is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise PolyblurHipError(
+                "libpolyblur_hip.so not found at %s -- build it with `python -m polyblur_amd.build` "
+                "(there is no CPU fallback)" % path)
+        lib = C.CDLL(path)
+        vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        fp = C.POINTER(C.c_float)
+        proto = {
+            "pb_version": (ci, []),
+            "pb_create": (ci, [C.POINTER(vp), ci, vp]),
+            "pb_destroy": (ci, [vp]),
+            "pb_set_stream": (ci, [vp, vp]),
+            "pb_synchronize": (ci, [vp]),
+            "pb_last_error_string": (C.c_char_p, [vp]),
+            "pb_default_options": (None, [C.POINTER(pb_options)]),
+            "pb_workspace_bytes": (sz, [vp]),
+            "pb_malloc": (ci, [vp, C.POINTER(vp), sz]),
+            "pb_free": (ci, [vp, vp]),
+            "pb_memcpy_h2d": (ci, [vp, vp, vp, sz]),
+            "pb_memcpy_d2h": (ci, [vp, vp, vp, sz]),
+            "pb_polyblur_batch": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), vp]),
+            "pb_estimate_blur": (ci, [vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), vp]),
+            "pb_make_kernels": (ci, [vp, ci, fp, fp, fp, ci, vp]),
+            "pb_set_kernels": (ci, [vp, ci, fp, ci, vp]),
+            "pb_fourier_gradients": (ci, [vp, vp, ci, ci, ci, vp, vp]),
+            "pb_inverse_filter": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, cf, cf, ci, ci, ci, vp, vp]),
+            "pb_convolve2d": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, ci]),
+            "pb_edgetaper": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, ci]),
+            "pb_halo_mask": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci]),
+            "pb_dt_recursive_filter": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, ci]),
+            "pb_bilateral5": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
+            "pb_time_inner_loop": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, cf, cf, ci, ci, fp]),
+        }
+        for name in SYMBOLS:
+            fn = getattr(lib, name)           # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = proto[name]
+        _lib = lib
+        return lib

@@ -1,0 +1,76 @@
+"""Build libpolyblur_hip.so in-tree with hipcc for gfx950 (no cmake, no torch extension).
+
+    python -m polyblur_amd.build [--force]
+
+The library lands in polyblur_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBNAME = "libpolyblur_hip.so"
+SOURCES = ["api.hip", "conv.hip", "estimate.hip", "filters.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def lib_path() -> str:
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = hipcc_path()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "polyblur_hip.h"))
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    out = lib_path()
+    if jobs or not os.path.exists(out):
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", out] + objs)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,523 @@
+// C ABI of libpolyblur_hip.so (include/polyblur_hip.h): context, scratch memory, and the
+// drivers that chain the kernels of conv.hip / estimate.hip / filters.hip on one stream.
+// Mirrors polyblur_deblurring's main loop (reference deblurring.py:58-96) and
+// inverse_filtering_rank3 (deblurring.py:211-239).
+#include <cstring>
+
+#include "common.h"
+
+int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int P, long HW);
+int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
+                  const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
+                  int clamp01);
+int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, const float *smooth, void *out, int dtype, long n);
+int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int out_dtype, int P, int H, int W);
+int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype, float *out, int B, int C, int H, int W,
+                      float sigma_s, float sigma_r, int num_iterations);
+int pb_convert_from_float(pb_ctx *ctx, const float *in, void *out, int dtype, long n);
+int pb_convert_to_float(pb_ctx *ctx, const void *in, int dtype, float *out, long n);
+
+int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes) {
+    ScratchBuf &b = ctx->scratch[name];
+    if (b.bytes >= bytes && b.p) return b.p;
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        pb_fail(ctx, PB_ERR_NOMEM, "scratch '%s': hipMalloc(%zu) failed", name, want);
+        return nullptr;
+    }
+    b.bytes = want;
+    return b.p;
+}
+
+static size_t dsize(int dtype) { return dtype == PB_F16 ? 2 : 4; }
+static int pitch4(int w) { return (w + 3) & ~3; }
+
+extern "C" {
+
+int pb_version(void) { return PB_VERSION; }
+
+void pb_default_options(pb_options *o) {
+    // deblurring.py:23-25
+    memset(o, 0, sizeof(*o));
+    o->n_iter = 1; o->c = 0.352f; o->b = 0.768f; o->alpha = 2.f; o->beta = 3.f;
+    o->sigma_r = 0.8f; o->sigma_s = 2.0f; o->q = 0.f; o->n_angles = 6; o->n_interpolated_angles = 30;
+    o->remove_halo = 0; o->edgetaping = 0; o->prefilter = PB_PREFILTER_NONE; o->discard_saturation = 0;
+    o->boundary = PB_WRAP; o->support = PB_SUPPORT_FULL; o->force_theta_deg = -1.f;
+}
+
+int pb_create(pb_ctx **out, int device, void *stream) {
+    if (!out) return PB_ERR_BADARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PB_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return PB_ERR_HIP;
+    pb_ctx *ctx = new pb_ctx();
+    ctx->device = device;
+    ctx->stream = static_cast<hipStream_t>(stream);
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
+    *out = ctx;
+    return PB_OK;
+}
+
+int pb_destroy(pb_ctx *ctx) {
+    if (!ctx) return PB_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &kv : ctx->plans) {
+        FftPlan &p = kv.second;
+        if (p.tw) (void)hipFree(p.tw);
+        if (p.drev) (void)hipFree(p.drev);
+        if (p.chirp) (void)hipFree(p.chirp);
+        if (p.bfilt_rev) (void)hipFree(p.bfilt_rev);
+        if (p.dnat) (void)hipFree(p.dnat);
+    }
+    if (ctx->interp_w) (void)hipFree(ctx->interp_w);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return PB_OK;
+}
+
+int pb_set_stream(pb_ctx *ctx, void *stream) {
+    if (!ctx) return PB_ERR_BADARG;
+    ctx->stream = static_cast<hipStream_t>(stream);
+    return PB_OK;
+}
+
+int pb_synchronize(pb_ctx *ctx) {
+    if (!ctx) return PB_ERR_BADARG;
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
+}
+
+const char *pb_last_error_string(pb_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+size_t pb_workspace_bytes(pb_ctx *ctx) {
+    size_t t = 0;
+    if (ctx) for (auto &kv : ctx->scratch) t += kv.second.bytes;
+    return t;
+}
+
+int pb_malloc(pb_ctx *ctx, void **dptr, size_t bytes) {
+    if (!ctx || !dptr) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) return pb_fail(ctx, PB_ERR_NOMEM, "pb_malloc(%zu) failed", bytes);
+    return PB_OK;
+}
+int pb_free(pb_ctx *ctx, void *dptr) {
+    if (!ctx) return PB_ERR_BADARG;
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    PB_HIP(hipFree(dptr));
+    return PB_OK;
+}
+int pb_memcpy_h2d(pb_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return PB_ERR_BADARG;
+    PB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
+}
+int pb_memcpy_d2h(pb_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return PB_ERR_BADARG;
+    PB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    return PB_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// inverse filtering (deblurring.py:211-239)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Geometry {
+    int B, C, H, W, P, Hp, Wp, pp;     // pp = pitch of padded fp32 planes
+    long pplane;                        // elements per padded plane
+    long HW;
+};
+
+Geometry geometry(int B, int C, int H, int W) {
+    Geometry g;
+    g.B = B; g.C = C; g.H = H; g.W = W; g.P = B * C;
+    g.Hp = H + 2 * PB_PAD; g.Wp = W + 2 * PB_PAD; g.pp = pitch4(g.Wp);
+    g.pplane = (long)g.Hp * g.pp;
+    g.HW = (long)H * W;
+    return g;
+}
+
+ConvPass base_pass(const Geometry &g, const pb_blur_info *info, int boundary, int force_full) {
+    ConvPass p;
+    memset(&p, 0, sizeof(p));
+    p.H = g.H; p.W = g.W; p.C = g.C; p.P = g.P; p.info = info; p.boundary = boundary;
+    p.scale = 1.f; p.coef = 0.f; p.epilogue = EPI_HORNER; p.clamp01 = 0; p.force_full = force_full;
+    return p;
+}
+void set_in_virtual(ConvPass &p, const Geometry &g, const void *ptr, int dtype) {
+    p.in = ptr; p.in_kind = SRC_VIRTUAL; p.in_dtype = dtype; p.in_pitch = g.W; p.in_plane = g.HW;
+}
+void set_in_padded(ConvPass &p, const Geometry &g, const float *ptr) {
+    p.in = ptr; p.in_kind = SRC_PADDED; p.in_dtype = PB_F32; p.in_pitch = g.pp; p.in_plane = g.pplane;
+}
+void set_x_virtual(ConvPass &p, const Geometry &g, const void *ptr, int dtype) {
+    p.x = ptr; p.x_kind = SRC_VIRTUAL; p.x_dtype = dtype; p.x_pitch = g.W; p.x_plane = g.HW;
+}
+void set_x_padded(ConvPass &p, const Geometry &g, const float *ptr) {
+    p.x = ptr; p.x_kind = SRC_PADDED; p.x_dtype = PB_F32; p.x_pitch = g.pp; p.x_plane = g.pplane;
+}
+void set_out_padded(ConvPass &p, const Geometry &g, float *ptr) {
+    p.out = ptr; p.out_kind = OUT_PADDED; p.out_dtype = PB_F32; p.out_pitch = g.pp; p.out_plane = g.pplane;
+}
+void set_out_interior(ConvPass &p, const Geometry &g, void *ptr, int dtype) {
+    p.out = ptr; p.out_kind = OUT_INTERIOR; p.out_dtype = dtype; p.out_pitch = g.W; p.out_plane = g.HW;
+}
+
+// Three edgetaper blends on the padded domain (edgetaper.py:26-33).  src is an un-padded image
+// (virtual replicate pad).  Returns the padded fp32 result in *result (one of the two scratch planes).
+int run_edgetaper(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype, const pb_blur_info *info, int boundary,
+                  float *pa, float *pb, float **result) {
+    ConvPass p = base_pass(g, info, boundary, 0);
+    p.epilogue = EPI_TAPER;
+    set_in_virtual(p, g, src, src_dtype);
+    set_x_virtual(p, g, src, src_dtype);
+    set_out_padded(p, g, pa);
+    int rc = pb_launch_conv(ctx, p);
+    if (rc) return rc;
+    set_in_padded(p, g, pa); set_x_padded(p, g, pa); set_out_padded(p, g, pb);
+    rc = pb_launch_conv(ctx, p);
+    if (rc) return rc;
+    set_in_padded(p, g, pb); set_x_padded(p, g, pb); set_out_padded(p, g, pa);
+    rc = pb_launch_conv(ctx, p);
+    *result = pa;
+    return rc;
+}
+
+// y = a3 K^3 x + a2 K^2 x + a1 K x + beta x by Horner, three stencil passes (deblurring.py:122-138).
+// X is either the un-padded image (virtual pad) or a padded fp32 image (after edgetaper).
+int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype, const float *xpadded,
+                   const pb_blur_info *info, float alpha, float beta, int boundary, float *t1, float *t2, void *dst,
+                   int dst_dtype, int clamp01, int force_full) {
+    const float a3 = alpha / 2 - beta + 2, a2 = 3 * beta - alpha - 6, a1 = 5 - 3 * beta + alpha / 2;
+    ConvPass p = base_pass(g, info, boundary, force_full);
+    auto set_x = [&](ConvPass &q) { if (xpadded) set_x_padded(q, g, xpadded); else set_x_virtual(q, g, xsrc, x_dtype); };
+    // t1 = K * (a3 x) + a2 x
+    if (xpadded) set_in_padded(p, g, xpadded); else set_in_virtual(p, g, xsrc, x_dtype);
+    set_x(p); set_out_padded(p, g, t1);
+    p.scale = a3; p.coef = a2;
+    int rc = pb_launch_conv(ctx, p);
+    if (rc) return rc;
+    // t2 = K * t1 + a1 x
+    set_in_padded(p, g, t1); set_out_padded(p, g, t2);
+    p.scale = 1.f; p.coef = a1;
+    rc = pb_launch_conv(ctx, p);
+    if (rc) return rc;
+    // y = K * t2 + beta x   (only the crop is needed)
+    set_in_padded(p, g, t2); set_out_interior(p, g, dst, dst_dtype);
+    p.coef = beta; p.clamp01 = clamp01;
+    return pb_launch_conv(ctx, p);
+}
+
+struct InverseScratch {
+    float *t1, *t2, *y, *ox, *nM;
+};
+
+// src: what gets deconvolved (cur, or the smooth component).  dst: (B,C,H,W) of dst_dtype.
+int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype, void *dst, int dst_dtype,
+                   const pb_blur_info *info, float alpha, float beta, int boundary, int edgetaping, int remove_halo,
+                   const float *g0x, const float *g0y, const float *nM, int final_clamp, int force_full) {
+    float *t1 = static_cast<float *>(pb_scratch(ctx, "inv.t1", sizeof(float) * g.P * g.pplane));
+    float *t2 = static_cast<float *>(pb_scratch(ctx, "inv.t2", sizeof(float) * g.P * g.pplane));
+    if (!t1 || !t2) return PB_ERR_NOMEM;
+    const float *xpadded = nullptr;
+    if (edgetaping) {
+        float *pa = static_cast<float *>(pb_scratch(ctx, "inv.pa", sizeof(float) * g.P * g.pplane));
+        if (!pa) return PB_ERR_NOMEM;
+        float *res = nullptr;
+        int rc = run_edgetaper(ctx, g, src, src_dtype, info, boundary, pa, t1, &res);   // t1 is free until the polynomial
+        if (rc) return rc;
+        xpadded = res;
+    }
+    if (!remove_halo)
+        return run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, dst, dst_dtype,
+                              final_clamp, force_full);
+    float *y = static_cast<float *>(pb_scratch(ctx, "inv.y", sizeof(float) * g.P * g.HW));
+    float *ox = static_cast<float *>(pb_scratch(ctx, "inv.ox", sizeof(float) * g.P * g.HW));
+    if (!y || !ox) return PB_ERR_NOMEM;
+    int rc = run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, y, PB_F32, 0, force_full);
+    if (rc) return rc;
+    rc = pb_fourier_gradients_impl(ctx, y, g.P, g.H, g.W, ox, nullptr);     // only gout_x is used (deblurring.py:174)
+    if (rc) return rc;
+    if (xpadded)
+        return pb_halo_apply(ctx, xpadded + (long)PB_PAD * g.pp + PB_PAD, PB_F32, g.pp, g.pplane, y, g0x, g0y, ox, nM, dst,
+                             dst_dtype, g.P, g.H, g.W, final_clamp);
+    return pb_halo_apply(ctx, src, src_dtype, g.W, g.HW, y, g0x, g0y, ox, nM, dst, dst_dtype, g.P, g.H, g.W, final_clamp);
+}
+
+int check_shape(pb_ctx *ctx, int dtype, int B, int C, int H, int W) {
+    if (!ctx) return PB_ERR_BADARG;
+    if (dtype != PB_F32 && dtype != PB_F16) return pb_fail(ctx, PB_ERR_BADARG, "dtype must be PB_F32 or PB_F16");
+    if (B < 1 || C < 1 || H < 2 || W < 2) return pb_fail(ctx, PB_ERR_BADARG, "bad shape (%d,%d,%d,%d)", B, C, H, W);
+    return PB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pb_estimate_blur(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, const pb_options *opt,
+                     pb_blur_info *dev_info) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!in || !opt || !dev_info) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_estimate_impl(ctx, in, dtype, B, C, H, W, opt, dev_info);
+}
+
+int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *host_rho, const float *host_theta_rad,
+                    int support, pb_blur_info *dev_info) {
+    if (!ctx || B < 1 || !host_sigma || !host_rho || !host_theta_rad || !dev_info) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    std::vector<pb_blur_info> h(B);
+    memset(h.data(), 0, sizeof(pb_blur_info) * B);
+    for (int i = 0; i < B; ++i) { h[i].sigma = host_sigma[i]; h[i].rho = host_rho[i]; h[i].theta = host_theta_rad[i]; }
+    PB_HIP(hipMemcpyAsync(dev_info, h.data(), sizeof(pb_blur_info) * B, hipMemcpyHostToDevice, ctx->stream));
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    return pb_make_kernels_dev(ctx, B, dev_info, support, 0);
+}
+
+int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_blur_info *dev_info) {
+    if (!ctx || B < 1 || !host_taps || !dev_info) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    std::vector<pb_blur_info> h(B);
+    memset(h.data(), 0, sizeof(pb_blur_info) * B);
+    for (int i = 0; i < B; ++i) memcpy(h[i].kernel, host_taps + (size_t)i * PB_KSIZE * PB_KSIZE, sizeof(float) * PB_KSIZE * PB_KSIZE);
+    PB_HIP(hipMemcpyAsync(dev_info, h.data(), sizeof(pb_blur_info) * B, hipMemcpyHostToDevice, ctx->stream));
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    return pb_make_kernels_dev(ctx, B, dev_info, support, 1);
+}
+
+int pb_fourier_gradients(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy) {
+    if (!ctx || !planes) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_fourier_gradients_impl(ctx, planes, P, H, W, gx, gy);
+}
+
+int pb_inverse_filter(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
+                      const pb_blur_info *dev_info, float alpha, float beta, int boundary, int edgetaping,
+                      int remove_halo, const float *grad0_x, const float *grad0_y) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!in || !out || !dev_info) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
+    if (remove_halo && (!grad0_x || !grad0_y)) return pb_fail(ctx, PB_ERR_BADARG, "remove_halo needs grad0_x / grad0_y");
+    PB_HIP(hipSetDevice(ctx->device));
+    const Geometry g = geometry(B, C, H, W);
+    float *nM = nullptr;
+    if (remove_halo) {
+        nM = static_cast<float *>(pb_scratch(ctx, "inv.nM", sizeof(float) * g.P));
+        if (!nM) return PB_ERR_NOMEM;
+        rc = pb_grad_energy(ctx, grad0_x, grad0_y, nM, g.P, g.HW);
+        if (rc) return rc;
+    }
+    return inverse_filter(ctx, g, in, dtype, out, dtype, dev_info, alpha, beta, boundary, edgetaping, remove_halo, grad0_x,
+                          grad0_y, nM, 1, 0);
+}
+
+int pb_convolve2d(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp, int Wp, const pb_blur_info *dev_info,
+                  int boundary) {
+    if (!ctx || !in || !out || !dev_info || Hp <= 2 * PB_PAD || Wp <= 2 * PB_PAD) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    // The given image IS the padded domain: address it as a padded source with pitch Wp.
+    Geometry g = geometry(B, C, Hp - 2 * PB_PAD, Wp - 2 * PB_PAD);
+    g.pp = Wp; g.pplane = (long)Hp * Wp;
+    ConvPass p = base_pass(g, dev_info, boundary, 0);
+    set_in_padded(p, g, in); set_x_padded(p, g, in); set_out_padded(p, g, out);
+    p.scale = 1.f; p.coef = 0.f;
+    return pb_launch_conv(ctx, p);
+}
+
+int pb_edgetaper(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp, int Wp, const pb_blur_info *dev_info,
+                 int boundary) {
+    if (!ctx || !in || !out || !dev_info || Hp <= 2 * PB_PAD || Wp <= 2 * PB_PAD) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    Geometry g = geometry(B, C, Hp - 2 * PB_PAD, Wp - 2 * PB_PAD);
+    g.pp = Wp; g.pplane = (long)Hp * Wp;
+    float *tmp = static_cast<float *>(pb_scratch(ctx, "taper.tmp", sizeof(float) * g.P * g.pplane));
+    if (!tmp) return PB_ERR_NOMEM;
+    ConvPass p = base_pass(g, dev_info, boundary, 0);
+    p.epilogue = EPI_TAPER;
+    set_in_padded(p, g, in); set_x_padded(p, g, in); set_out_padded(p, g, out);
+    int rc = pb_launch_conv(ctx, p);
+    if (rc) return rc;
+    set_in_padded(p, g, out); set_x_padded(p, g, out); set_out_padded(p, g, tmp);
+    rc = pb_launch_conv(ctx, p);
+    if (rc) return rc;
+    set_in_padded(p, g, tmp); set_x_padded(p, g, tmp); set_out_padded(p, g, out);
+    return pb_launch_conv(ctx, p);
+}
+
+int pb_halo_mask(pb_ctx *ctx, const float *x, const float *y, const float *grad0_x, const float *grad0_y, float *out,
+                 int B, int C, int H, int W) {
+    if (!ctx || !x || !y || !grad0_x || !grad0_y || !out) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    const Geometry g = geometry(B, C, H, W);
+    float *nM = static_cast<float *>(pb_scratch(ctx, "inv.nM", sizeof(float) * g.P));
+    float *ox = static_cast<float *>(pb_scratch(ctx, "inv.ox", sizeof(float) * g.P * g.HW));
+    if (!nM || !ox) return PB_ERR_NOMEM;
+    int rc = pb_grad_energy(ctx, grad0_x, grad0_y, nM, g.P, g.HW);
+    if (rc) return rc;
+    rc = pb_fourier_gradients_impl(ctx, y, g.P, H, W, ox, nullptr);
+    if (rc) return rc;
+    return pb_halo_apply(ctx, x, PB_F32, W, g.HW, y, grad0_x, grad0_y, ox, nM, out, PB_F32, g.P, H, W, 0);
+}
+
+int pb_dt_recursive_filter(pb_ctx *ctx, const void *in, const void *joint, void *out, int dtype, int B, int C, int H,
+                           int W, float sigma_s, float sigma_r, int num_iterations) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!in || !out || num_iterations < 1) return pb_fail(ctx, PB_ERR_BADARG, "bad argument");
+    PB_HIP(hipSetDevice(ctx->device));
+    const long n = (long)B * C * H * W;
+    if (dtype == PB_F32) return pb_dt_filter_impl(ctx, in, joint, dtype, static_cast<float *>(out), B, C, H, W, sigma_s, sigma_r, num_iterations);
+    float *tmp = static_cast<float *>(pb_scratch(ctx, "dt.out", sizeof(float) * n));
+    if (!tmp) return PB_ERR_NOMEM;
+    rc = pb_dt_filter_impl(ctx, in, joint, dtype, tmp, B, C, H, W, sigma_s, sigma_r, num_iterations);
+    if (rc) return rc;
+    return pb_convert_from_float(ctx, tmp, out, dtype, n);
+}
+
+int pb_bilateral5(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!in || !out) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_bilateral5_impl(ctx, in, dtype, out, dtype, B * C, H, W);
+}
+
+// ---------------------------------------------------------------------------------------------
+// polyblur_deblurring (deblurring.py:23-96)
+// ---------------------------------------------------------------------------------------------
+int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
+                      const pb_options *opt, pb_blur_info *host_info) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!in || !out || !opt) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
+    if (in == out) return pb_fail(ctx, PB_ERR_BADARG, "out may not alias in");
+    if (opt->n_iter < 0) return pb_fail(ctx, PB_ERR_BADARG, "n_iter < 0");
+    if (opt->boundary != PB_WRAP && opt->boundary != PB_ZERO) return pb_fail(ctx, PB_ERR_BADARG, "bad boundary");
+    PB_HIP(hipSetDevice(ctx->device));
+    const Geometry g = geometry(B, C, H, W);
+    const long n = (long)g.P * g.HW;
+    const int n_iter = opt->n_iter;
+    if (n_iter == 0) {
+        PB_HIP(hipMemcpyAsync(out, in, dsize(dtype) * n, hipMemcpyDeviceToDevice, ctx->stream));
+        return PB_OK;
+    }
+    pb_blur_info *infos = static_cast<pb_blur_info *>(pb_scratch(ctx, "pipe.info", sizeof(pb_blur_info) * (size_t)n_iter * B));
+    if (!infos) return PB_ERR_NOMEM;
+    void *tmpimg = nullptr;
+    if (n_iter > 1) {
+        tmpimg = pb_scratch(ctx, "pipe.img", dsize(dtype) * n);
+        if (!tmpimg) return PB_ERR_NOMEM;
+    }
+    // gradients of the ORIGINAL image, used by halo masking in every iteration (deblurring.py:61,83)
+    float *g0x = nullptr, *g0y = nullptr, *nM = nullptr;
+    if (opt->remove_halo) {
+        g0x = static_cast<float *>(pb_scratch(ctx, "pipe.g0x", sizeof(float) * n));
+        g0y = static_cast<float *>(pb_scratch(ctx, "pipe.g0y", sizeof(float) * n));
+        nM = static_cast<float *>(pb_scratch(ctx, "inv.nM", sizeof(float) * g.P));
+        if (!g0x || !g0y || !nM) return PB_ERR_NOMEM;
+        const float *in32 = static_cast<const float *>(in);
+        if (dtype != PB_F32) {
+            float *conv = static_cast<float *>(pb_scratch(ctx, "pipe.in32", sizeof(float) * n));
+            if (!conv) return PB_ERR_NOMEM;
+            rc = pb_convert_to_float(ctx, in, dtype, conv, n);
+            if (rc) return rc;
+            in32 = conv;
+        }
+        rc = pb_fourier_gradients_impl(ctx, in32, g.P, H, W, g0x, g0y);
+        if (rc) return rc;
+        rc = pb_grad_energy(ctx, g0x, g0y, nM, g.P, g.HW);
+        if (rc) return rc;
+    }
+    float *smooth = nullptr, *ybuf = nullptr;
+    if (opt->prefilter != PB_PREFILTER_NONE) {
+        smooth = static_cast<float *>(pb_scratch(ctx, "pipe.smooth", sizeof(float) * n));
+        ybuf = static_cast<float *>(pb_scratch(ctx, "pipe.y", sizeof(float) * n));
+        if (!smooth || !ybuf) return PB_ERR_NOMEM;
+    }
+    const void *cur = in;
+    const int force_full = (opt->support & 15) == PB_SUPPORT_FULL;
+    for (int it = 0; it < n_iter; ++it) {
+        // the last iteration must land in `out`; alternate between out and tmpimg before that
+        void *dst = ((n_iter - 1 - it) % 2 == 0) ? out : tmpimg;
+        pb_blur_info *info = infos + (size_t)it * B;
+        rc = pb_estimate_impl(ctx, cur, dtype, B, C, H, W, opt, info);
+        if (rc) return rc;
+        if (opt->prefilter == PB_PREFILTER_NONE) {
+            rc = inverse_filter(ctx, g, cur, dtype, dst, dtype, info, opt->alpha, opt->beta, opt->boundary,
+                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1, force_full);
+            if (rc) return rc;
+        } else {
+            if (opt->prefilter == PB_PREFILTER_BILATERAL)
+                rc = pb_bilateral5_impl(ctx, cur, dtype, smooth, PB_F32, g.P, H, W);
+            else
+                rc = pb_dt_filter_impl(ctx, cur, nullptr, dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
+            if (rc) return rc;
+            rc = inverse_filter(ctx, g, smooth, PB_F32, ybuf, PB_F32, info, opt->alpha, opt->beta, opt->boundary,
+                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1, force_full);
+            if (rc) return rc;
+            rc = pb_recombine(ctx, ybuf, cur, smooth, dst, dtype, n);
+            if (rc) return rc;
+        }
+        cur = dst;
+    }
+    if (host_info) {
+        PB_HIP(hipMemcpyAsync(host_info, infos, sizeof(pb_blur_info) * (size_t)n_iter * B, hipMemcpyDeviceToHost, ctx->stream));
+        PB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PB_OK;
+}
+
+int pb_time_inner_loop(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
+                       const pb_blur_info *dev_info, float alpha, float beta, int boundary, int reps, float *host_ms) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!in || !out || !dev_info || reps < 1 || !host_ms) return pb_fail(ctx, PB_ERR_BADARG, "bad argument");
+    PB_HIP(hipSetDevice(ctx->device));
+    const Geometry g = geometry(B, C, H, W);
+    float *t1 = static_cast<float *>(pb_scratch(ctx, "inv.t1", sizeof(float) * g.P * g.pplane));
+    float *t2 = static_cast<float *>(pb_scratch(ctx, "inv.t2", sizeof(float) * g.P * g.pplane));
+    if (!t1 || !t2) return PB_ERR_NOMEM;
+    rc = run_polynomial(ctx, g, in, dtype, nullptr, dev_info, alpha, beta, boundary, t1, t2, out, dtype, 1, 0);   // warm
+    if (rc) return rc;
+    PB_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r) {
+        rc = run_polynomial(ctx, g, in, dtype, nullptr, dev_info, alpha, beta, boundary, t1, t2, out, dtype, 1, 0);
+        if (rc) return rc;
+    }
+    PB_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    PB_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PB_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *host_ms = ms / reps;
+    return PB_OK;
+}
+
+}  // extern "C"

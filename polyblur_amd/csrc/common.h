@@ -1,0 +1,121 @@
+// Internal declarations shared by the HIP translation units of libpolyblur_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/polyblur_hip.h"
+
+#define PB_PAD PB_KRAD
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+struct FftPlan {
+    int n = 0;
+    int nstage = 0;
+    int radix[24];
+    int bluestein_m = 0;          // 0: direct mixed-radix; else the power-of-two length used
+    float2 *tw = nullptr;         // W_n^m (or W_m^m for bluestein), m = 0..n-1
+    float *drev = nullptr;        // derivative multiplier in digit-reversed order, / n
+    // bluestein extras
+    float2 *chirp = nullptr;      // w[n] = exp(+i pi n^2 / N), n = 0..N-1
+    float2 *bfilt_rev = nullptr;  // FFT_M(b) in digit-reversed order, / M
+    float *dnat = nullptr;        // derivative multiplier in natural order, / N
+};
+
+struct ScratchBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct pb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, ScratchBuf> scratch;
+    std::map<int, FftPlan> plans;
+    float *interp_w = nullptr;     // (n_interp x (n_angles+1)) Keys weights
+    int interp_na = 0, interp_ni = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);
+void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes);   // nullptr on failure (error set)
+const FftPlan *pb_get_plan(pb_ctx *ctx, int n);
+const float *pb_get_interp_weights(pb_ctx *ctx, int n_angles, int n_interp);
+
+#define PB_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return pb_fail(ctx, PB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define PB_LAUNCH_CHECK()                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess)                                                                 \
+            return pb_fail(ctx, PB_ERR_HIP, "kernel launch failed: %s (%s:%d)",               \
+                           hipGetErrorString(e_), __FILE__, __LINE__);                        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// stencil pass (conv.hip)
+// ------------------------------------------------------------------------------------
+enum { SRC_VIRTUAL = 0,   // an un-padded H x W plane addressed in padded coordinates (replicate pad by index clamp)
+       SRC_PADDED = 1 };  // a materialised Hp x Wp plane
+enum { OUT_INTERIOR = 0,  // write the H x W crop into an un-padded plane
+       OUT_PADDED = 1 };  // write the whole Hp x Wp domain
+enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
+       EPI_TAPER = 1 };   // out = a * x + (1-a) * (K*in),  a = v1[py] * v2[px]
+
+struct ConvPass {
+    const void *in;  int in_kind;  int in_dtype;  int in_pitch;  long in_plane;
+    const void *x;   int x_kind;   int x_dtype;   int x_pitch;   long x_plane;
+    void *out;       int out_kind; int out_dtype; int out_pitch; long out_plane;
+    int H, W;            // un-padded size; Hp = H + 2*PB_PAD, Wp = W + 2*PB_PAD
+    int C;               // planes per image
+    int P;               // number of planes (B*C)
+    const pb_blur_info *info;
+    float scale, coef;
+    int boundary;
+    int epilogue;
+    int clamp01;
+    int force_full;      // ignore info->radius, evaluate all 25 taps
+};
+
+int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
+
+// ------------------------------------------------------------------------------------
+// estimation (estimate.hip)
+// ------------------------------------------------------------------------------------
+int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W,
+                     const pb_options *opt, pb_blur_info *dev_info);
+int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy);
+int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps);
+
+// ------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float pb_ld(const T *p);
+template <> __device__ __forceinline__ float pb_ld<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float pb_ld<__half>(const __half *p) { return __half2float(*p); }
+template <typename T> __device__ __forceinline__ void pb_st(T *p, float v);
+template <> __device__ __forceinline__ void pb_st<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void pb_st<__half>(__half *p, float v) { *p = __float2half_rn(v); }
+
+// order-preserving float <-> uint encoding for atomicMin/atomicMax on floats
+__device__ __forceinline__ unsigned pb_f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float pb_ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}

@@ -1,0 +1,616 @@
+// Blur estimation on the device (reference blur_estimation.py:18-79) and the spectral image
+// gradient it is built on (filters.py:159-186).
+//
+//   gray_minmax_kernel   imgc.mean(dim=1) + amin/amax           blur_estimation.py:36-37,107-108
+//   grad_rows_kernel     d/dx by row-wise spectral derivative    filters.py:172-181 (+ normalize :92-109)
+//   grad_cols_kernel     d/dy by column-wise spectral derivative filters.py:182-184,
+//                        fused with the directional maxima       blur_estimation.py:122-134
+//                        and the saturation mask                 blur_estimation.py:83-88,117-118
+//   blur_params_kernel   cubic interpolation, argmin, affine model, 25x25 Gaussian
+//                                                                blur_estimation.py:138-232
+// Everything stays on the stream: no host synchronisation between stages.
+#include <cmath>
+
+#include "common.h"
+#include "fft.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------------
+// FFT plans (host)
+// ------------------------------------------------------------------------------------
+static void factorize(int n, std::vector<int> &radix, int &rest) {
+    radix.clear();
+    while (n % 4 == 0) { radix.push_back(4); n /= 4; }
+    while (n % 2 == 0) { radix.push_back(2); n /= 2; }
+    while (n % 3 == 0) { radix.push_back(3); n /= 3; }
+    while (n % 5 == 0) { radix.push_back(5); n /= 5; }
+    while (n % 7 == 0) { radix.push_back(7); n /= 7; }
+    rest = n;
+}
+
+// frequency index held at position p after the DIF stages
+static int digit_reversed_freq(int p, int n, const std::vector<int> &radix) {
+    int k = 0, weight = 1, stride = n;
+    for (int r : radix) {
+        stride /= r;
+        const int digit = p / stride;
+        p -= digit * stride;
+        k += digit * weight;
+        weight *= r;
+    }
+    return k;
+}
+
+static double deriv_freq(int k, int n) {
+    // filters.py:175-176 in un-shifted order, Nyquist bin dropped (see fft.h)
+    if (n % 2 == 0 && k == n / 2) return 0.0;
+    return (k <= (n - 1) / 2) ? (double)k / n : (double)(k - n) / n;
+}
+
+template <typename T> static T *upload(pb_ctx *ctx, const std::vector<T> &h) {
+    T *d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(T)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    (void)ctx;
+    return d;
+}
+
+}  // namespace
+
+const FftPlan *pb_get_plan(pb_ctx *ctx, int n) {
+    auto it = ctx->plans.find(n);
+    if (it != ctx->plans.end()) return &it->second;
+    FftPlan pl;
+    pl.n = n;
+    std::vector<int> radix;
+    int rest = 1;
+    factorize(n, radix, rest);
+    const double two_pi = 6.283185307179586476925286766559;
+    int core = n;
+    if (rest != 1) {               // Bluestein with a power-of-two core
+        core = 1;
+        while (core < 2 * n - 1) core *= 2;
+        pl.bluestein_m = core;
+        factorize(core, radix, rest);
+    }
+    if ((int)radix.size() > 24) { pb_fail(ctx, PB_ERR_UNSUPPORTED, "fft length %d: too many stages", n); return nullptr; }
+    pl.nstage = (int)radix.size();
+    for (int i = 0; i < pl.nstage; ++i) pl.radix[i] = radix[i];
+    std::vector<float2> tw(core);
+    for (int m = 0; m < core; ++m) {
+        const double a = -two_pi * m / core;
+        tw[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    pl.tw = upload(ctx, tw);
+    bool ok = pl.tw != nullptr;
+    if (!pl.bluestein_m) {
+        std::vector<float> drev(n);
+        for (int p = 0; p < n; ++p) drev[p] = (float)(two_pi * deriv_freq(digit_reversed_freq(p, n, radix), n) / n);
+        pl.drev = upload(ctx, drev);
+        ok = ok && pl.drev;
+    } else {
+        const int M = core;
+        std::vector<float2> chirp(n);
+        std::vector<double> cre(n), cim(n);
+        for (int k = 0; k < n; ++k) {
+            const long long k2 = ((long long)k * k) % (2LL * n);
+            const double a = two_pi * 0.5 * (double)k2 / n;
+            cre[k] = std::cos(a); cim[k] = std::sin(a);
+            chirp[k] = make_float2((float)cre[k], (float)cim[k]);
+        }
+        // filter b_M[m] = w[|m|] wrapped; its DFT in double (O(M log M) not needed: direct O(M*N) is fine
+        // for a one-off plan, but keep it cheap with a simple radix-2 recursion-free FFT)
+        std::vector<double> br(M, 0.0), bi(M, 0.0);
+        for (int m = 0; m < n; ++m) {
+            br[m] = cre[m]; bi[m] = cim[m];
+            if (m) { br[M - m] = cre[m]; bi[M - m] = cim[m]; }
+        }
+        // iterative radix-2 FFT (M is a power of two)
+        for (int i = 1, j = 0; i < M; ++i) {
+            int bit = M >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+        }
+        for (int len = 2; len <= M; len <<= 1) {
+            const double ang = -two_pi / len;
+            for (int i = 0; i < M; i += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+                    const int a = i + k, b = i + k + len / 2;
+                    const double xr = br[b] * wr - bi[b] * wi, xi = br[b] * wi + bi[b] * wr;
+                    br[b] = br[a] - xr; bi[b] = bi[a] - xi;
+                    br[a] += xr; bi[a] += xi;
+                }
+        }
+        std::vector<float2> brev(M);
+        for (int p = 0; p < M; ++p) {
+            const int k = digit_reversed_freq(p, M, radix);
+            brev[p] = make_float2((float)(br[k] / M), (float)(bi[k] / M));
+        }
+        std::vector<float> dnat(n);
+        for (int k = 0; k < n; ++k) dnat[k] = (float)(two_pi * deriv_freq(k, n) / n);
+        pl.chirp = upload(ctx, chirp);
+        pl.bfilt_rev = upload(ctx, brev);
+        pl.dnat = upload(ctx, dnat);
+        ok = ok && pl.chirp && pl.bfilt_rev && pl.dnat;
+    }
+    if (!ok) { pb_fail(ctx, PB_ERR_NOMEM, "fft plan %d: device allocation failed", n); return nullptr; }
+    auto res = ctx->plans.emplace(n, pl);
+    return &res.first->second;
+}
+
+const float *pb_get_interp_weights(pb_ctx *ctx, int n_angles, int n_interp) {
+    if (ctx->interp_w && ctx->interp_na == n_angles && ctx->interp_ni == n_interp) return ctx->interp_w;
+    if (ctx->interp_w) { (void)hipFree(ctx->interp_w); ctx->interp_w = nullptr; }
+    // Keys cubic weights exactly as blur_estimation.py:138-147 evaluates them in fp32:
+    // both angle grids are truncated to integers (deblurring.py:62-63) and divided by N.
+    const int na = n_angles + 1;
+    std::vector<float> w((size_t)n_interp * na);
+    for (int i = 0; i < n_interp; ++i) {
+        const float xn = (float)(long)((double)i * (180.0 / n_interp)) / (float)n_interp;
+        float sum = 0.f;
+        for (int k = 0; k < na; ++k) {
+            const float xo = (float)(long)(180.0 * k / n_angles) / (float)n_interp;
+            const float d = std::fabs(xn - xo);
+            float v = 0.f;
+            if (d < 1.f) v = (1.5f * d - 2.5f) * d * d + 1.f;
+            else if (d < 2.f) v = ((-0.5f * d + 2.5f) * d - 4.f) * d + 2.f;
+            w[(size_t)i * na + k] = v;
+            sum += v;
+        }
+        for (int k = 0; k < na; ++k) w[(size_t)i * na + k] /= (sum + 1e-5f);
+    }
+    ctx->interp_w = upload(ctx, w);
+    if (!ctx->interp_w) { pb_fail(ctx, PB_ERR_NOMEM, "interp weights: allocation failed"); return nullptr; }
+    ctx->interp_na = n_angles;
+    ctx->interp_ni = n_interp;
+    return ctx->interp_w;
+}
+
+namespace {
+
+pbfft::DevPlan dev_plan(const FftPlan *pl) {
+    pbfft::DevPlan d;
+    d.line_n = pl->n;
+    d.n = pl->bluestein_m ? pl->bluestein_m : pl->n;
+    d.nstage = pl->nstage;
+    for (int i = 0; i < 24; ++i) d.radix[i] = i < pl->nstage ? pl->radix[i] : 1;
+    d.tw = pl->tw;
+    d.drev = pl->drev;
+    d.chirp = pl->chirp;
+    d.bfilt_rev = pl->bfilt_rev;
+    d.dnat = pl->dnat;
+    return d;
+}
+
+// ------------------------------------------------------------------------------------
+// gray + min/max
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void gray_minmax_kernel(const T *__restrict__ in, float *__restrict__ gray,
+                                                         unsigned *__restrict__ mm, int C, long HW, int blocks_per_image) {
+    const int b = blockIdx.x / blocks_per_image;
+    const int blk = blockIdx.x - b * blocks_per_image;
+    const T *src = in + (long)b * C * HW;
+    float *dst = gray + (long)b * HW;
+    float lo = INFINITY, hi = -INFINITY;
+    const float invc = 1.f / (float)C;
+    for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)blocks_per_image * NT) {
+        float s = pb_ld(src + i);
+        for (int c = 1; c < C; ++c) s += pb_ld(src + c * HW + i);
+        const float g = (C == 1) ? s : ((C == 3) ? s / 3.0f : s * invc);
+        dst[i] = g;
+        lo = fminf(lo, g);
+        hi = fmaxf(hi, g);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    __shared__ float slo[NT / 64], shi[NT / 64];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NT / 64; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+        atomicMin(mm + 2 * b, pb_f2ord(lo));
+        atomicMax(mm + 2 * b + 1, pb_f2ord(hi));
+    }
+}
+
+__global__ void init_minmax_kernel(unsigned *mm, unsigned *mags, int B, int na) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { mm[2 * i] = 0xffffffffu; mm[2 * i + 1] = 0u; }
+    if (i < B * na) mags[i] = 0u;
+}
+
+// ------------------------------------------------------------------------------------
+// spectral derivative along rows: one workgroup = two rows packed as one complex line
+// ------------------------------------------------------------------------------------
+// NORMALIZE: lines are range-normalised on load with the per-image (lo, hi) in mm
+// (blur_estimation.py:92-93); planes_per_image maps a plane to its image's min/max.
+template <bool NORMALIZE>
+__global__ __launch_bounds__(NT) void grad_rows_kernel(const float *__restrict__ planes, float *__restrict__ gx,
+                                                       int H, int W, const unsigned *__restrict__ mm,
+                                                       int planes_per_image, pbfft::DevPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float2 sfft[];
+    const int pairs = (H + 1) / 2;
+    const int plane = blockIdx.x / pairs;
+    const int r0 = 2 * (blockIdx.x - plane * pairs);
+    const bool has1 = r0 + 1 < H;
+    const float *row0 = planes + ((long)plane * H + r0) * W;
+    const float *row1 = row0 + W;
+    float lo = 0.f, scale = 1.f;
+    if (NORMALIZE) {
+        const int img = plane / planes_per_image;
+        lo = pb_ord2f(mm[2 * img]);
+        scale = pb_ord2f(mm[2 * img + 1]) - lo;
+    }
+    for (int n = threadIdx.x; n < W; n += NT) {
+        float a = row0[n], b = has1 ? row1[n] : 0.f;
+        if (NORMALIZE) {
+            a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
+            b = has1 ? fminf(fmaxf((b - lo) / scale, 0.f), 1.f) : 0.f;
+        }
+        sfft[n] = make_float2(a, b);
+    }
+    __syncthreads();
+    pbfft::spectral_derivative(sfft, plan, 0);
+    float *o0 = gx + ((long)plane * H + r0) * W;
+    for (int n = threadIdx.x; n < W; n += NT) {
+        const float2 v = sfft[n];
+        o0[n] = v.x;
+        if (has1) o0[W + n] = -v.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// spectral derivative along columns: one workgroup = 2*NB adjacent columns (NB complex lines)
+// MODE 0: write gy.  MODE 1: fuse the directional maxima (needs gx of the same plane).
+// ------------------------------------------------------------------------------------
+template <int MODE, bool NORMALIZE>
+__global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__ planes, const float *__restrict__ gx,
+                                                       float *__restrict__ gy, int H, int W, int lognb,
+                                                       const unsigned *__restrict__ mm, int planes_per_image,
+                                                       unsigned *__restrict__ mags, int n_angles, int discard_sat,
+                                                       float sat_threshold, pbfft::DevPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float2 sfft[];
+    const int nb = 1 << lognb;
+    const int tc = 2 * nb;
+    const int tiles = (W + tc - 1) / tc;
+    const int plane = blockIdx.x / tiles;
+    const int c0 = (blockIdx.x - plane * tiles) * tc;
+    const float *src = planes + (long)plane * H * W;
+    float lo = 0.f, scale = 1.f;
+    if (NORMALIZE) {
+        const int img = plane / planes_per_image;
+        lo = pb_ord2f(mm[2 * img]);
+        scale = pb_ord2f(mm[2 * img + 1]) - lo;
+    }
+    // element e = p*nb + j  <->  row p, columns c0+2j, c0+2j+1
+    for (int e = threadIdx.x; e < (H << lognb); e += NT) {
+        const int p = e >> lognb, j = e & (nb - 1);
+        const int c = c0 + 2 * j;
+        float a = 0.f, b = 0.f;
+        if (c < W) a = src[(long)p * W + c];
+        if (c + 1 < W) b = src[(long)p * W + c + 1];
+        if (NORMALIZE) {
+            a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
+            b = fminf(fmaxf((b - lo) / scale, 0.f), 1.f);
+        }
+        sfft[e] = make_float2(a, b);
+    }
+    __syncthreads();
+    pbfft::spectral_derivative(sfft, plan, lognb);
+    if (MODE == 0) {
+        float *dst = gy + (long)plane * H * W;
+        for (int e = threadIdx.x; e < (H << lognb); e += NT) {
+            const int p = e >> lognb, j = e & (nb - 1);
+            const int c = c0 + 2 * j;
+            const float2 v = sfft[e];
+            if (c < W) dst[(long)p * W + c] = v.x;
+            if (c + 1 < W) dst[(long)p * W + c + 1] = -v.y;
+        }
+    } else {
+        // m_k = max |cos(t_k) gx - sin(t_k) gy|, t_k = k pi / n_angles  (blur_estimation.py:129-133)
+        float cs[PB_MAX_ANGLES], sn[PB_MAX_ANGLES], best[PB_MAX_ANGLES];
+#pragma unroll
+        for (int k = 0; k < PB_MAX_ANGLES; ++k) {
+            const float t = 3.14159265358979323846f * (float)k / (float)n_angles;
+            cs[k] = cosf(t); sn[k] = sinf(t); best[k] = 0.f;
+        }
+        const float *gxp = gx + (long)plane * H * W;
+        for (int e = threadIdx.x; e < (H << lognb); e += NT) {
+            const int p = e >> lognb, j = e & (nb - 1);
+            const int c = c0 + 2 * j;
+            const float2 v = sfft[e];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (c + h >= W) continue;
+                const long idx = (long)p * W + c + h;
+                if (discard_sat && src[idx] > sat_threshold) continue;   // gradients zeroed under the mask
+                const float dx = gxp[idx];
+                const float dy = h ? -v.y : v.x;
+#pragma unroll
+                for (int k = 0; k < PB_MAX_ANGLES; ++k)
+                    if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(cs[k] * dx - sn[k] * dy));
+            }
+        }
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(sfft);
+#pragma unroll
+        for (int k = 0; k < PB_MAX_ANGLES; ++k) {
+            float m = best[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * PB_MAX_ANGLES + k] = m;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x <= n_angles) {
+            float m = red[threadIdx.x];
+            for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w * PB_MAX_ANGLES + threadIdx.x]);
+            const int img = plane / planes_per_image;
+            atomicMax(mags + img * PB_MAX_ANGLES + threadIdx.x, __float_as_uint(m));   // m >= 0
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// parameters and kernels
+// ------------------------------------------------------------------------------------
+__device__ float block_sum(float v, float *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < NT / 64; ++w) s += red[w];
+    return s;
+}
+
+// Fills kernel (unless from_taps), marginals, autocorrelations, separability and radius of one
+// record.  Called by all NT threads of a block.
+__device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red) {
+    const int tid = threadIdx.x;
+    if (!from_taps) {
+        // blur_estimation.py:189-232
+        const float th = -info->theta;
+        const float c = cosf(th), s = sinf(th);
+        const float i1 = 1.f / (info->sigma * info->sigma), i2 = 1.f / (info->rho * info->rho);
+        const float a00 = c * c * i1 + s * s * i2;
+        const float a01 = s * c * (i1 - i2);
+        const float a11 = c * c * i2 + s * s * i1;
+        float e[3];
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + q * NT;
+            e[q] = 0.f;
+            if (idx < PB_KSIZE * PB_KSIZE) {
+                const float Y = (float)(idx / PB_KSIZE - PB_KRAD), X = (float)(idx % PB_KSIZE - PB_KRAD);
+                const float quad = (X * a00 + Y * a01) * X + (X * a01 + Y * a11) * Y;
+                e[q] = expf(-0.5f * quad);
+                part += e[q];
+            }
+        }
+        const float total = block_sum(part, red);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + q * NT;
+            if (idx < PB_KSIZE * PB_KSIZE) info->kernel[idx] = e[q] / total;
+        }
+    }
+    __syncthreads();
+    if (tid < PB_KSIZE) {
+        float sx = 0.f, sy = 0.f;
+        for (int i = 0; i < PB_KSIZE; ++i) {
+            sx += info->kernel[i * PB_KSIZE + tid];     // column sum -> kx[tid]
+            sy += info->kernel[tid * PB_KSIZE + i];     // row sum    -> ky[tid]
+        }
+        info->kx[tid] = sx;
+        info->ky[tid] = sy;
+    }
+    __syncthreads();
+    if (tid < PB_KSIZE) {
+        float ax = 0.f, ay = 0.f;
+        for (int n = 0; n + tid < PB_KSIZE; ++n) {
+            ax += info->kx[n] * info->kx[n + tid];
+            ay += info->ky[n] * info->ky[n + tid];
+        }
+        info->acorr_x[tid] = ax;
+        info->acorr_y[tid] = ay;
+    }
+    // rank-1 residual  sum |k - ky (x) kx|  and the total mass (for arbitrary taps)
+    float res = 0.f;
+    for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT)
+        res += fabsf(info->kernel[idx] - info->ky[idx / PB_KSIZE] * info->kx[idx % PB_KSIZE]);
+    const float resid = block_sum(res, red);
+    if (tid == 0) {
+        info->separable = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL)) ? 1 : 0;
+        int rad = PB_KRAD;
+        if ((support & 15) == PB_SUPPORT_ADAPTIVE) {
+            // smallest radius outside which both marginals carry < 1e-8 of the mass
+            rad = 0;
+            for (int t = 0; t < PB_KSIZE; ++t) {
+                const int d = t > PB_KRAD ? t - PB_KRAD : PB_KRAD - t;
+                if ((fabsf(info->kx[t]) >= 1e-8f || fabsf(info->ky[t]) >= 1e-8f) && d > rad) rad = d;
+            }
+            rad = rad <= 4 ? 4 : (rad <= 8 ? 8 : PB_KRAD);
+        }
+        info->radius = rad;
+    }
+}
+
+__global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, const unsigned *__restrict__ mm,
+                                                         const unsigned *__restrict__ mags_u,
+                                                         const float *__restrict__ wts, int n_angles, int n_interp,
+                                                         float c, float b, int support, float force_theta_deg) {
+    __shared__ float red[NT / 64];
+    pb_blur_info *info = infos + blockIdx.x;
+    if (threadIdx.x == 0) {
+        const int na = n_angles + 1;
+        info->gray_min = pb_ord2f(mm[2 * blockIdx.x]);
+        info->gray_max = pb_ord2f(mm[2 * blockIdx.x + 1]);
+        float mags[PB_MAX_ANGLES];
+        for (int k = 0; k < PB_MAX_ANGLES; ++k) {
+            mags[k] = k < na ? __uint_as_float(mags_u[blockIdx.x * PB_MAX_ANGLES + k]) : 0.f;
+            info->mags[k] = mags[k];
+        }
+        // cubic interpolation to n_interp angles + argmin (blur_estimation.py:156-160)
+        int i_min = 0;
+        float vmin = INFINITY;
+        for (int i = 0; i < PB_MAX_INTERP; ++i) {
+            float v = 0.f;
+            if (i < n_interp) {
+                for (int k = 0; k < na; ++k) v += wts[i * na + k] * mags[k];
+                if (v < vmin) { vmin = v; i_min = i; }
+            }
+            info->interp[i] = v;
+        }
+        const float step = 180.0f / (float)n_interp;
+        int theta_deg = (int)((float)i_min * step);            // interpolated_thetas.long()
+        if (force_theta_deg >= 0.f) {
+            theta_deg = (int)force_theta_deg;
+            i_min = (int)((float)theta_deg / step);
+            vmin = info->interp[i_min];
+        }
+        const int ortho_deg = (theta_deg + 90) % 180;
+        const int i_ortho = (int)((float)ortho_deg / step);
+        const float m_n = vmin, m_o = info->interp[i_ortho];
+        const float cc = c * c, bb = b * b;
+        info->sigma = sqrtf(fminf(fmaxf(cc / (m_n * m_n + 1e-8f) - bb, 0.09f), 16.0f));
+        info->rho = sqrtf(fminf(fmaxf(cc / (m_o * m_o + 1e-8f) - bb, 0.09f), 16.0f));
+        info->theta = (float)theta_deg * 3.14159274101257324f / 180.0f;
+        info->i_min = i_min;
+    }
+    __syncthreads();
+    finish_record(info, support, false, red);
+}
+
+__global__ __launch_bounds__(NT) void make_kernels_kernel(pb_blur_info *infos, int support, int from_taps) {
+    __shared__ float red[NT / 64];
+    finish_record(infos + blockIdx.x, support, from_taps != 0, red);
+}
+
+size_t fft_lds_bytes(const FftPlan *pl, int nb) {
+    const size_t n = pl->bluestein_m ? pl->bluestein_m : pl->n;
+    return n * nb * sizeof(float2);
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <typename K> int allow_lds(pb_ctx *ctx, K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PB_OK;
+}
+
+// choose how many complex lines a column workgroup transforms together
+int pick_lognb(const FftPlan *pl, int W) {
+    int lognb = 3;
+    while (lognb > 0 && fft_lds_bytes(pl, 1 << lognb) > 80 * 1024) --lognb;
+    while (lognb > 0 && (2 << (lognb - 1)) >= W * 2) --lognb;
+    return lognb;
+}
+
+int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
+                const unsigned *mm, int planes_per_image) {
+    const FftPlan *pl = pb_get_plan(ctx, W);
+    if (!pl) return PB_ERR_NOMEM;
+    const size_t lds = fft_lds_bytes(pl, 1);
+    if (lds > kMaxLds) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image width %d too large for the in-LDS FFT", W);
+    const long blocks = (long)P * ((H + 1) / 2);
+    const pbfft::DevPlan dp = dev_plan(pl);
+    if (normalize) {
+        int rc = allow_lds(ctx, grad_rows_kernel<true>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(grad_rows_kernel<true>, dim3((unsigned)blocks), dim3(NT), lds, ctx->stream, planes, gx, H, W, mm, planes_per_image, dp);
+    } else {
+        int rc = allow_lds(ctx, grad_rows_kernel<false>, lds); if (rc) return rc;
+        hipLaunchKernelGGL(grad_rows_kernel<false>, dim3((unsigned)blocks), dim3(NT), lds, ctx->stream, planes, gx, H, W, mm, planes_per_image, dp);
+    }
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, int P, int H, int W, int mode,
+                bool normalize, const unsigned *mm, int planes_per_image, unsigned *mags, int n_angles,
+                int discard_sat) {
+    const FftPlan *pl = pb_get_plan(ctx, H);
+    if (!pl) return PB_ERR_NOMEM;
+    const int lognb = pick_lognb(pl, W);
+    const size_t lds = fft_lds_bytes(pl, 1 << lognb);
+    if (lds > kMaxLds) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image height %d too large for the in-LDS FFT", H);
+    const int tc = 2 << lognb;
+    const long blocks = (long)P * ((W + tc - 1) / tc);
+    const pbfft::DevPlan dp = dev_plan(pl);
+    const float thr = 0.99f;
+#define PB_COLS(MODE, NORM)                                                                                      \
+    do {                                                                                                         \
+        int rc = allow_lds(ctx, grad_cols_kernel<MODE, NORM>, lds);                                              \
+        if (rc) return rc;                                                                                       \
+        hipLaunchKernelGGL((grad_cols_kernel<MODE, NORM>), dim3((unsigned)blocks), dim3(NT), lds, ctx->stream,    \
+                           planes, gx, gy, H, W, lognb, mm, planes_per_image, mags, n_angles, discard_sat, thr, dp); \
+    } while (0)
+    if (mode == 0) { if (normalize) PB_COLS(0, true); else PB_COLS(0, false); }
+    else { if (normalize) PB_COLS(1, true); else PB_COLS(1, false); }
+#undef PB_COLS
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+}  // namespace
+
+int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy) {
+    if (P <= 0 || H < 2 || W < 2) return pb_fail(ctx, PB_ERR_BADARG, "fourier_gradients: bad shape");
+    if (gx) { int rc = launch_rows(ctx, planes, gx, P, H, W, false, nullptr, 1); if (rc) return rc; }
+    if (gy) { int rc = launch_cols(ctx, planes, nullptr, gy, P, H, W, 0, false, nullptr, 1, nullptr, 0, 0); if (rc) return rc; }
+    return PB_OK;
+}
+
+int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, const pb_options *opt,
+                     pb_blur_info *dev_info) {
+    if (opt->q != 0.f) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "quantile normalisation (q > 0) is not implemented");
+    if (opt->n_angles < 1 || opt->n_angles + 1 > PB_MAX_ANGLES || opt->n_interpolated_angles < 1 ||
+        opt->n_interpolated_angles > PB_MAX_INTERP)
+        return pb_fail(ctx, PB_ERR_BADARG, "n_angles / n_interpolated_angles out of range");
+    const long HW = (long)H * W;
+    float *gray = static_cast<float *>(pb_scratch(ctx, "est.gray", sizeof(float) * B * HW));
+    float *gx = static_cast<float *>(pb_scratch(ctx, "est.gx", sizeof(float) * B * HW));
+    unsigned *mm = static_cast<unsigned *>(pb_scratch(ctx, "est.mm", sizeof(unsigned) * (2 * B + (size_t)B * PB_MAX_ANGLES)));
+    if (!gray || !gx || !mm) return PB_ERR_NOMEM;
+    unsigned *mags = mm + 2 * B;
+    const float *wts = pb_get_interp_weights(ctx, opt->n_angles, opt->n_interpolated_angles);
+    if (!wts) return PB_ERR_NOMEM;
+    const int ninit = B * PB_MAX_ANGLES;
+    hipLaunchKernelGGL(init_minmax_kernel, dim3((ninit + 255) / 256), dim3(256), 0, ctx->stream, mm, mags, B, PB_MAX_ANGLES);
+    PB_LAUNCH_CHECK();
+    int bpi = (int)((HW + NT * 8 - 1) / (NT * 8));
+    if (bpi > 1024) bpi = 1024;
+    if (bpi < 1) bpi = 1;
+    if (dtype == PB_F32)
+        hipLaunchKernelGGL(gray_minmax_kernel<float>, dim3(B * bpi), dim3(NT), 0, ctx->stream,
+                           static_cast<const float *>(in), gray, mm, C, HW, bpi);
+    else
+        hipLaunchKernelGGL(gray_minmax_kernel<__half>, dim3(B * bpi), dim3(NT), 0, ctx->stream,
+                           static_cast<const __half *>(in), gray, mm, C, HW, bpi);
+    PB_LAUNCH_CHECK();
+    int rc = launch_rows(ctx, gray, gx, B, H, W, true, mm, 1);
+    if (rc) return rc;
+    rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, true, mm, 1, mags, opt->n_angles, opt->discard_saturation);
+    if (rc) return rc;
+    hipLaunchKernelGGL(blur_params_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
+                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps) {
+    hipLaunchKernelGGL(make_kernels_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, support, from_taps);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}

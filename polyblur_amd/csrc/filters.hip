@@ -1,0 +1,339 @@
+// Optional stages of the hot path:
+//   halo masking                     deblurring.py:172-208   (bug-compatible, see halo_kernel)
+//   domain-transform recursive filter domain_transform.py:6-85, native twin RF.cpp:14-92
+//   5x5 bilateral filter             filters.py:107-148
+//   prefilter recombination          deblurring.py:84,88
+#include "common.h"
+
+int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy);
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------------
+// halo masking
+// ------------------------------------------------------------------------------------
+// nM[plane] = sum_{H,W} gx^2 + gy^2          (deblurring.py:178-179,206)
+__global__ __launch_bounds__(NT) void grad_energy_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                         float *__restrict__ nM, long HW, int blocks_per_plane) {
+    const int plane = blockIdx.x / blocks_per_plane;
+    const int blk = blockIdx.x - plane * blocks_per_plane;
+    const float *a = gx + (long)plane * HW, *b = gy + (long)plane * HW;
+    float s = 0.f;
+    for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)blocks_per_plane * NT) s += a[i] * a[i] + b[i] * b[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ float red[NT / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NT / 64; ++w) t += red[w];
+        atomicAdd(nM + plane, t);
+    }
+}
+
+// M = -gx*ox - gy*gy  (sic: deblurring.py:174 multiplies grad_y by itself, not by gout_y)
+// z = max(M / (nM + M), 0);  out = y + z (x - y)   [+ clamp to [0,1], deblurring.py:239]
+template <typename TX, typename TOut>
+__global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int x_pitch, long x_plane,
+                                                  const float *__restrict__ y, const float *__restrict__ gx,
+                                                  const float *__restrict__ gy, const float *__restrict__ ox,
+                                                  const float *__restrict__ nM, TOut *__restrict__ out, int H, int W,
+                                                  int clamp01) {
+    const int plane = blockIdx.y;
+    const long HW = (long)H * W;
+    const float nm = nM[plane];
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
+        const int r = (int)(i / W), c = (int)(i - (long)r * W);
+        const long k = (long)plane * HW + i;
+        const float gxx = gx[k], gyy = gy[k];
+        const float M = (-gxx * ox[k]) + (-gyy * gyy);
+        const float z = fmaxf(M / (nm + M), 0.f);
+        const float xv = pb_ld(x + (long)plane * x_plane + (long)r * x_pitch + c);
+        const float yv = y[k];
+        float v = yv + z * (xv - yv);
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        pb_st(out + k, v);
+    }
+}
+
+// out = clip(clip(y,0,1) + (cur - smooth), 0, 1)          (deblurring.py:84,88,239)
+template <typename T>
+__global__ __launch_bounds__(NT) void recombine_kernel(const float *__restrict__ y, const T *__restrict__ cur,
+                                                       const float *__restrict__ smooth, T *__restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float d = pb_ld(cur + i) - smooth[i];
+        const float v = fminf(fmaxf(y[i], 0.f), 1.f) + d;
+        pb_st(out + i, fminf(fmaxf(v, 0.f), 1.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// bilateral 5x5
+// ------------------------------------------------------------------------------------
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(NT) void bilateral5_kernel(const TIn *__restrict__ in, TOut *__restrict__ out, int H, int W,
+                                                        float inv_var2_color, float inv_var2_space) {
+    constexpr int TWB = 64, THB = 16, R = 2, LW = TWB + 2 * R, LH = THB + 2 * R;
+    __shared__ float s[LH * LW];
+    const int plane = blockIdx.z;
+    const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB;
+    const TIn *src = in + (long)plane * H * W;
+    for (int e = threadIdx.x; e < LH * LW; e += NT) {
+        const int r = e / LW, c = e - r * LW;
+        const int yy = min(max(y0 + r - R, 0), H - 1), xx = min(max(x0 + c - R, 0), W - 1);   // replicate pad
+        s[e] = pb_ld(src + (long)yy * W + xx);
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TWB, ty0 = threadIdx.x / TWB;       // 4 row phases
+    for (int ty = ty0; ty < THB; ty += NT / TWB) {
+        const int yy = y0 + ty, xx = x0 + tx;
+        if (yy >= H || xx >= W) continue;
+        const float ctr = s[(ty + R) * LW + tx + R];
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float v = s[(ty + i) * LW + tx + j];
+                const float d = v - ctr;
+                const float gw = expf(-(float)((i - 2) * (i - 2) + (j - 2) * (j - 2)) * inv_var2_space);
+                const float w = expf(-d * d * inv_var2_color) * gw;
+                num += w * v;
+                den += w;
+            }
+        pb_st(out + (long)plane * H * W + (long)yy * W + xx, num / (den + 1e-5f));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// domain-transform recursive filter
+// ------------------------------------------------------------------------------------
+// The recurrence F[i] <- F[i] + V[i] (F[i-1] - F[i]) is the affine map F[i] = V[i] F[i-1] + (1-V[i]) x[i].
+// Rows: one wave per (image, row); lanes own 64 consecutive columns and combine their maps with a
+// wave-level inclusive scan (composition of affine maps), carrying the last value between chunks, so
+// every global access is a coalesced 256-B row segment.  Columns: one thread per column walks down
+// and up (adjacent lanes = adjacent columns, already coalesced).
+//
+// dom[i] = 1 + sigma_s/sigma_r * sum_c |J[c][i] - J[c][i-1]| (0 difference at i = 0);  V = a^dom.
+
+template <typename T>
+__global__ __launch_bounds__(NT) void dt_domain_kernel(const T *__restrict__ J, float *__restrict__ domx,
+                                                       float *__restrict__ domy, int C, int H, int W, float ratio) {
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const T *src = J + (long)b * C * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
+        const int r = (int)(i / W), c = (int)(i - (long)r * W);
+        float dx = 0.f, dy = 0.f;
+        for (int ch = 0; ch < C; ++ch) {
+            const float v = pb_ld(src + ch * HW + i);
+            if (c > 0) dx += fabsf(v - pb_ld(src + ch * HW + i - 1));
+            if (r > 0) dy += fabsf(v - pb_ld(src + ch * HW + i - W));
+        }
+        domx[(long)b * HW + i] = 1.f + ratio * dx;
+        domy[(long)b * HW + i] = 1.f + ratio * dy;
+    }
+}
+
+struct Affine { float a, b; };   // f(t) = a t + b
+__device__ __forceinline__ Affine compose(Affine second, Affine first) {   // second(first(t))
+    return Affine{second.a * first.a, fmaf(second.a, first.b, second.b)};
+}
+
+// One horizontal pass (left->right then right->left) over every row of every plane, in place on F.
+__global__ __launch_bounds__(NT) void dt_rows_kernel(float *__restrict__ F, const float *__restrict__ domx, int C, int H,
+                                                     int W, float log_a, long rows_total) {
+    const int lane = threadIdx.x & 63;
+    const long row_id = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);   // over B*C*H
+    if (row_id >= rows_total) return;
+    const long plane = row_id / H;
+    const int r = (int)(row_id - plane * H);
+    const long b = plane / C;
+    float *f = F + row_id * W;
+    const float *d = domx + (b * H + r) * (long)W;
+    // ---- left -> right:  F[i] = V[i] F[i-1] + (1 - V[i]) F[i],  i >= 1
+    float carry = 0.f;
+    for (int base = 0; base < W; base += 64) {
+        const int i = base + lane;
+        float x = 0.f, v = 1.f;
+        if (i < W) { x = f[i]; v = expf(d[i] * log_a); }
+        Affine m = (i == 0 || i >= W) ? Affine{0.f, x} : Affine{v, (1.f - v) * x};
+        if (i >= W) m = Affine{1.f, 0.f};
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Affine prev{__shfl_up(m.a, o), __shfl_up(m.b, o)};
+            if (lane >= o) m = compose(m, prev);
+        }
+        const float y = fmaf(m.a, carry, m.b);
+        if (i < W) f[i] = y;
+        carry = __shfl(y, 63);
+        if (base + 63 >= W) carry = __shfl(y, (W - 1) - base);
+    }
+    // ---- right -> left:  F[i] = V[i+1] F[i+1] + (1 - V[i+1]) F[i],  i <= W-2
+    const int last_base = ((W - 1) / 64) * 64;
+    carry = 0.f;
+    for (int base = last_base; base >= 0; base -= 64) {
+        const int i = base + (63 - lane);            // lane 0 handles the right-most element of the chunk
+        float x = 0.f, v = 1.f;
+        if (i < W) x = f[i];
+        if (i + 1 < W) v = expf(d[i + 1] * log_a);
+        Affine m = (i >= W - 1) ? Affine{0.f, x} : Affine{v, (1.f - v) * x};
+        if (i >= W) m = Affine{1.f, 0.f};
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Affine prev{__shfl_up(m.a, o), __shfl_up(m.b, o)};
+            if (lane >= o) m = compose(m, prev);
+        }
+        const float y = fmaf(m.a, carry, m.b);
+        if (i < W) f[i] = y;
+        carry = __shfl(y, 63);                        // element `base`, the left-most of this chunk
+    }
+}
+
+// One vertical pass (top->bottom then bottom->top) in place on F; thread = (plane, column).
+__global__ __launch_bounds__(NT) void dt_cols_kernel(float *__restrict__ F, const float *__restrict__ domy, int C, int H,
+                                                     int W, float log_a, long cols_total) {
+    const long id = (long)blockIdx.x * NT + threadIdx.x;   // over B*C*W
+    if (id >= cols_total) return;
+    const long plane = id / W;
+    const int c = (int)(id - plane * W);
+    const long b = plane / C;
+    float *f = F + plane * (long)H * W + c;
+    const float *d = domy + b * (long)H * W + c;
+    float prev = f[0];
+    for (int r = 1; r < H; ++r) {
+        const float v = expf(d[(long)r * W] * log_a);
+        const float x = f[(long)r * W];
+        prev = x + v * (prev - x);
+        f[(long)r * W] = prev;
+    }
+    for (int r = H - 2; r >= 0; --r) {
+        const float v = expf(d[(long)(r + 1) * W] * log_a);
+        const float x = f[(long)r * W];
+        prev = x + v * (prev - x);
+        f[(long)r * W] = prev;
+    }
+}
+
+template <typename T> __global__ void to_float_kernel(const T *__restrict__ in, float *__restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = pb_ld(in + i);
+}
+template <typename T> __global__ void from_float_kernel(const float *__restrict__ in, T *__restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) pb_st(out + i, in[i]);
+}
+
+unsigned grid_for(long n, int per_block = NT, int cap = 8192) {
+    long g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+// ---- internal entry points used by api.hip --------------------------------------------------
+int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int P, long HW) {
+    PB_HIP(hipMemsetAsync(nM, 0, sizeof(float) * P, ctx->stream));
+    int bpp = (int)((HW + NT * 16 - 1) / (NT * 16));
+    if (bpp > 256) bpp = 256;
+    if (bpp < 1) bpp = 1;
+    hipLaunchKernelGGL(grad_energy_kernel, dim3(P * bpp), dim3(NT), 0, ctx->stream, gx, gy, nM, HW, bpp);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
+                  const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
+                  int clamp01) {
+    dim3 grid(grid_for((long)H * W, NT, 2048), P);
+#define PB_HALO(TX, TO)                                                                                           \
+    hipLaunchKernelGGL((halo_kernel<TX, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
+                       x_plane, y, gx, gy, ox, nM, static_cast<TO *>(out), H, W, clamp01)
+    if (x_dtype == PB_F32 && out_dtype == PB_F32) PB_HALO(float, float);
+    else if (x_dtype == PB_F32 && out_dtype == PB_F16) PB_HALO(float, __half);
+    else if (x_dtype == PB_F16 && out_dtype == PB_F32) PB_HALO(__half, float);
+    else PB_HALO(__half, __half);
+#undef PB_HALO
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, const float *smooth, void *out, int dtype, long n) {
+    if (dtype == PB_F32)
+        hipLaunchKernelGGL(recombine_kernel<float>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, y,
+                           static_cast<const float *>(cur), smooth, static_cast<float *>(out), n);
+    else
+        hipLaunchKernelGGL(recombine_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, y,
+                           static_cast<const __half *>(cur), smooth, static_cast<__half *>(out), n);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int out_dtype, int P, int H, int W) {
+    const float sigma_color = 0.1f, sigma_space = 5.0f;
+    const float ivc = 1.f / (2.f * sigma_color * sigma_color), ivs = 1.f / (2.f * sigma_space * sigma_space);
+    dim3 grid((W + 63) / 64, (H + 15) / 16, P);
+#define PB_BIL(TI, TO)                                                                                           \
+    hipLaunchKernelGGL((bilateral5_kernel<TI, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TI *>(in),  \
+                       static_cast<TO *>(out), H, W, ivc, ivs)
+    if (in_dtype == PB_F32 && out_dtype == PB_F32) PB_BIL(float, float);
+    else if (in_dtype == PB_F16 && out_dtype == PB_F32) PB_BIL(__half, float);
+    else if (in_dtype == PB_F16 && out_dtype == PB_F16) PB_BIL(__half, __half);
+    else PB_BIL(float, __half);
+#undef PB_BIL
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+// out (float32, B*C*H*W) = recursive_filter(in, joint)
+int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype, float *out, int B, int C, int H, int W,
+                      float sigma_s, float sigma_r, int num_iterations) {
+    const long HW = (long)H * W, n = (long)B * C * HW;
+    float *domx = static_cast<float *>(pb_scratch(ctx, "dt.domx", sizeof(float) * B * HW));
+    float *domy = static_cast<float *>(pb_scratch(ctx, "dt.domy", sizeof(float) * B * HW));
+    if (!domx || !domy) return PB_ERR_NOMEM;
+    const void *J = joint ? joint : in;
+    const float ratio = sigma_s / sigma_r;
+    dim3 dgrid(grid_for(HW, NT, 2048), B);
+    if (dtype == PB_F32) {
+        hipLaunchKernelGGL(dt_domain_kernel<float>, dgrid, dim3(NT), 0, ctx->stream, static_cast<const float *>(J), domx, domy, C, H, W, ratio);
+        hipLaunchKernelGGL(to_float_kernel<float>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, static_cast<const float *>(in), out, n);
+    } else {
+        hipLaunchKernelGGL(dt_domain_kernel<__half>, dgrid, dim3(NT), 0, ctx->stream, static_cast<const __half *>(J), domx, domy, C, H, W, ratio);
+        hipLaunchKernelGGL(to_float_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, static_cast<const __half *>(in), out, n);
+    }
+    PB_LAUNCH_CHECK();
+    const int N = num_iterations;
+    const long rows_total = (long)B * C * H, cols_total = (long)B * C * W;
+    for (int i = 0; i < N; ++i) {
+        // domain_transform.py:50,53
+        const double sigma_i = (double)sigma_s * std::sqrt(3.0) * std::pow(2.0, N - (i + 1)) / std::sqrt(std::pow(4.0, N) - 1.0);
+        const float a = (float)std::exp(-std::sqrt(2.0) / sigma_i);
+        const float log_a = std::log(a);
+        hipLaunchKernelGGL(dt_rows_kernel, dim3((unsigned)((rows_total + 3) / 4)), dim3(NT), 0, ctx->stream, out, domx, C, H, W, log_a, rows_total);
+        hipLaunchKernelGGL(dt_cols_kernel, dim3((unsigned)((cols_total + NT - 1) / NT)), dim3(NT), 0, ctx->stream, out, domy, C, H, W, log_a, cols_total);
+        PB_LAUNCH_CHECK();
+    }
+    return PB_OK;
+}
+
+int pb_convert_to_float(pb_ctx *ctx, const void *in, int dtype, float *out, long n) {
+    if (dtype == PB_F32) PB_HIP(hipMemcpyAsync(out, in, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    else {
+        hipLaunchKernelGGL(to_float_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, static_cast<const __half *>(in), out, n);
+        PB_LAUNCH_CHECK();
+    }
+    return PB_OK;
+}
+
+int pb_convert_from_float(pb_ctx *ctx, const float *in, void *out, int dtype, long n) {
+    if (dtype == PB_F32) PB_HIP(hipMemcpyAsync(out, in, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    else {
+        hipLaunchKernelGGL(from_float_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, in, static_cast<__half *>(out), n);
+        PB_LAUNCH_CHECK();
+    }
+    return PB_OK;
+}

@@ -1,4 +1,180 @@
-def polyblur_deblurring(*a, **k):
-    raise NotImplementedError
-class PolyblurDeblurring:
+"""Drop-in for the reference's public API (polyblur/deblurring.py:23-25 and :250-347).
+
+    from polyblur_amd import polyblur_deblurring, PolyblurDeblurring
+
+Same names, keyword arguments, defaults (including the functional/module defaults that
+differ in the reference), and the same in/out type rule:
+
+* ``np.ndarray`` (H,W) or (H,W,C)  ->  ``np.ndarray`` of the same shape, float32
+  (deblurring.py:46-48,93-94);
+* ``torch.Tensor`` (B,C,H,W)       ->  ``torch.Tensor`` on the same device, same dtype.
+  ROCm tensors are used in place (zero copy, on torch's current stream); CPU tensors
+  are staged through the GPU.
+
+The work is done by the HIP engine behind include/polyblur_hip.h; there is no CPU
+implementation here.  ``method`` keeps the reference's meaning as a *boundary model*:
+'fft' = circular reblurring on the replicate-padded domain (the reference default),
+'direct' = zero-padded reblurring -- both evaluated by the same spatial-domain Gaussian
+stencil kernels (no FFT convolution on the device).
+
+Extras that the reference does not have (all keyword-only, defaults keep reference
+behaviour): ``support`` ('full' | 'adaptive'), ``prefilter`` ('bilateral' |
+'domain_transform' -- which edge-aware filter ``prefiltering=True`` uses; the reference's
+live code path is the bilateral one, deblurring.py:107-108), ``return_info``.
+"""
+from __future__ import annotations
+
+from time import time
+
+import numpy as np
+
+from . import _capi as capi
+from .engine import get_engine
+
+_METHODS = {"fft": capi.PB_WRAP, "direct": capi.PB_ZERO, "direct_separable": capi.PB_ZERO}
+_SUPPORT = {"full": capi.PB_SUPPORT_FULL, "adaptive": capi.PB_SUPPORT_ADAPTIVE}
+_PREFILTER = {"bilateral": capi.PB_PREFILTER_BILATERAL, "domain_transform": capi.PB_PREFILTER_DOMAIN_TRANSFORM}
+
+
+def _is_torch_tensor(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
+
+
+def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles, n_interpolated_angles,
+                   remove_halo, edgetaping, prefiltering, discard_saturation, multichannel_kernel, method, support,
+                   prefilter, force_theta_deg=-1.0):
+    if method not in _METHODS:
+        raise ValueError("%s not implemented" % method)          # reference: deblurring.py:119 (never raised there)
+    if support not in _SUPPORT:
+        raise ValueError("support must be 'full' or 'adaptive'")
+    if prefilter not in _PREFILTER:
+        raise ValueError("prefilter must be 'bilateral' or 'domain_transform'")
+    if ker_size != capi.PB_KSIZE:
+        raise NotImplementedError("only ker_size=25 (the reference default) is built")
+    if q != 0:
+        raise NotImplementedError("quantile normalisation (q > 0) is not built yet; use q=0")
+    if multichannel_kernel and C not in (1, 3):
+        raise NotImplementedError("per-channel kernels crash in the reference for C not in {1,3}")
+    if not (1 <= n_angles <= capi.PB_MAX_ANGLES - 1 and 1 <= n_interpolated_angles <= capi.PB_MAX_INTERP):
+        raise ValueError("n_angles / n_interpolated_angles out of range")
+    from .engine import Engine
+    return Engine.make_options(n_iter=n_iter, c=c, b=b, alpha=alpha, beta=beta, sigma_r=sigma_r, sigma_s=sigma_s, q=q,
+                               n_angles=n_angles, n_interpolated_angles=n_interpolated_angles, remove_halo=remove_halo,
+                               edgetaping=edgetaping,
+                               prefilter=_PREFILTER[prefilter] if prefiltering else capi.PB_PREFILTER_NONE,
+                               discard_saturation=discard_saturation, boundary=_METHODS[method],
+                               support=_SUPPORT[support], force_theta_deg=force_theta_deg)
+
+
+def _info_to_dicts(info, n_angles, n_interp):
+    if info is None:
+        return None
+    out = []
+    for it in range(info.shape[0]):
+        rec = info[it]
+        out.append(dict(mags=rec["mags"][:, :n_angles + 1].copy(), interp=rec["interp"][:, :n_interp].copy(),
+                        i_min=rec["i_min"].copy(), theta=rec["theta"].copy(), sigma=rec["sigma"].copy(),
+                        rho=rec["rho"].copy(), kernel=rec["kernel"].copy(), separable=rec["separable"].copy(),
+                        radius=rec["radius"].copy(), lo=rec["gray_min"].copy(), hi=rec["gray_max"].copy()))
+    return out
+
+
+def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_r=0.8, sigma_s=2.0, ker_size=25, q=0.0,
+                        n_angles=6, n_interpolated_angles=30, remove_halo=False, edgetaping=False, prefiltering=False,
+                        discard_saturation=False, multichannel_kernel=False, method='fft', verbose=False, *,
+                        support='full', prefilter='bilateral', return_info=False, device=None):
+    """Blind deblurring of ``img`` -- see the module docstring; reference deblurring.py:23-96."""
+    start = time()
+    if isinstance(img, np.ndarray):
+        # utils.to_tensor + unsqueeze (deblurring.py:46-48): HWC -> (1,C,H,W) float32 copy
+        if img.ndim == 2:
+            x = img[None, None]
+        elif img.ndim == 3:
+            x = np.moveaxis(img, 2, 0)[None]
+        else:
+            raise ValueError("expected an (H,W) or (H,W,C) array, got shape %r" % (img.shape,))
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        opts = _build_options(x.shape[1], n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles,
+                              n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
+                              multichannel_kernel, method, support, prefilter)
+        eng = get_engine(0 if device is None else int(device))
+        res = eng.polyblur(x, opts, want_info=return_info)
+        out, info = res if return_info else (res, None)
+        # utils.to_array (utils.py:24-31): squeeze, CHW -> HWC
+        out = np.squeeze(out)
+        if out.ndim == 3:
+            out = np.ascontiguousarray(np.moveaxis(out, 0, -1))
+        if verbose:
+            print('-- polyblur (hip): %1.5f s' % (time() - start))
+        return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
+
+    if not _is_torch_tensor(img):
+        raise TypeError("img must be a numpy.ndarray or a torch.Tensor")
+    import torch
+    if img.dim() != 4:
+        raise ValueError("expected a (B,C,H,W) tensor, got shape %r" % (tuple(img.shape),))
+    if img.dtype not in (torch.float32, torch.float16):
+        raise TypeError("tensor dtype must be float32 or float16 (the reference is float32-only)")
+    opts = _build_options(img.shape[1], n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles,
+                          n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
+                          multichannel_kernel, method, support, prefilter)
+    dtype = capi.PB_F32 if img.dtype == torch.float32 else capi.PB_F16
+    if img.is_cuda:
+        dev = img.device.index if img.device.index is not None else torch.cuda.current_device()
+        eng = get_engine(dev)
+        xin = img.contiguous()
+        out = torch.empty_like(xin)
+        with torch.cuda.device(dev):
+            eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            info = eng.polyblur_ptr(xin.data_ptr(), out.data_ptr(), dtype, xin.shape, opts, want_info=return_info)
+    else:
+        eng = get_engine(0 if device is None else int(device))
+        arr = img.detach().contiguous().numpy()
+        res = eng.polyblur(arr, opts, want_info=return_info)
+        o, info = res if return_info else (res, None)
+        out = torch.from_numpy(o)
+    if verbose:
+        print('-- polyblur (hip): %1.5f s' % (time() - start))
+    return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
+
+
+class _ModuleBase:
     pass
+
+
+try:                                      # be an nn.Module when torch is importable, like the reference
+    import torch.nn as _nn
+    _Base = _nn.Module
+except Exception:                         # pragma: no cover
+    _Base = _ModuleBase
+
+
+class PolyblurDeblurring(_Base):
+    """Stateless module wrapper, reference deblurring.py:250-347.
+
+    ``patch_decomposition=True`` raises ``NameError`` in the reference (undefined
+    ``handling_saturation``, deblurring.py:289); here it raises ``NotImplementedError``.
+    Note the defaults of ``forward`` differ from the functional API's (deblurring.py:266-268).
+    """
+
+    def __init__(self, patch_decomposition=False, patch_size=400, patch_overlap=0.25, batch_size=1):
+        super().__init__()
+        self.batch_size = batch_size
+        self.patch_decomposition = patch_decomposition
+        self.patch_size = (patch_size, patch_size)
+        self.patch_overlap = patch_overlap
+
+    def forward(self, images, n_iter=1, c=0.352, b=0.468, alpha=2, beta=4, sigma_s=2, ker_size=25, sigma_r=0.4,
+                q=0.0, n_angles=6, n_interpolated_angles=30, remove_halo=False, edgetaping=False, prefiltering=False,
+                discard_saturation=False, multichannel_kernel=False, method='fft', device=None, **extras):
+        if self.patch_decomposition:
+            raise NotImplementedError("patch decomposition is broken in the reference (deblurring.py:289) "
+                                      "and not built yet")
+        return polyblur_deblurring(images, n_iter=n_iter, c=c, b=b, alpha=alpha, beta=beta, ker_size=ker_size,
+                                   sigma_s=sigma_s, sigma_r=sigma_r, remove_halo=remove_halo, edgetaping=edgetaping,
+                                   prefiltering=prefiltering, discard_saturation=discard_saturation,
+                                   multichannel_kernel=multichannel_kernel, method=method, q=q, n_angles=n_angles,
+                                   n_interpolated_angles=n_interpolated_angles, **extras)
+
+    if _Base is _ModuleBase:              # pragma: no cover
+        __call__ = forward

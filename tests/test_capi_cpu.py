@@ -1,0 +1,93 @@
+"""CPU-side checks of the boundary: the shared library builds/loads, exports every symbol the
+header declares, and the host logic (argument validation, layout, error behaviour) works
+without a GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from polyblur_amd import _capi as capi
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.library_path()):
+        from polyblur_amd.build import build
+        build(verbose=False)
+    return capi.load_library()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "polyblur_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pb_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pb_version() == 100
+
+
+def test_struct_layout_matches_header(lib):
+    o = capi.pb_options()
+    lib.pb_default_options(ctypes.byref(o))
+    # the functional API's defaults, reference deblurring.py:23-25
+    assert (o.n_iter, o.n_angles, o.n_interpolated_angles) == (1, 6, 30)
+    assert abs(o.c - 0.352) < 1e-7 and abs(o.b - 0.768) < 1e-7 and o.alpha == 2 and o.beta == 3
+    assert abs(o.sigma_r - 0.8) < 1e-7 and o.sigma_s == 2.0 and o.q == 0 and o.force_theta_deg == -1.0
+    assert (o.remove_halo, o.edgetaping, o.prefilter, o.discard_saturation, o.boundary, o.support) == (0,) * 6
+    assert ctypes.sizeof(capi.pb_blur_info) == capi.INFO_DTYPE.itemsize == 4 * (2 + 13 + 64 + 4 + 2 + 625 + 100)
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from polyblur_amd import polyblur_deblurring
+    with pytest.raises(capi.PolyblurHipError):
+        polyblur_deblurring(np.zeros((16, 16, 3), np.float32))
+
+
+def test_argument_validation_before_any_device_work():
+    from polyblur_amd import polyblur_deblurring, PolyblurDeblurring
+    x = np.zeros((16, 16, 3), np.float32)
+    with pytest.raises(ValueError):
+        polyblur_deblurring(x, method="nope")
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(x, q=1e-4)
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(x, ker_size=31)
+    with pytest.raises(ValueError):
+        polyblur_deblurring(np.zeros((4,), np.float32))
+    with pytest.raises(TypeError):
+        polyblur_deblurring([[0.0]])
+    with pytest.raises(NotImplementedError):
+        PolyblurDeblurring(patch_decomposition=True)(x)
+    # the module's defaults differ from the functional ones (reference deblurring.py:266-268)
+    import inspect
+    f = inspect.signature(polyblur_deblurring).parameters
+    m = inspect.signature(PolyblurDeblurring.forward).parameters
+    assert (f["b"].default, f["beta"].default, f["sigma_r"].default) == (0.768, 3, 0.8)
+    assert (m["b"].default, m["beta"].default, m["sigma_r"].default) == (0.468, 4, 0.4)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under polyblur_amd/ may reference it."""
+    for root, _, files in os.walk(os.path.join(REPO, "polyblur_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("on the oracle", ""), f
+
+
+def test_synthetic_generator_is_deterministic():
+    from polyblur_amd.synthetic import synthetic_blurry_batch
+    a, pa = synthetic_blurry_batch(2, 3, 40, 56, seed0=5)
+    b, pb = synthetic_blurry_batch(2, 3, 40, 56, seed0=5)
+    assert np.array_equal(a, b) and pa == pb and a.dtype == np.float32
+    assert a.min() >= 0 and a.max() <= 1 and not np.array_equal(a[0], a[1])
+    c, pc = synthetic_blurry_batch(1, 3, 40, 56, seed0=5, force_theta_deg=0.0)
+    assert pc[0][2] == 0.0
