@@ -90,6 +90,8 @@ int pb_destroy(pb_ctx *ctx) {
         if (p.dnat) (void)hipFree(p.dnat);
     }
     if (ctx->interp_w) (void)hipFree(ctx->interp_w);
+    for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -492,6 +494,32 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         PB_HIP(hipMemcpyAsync(host_info, infos, sizeof(pb_blur_info) * (size_t)n_iter * B, hipMemcpyDeviceToHost, ctx->stream));
         PB_HIP(hipStreamSynchronize(ctx->stream));
     }
+    return PB_OK;
+}
+
+int pb_profile_begin(pb_ctx *ctx) {
+    if (!ctx) return PB_ERR_BADARG;
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->prof) { ctx->evpool.push_back(r.a); ctx->evpool.push_back(r.b); }
+    ctx->prof.clear();
+    ctx->prof_on = true;
+    return PB_OK;
+}
+
+int pb_profile_end(pb_ctx *ctx, float *host_ms, int *host_count) {
+    if (!ctx || !host_ms || !host_count) return PB_ERR_BADARG;
+    ctx->prof_on = false;
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < PB_PROF_NTAGS; ++t) { host_ms[t] = 0.f; host_count[t] = 0; }
+    for (auto &r : ctx->prof) {
+        float ms = 0.f;
+        PB_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        host_ms[r.tag] += ms;
+        host_count[r.tag] += 1;
+        ctx->evpool.push_back(r.a);
+        ctx->evpool.push_back(r.b);
+    }
+    ctx->prof.clear();
     return PB_OK;
 }
 

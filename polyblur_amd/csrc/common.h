@@ -34,7 +34,15 @@ struct ScratchBuf {
     size_t bytes = 0;
 };
 
+struct ProfRec {
+    hipEvent_t a, b;
+    int tag;
+};
+
 struct pb_ctx {
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> evpool;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -46,6 +54,28 @@ struct pb_ctx {
 };
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);
+
+// RAII bracket: records an event pair around the launches issued in its scope when profiling is on
+struct ProfScope {
+    pb_ctx *ctx;
+    int idx = -1;
+    ProfScope(pb_ctx *c, int tag) : ctx(c) {
+        if (!c->prof_on) return;
+        ProfRec r;
+        r.tag = tag;
+        hipEvent_t *ev[2] = {&r.a, &r.b};
+        for (auto e : ev) {
+            if (!c->evpool.empty()) { *e = c->evpool.back(); c->evpool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) return;
+        }
+        (void)hipEventRecord(r.a, c->stream);
+        c->prof.push_back(r);
+        idx = (int)c->prof.size() - 1;
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(ctx->prof[idx].b, ctx->stream);
+    }
+};
 void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes);   // nullptr on failure (error set)
 const FftPlan *pb_get_plan(pb_ctx *ctx, int n);
 const float *pb_get_interp_weights(pb_ctx *ctx, int n_angles, int n_interp);

@@ -256,6 +256,7 @@ int launch_typed(pb_ctx *ctx, const ConvPass &p) {
     if (blocks <= 0 || blocks > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "conv pass: bad grid");
     constexpr int R = PB_KRAD;
     const size_t lds = sizeof(float) * ((TH + 2 * R) * (TW + 2 * R) + (TH + 2 * R) * TW);
+    ProfScope prof(ctx, PB_PROF_CONV);
     hipLaunchKernelGGL((conv_pass_kernel<TIn, TX, TOut, TH>), dim3((unsigned)blocks), dim3(NT), lds, ctx->stream, p,
                        tiles_x, tiles_y);
     PB_LAUNCH_CHECK();

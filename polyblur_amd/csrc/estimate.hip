@@ -526,6 +526,7 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     if (lds > kMaxLds) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image width %d too large for the in-LDS FFT", W);
     const long blocks = (long)P * ((H + 1) / 2);
     const pbfft::DevPlan dp = dev_plan(pl);
+    ProfScope prof(ctx, PB_PROF_GRAD_ROWS);
     if (normalize) {
         int rc = allow_lds(ctx, grad_rows_kernel<true>, lds); if (rc) return rc;
         hipLaunchKernelGGL(grad_rows_kernel<true>, dim3((unsigned)blocks), dim3(NT), lds, ctx->stream, planes, gx, H, W, mm, planes_per_image, dp);
@@ -549,6 +550,7 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     const long blocks = (long)P * ((W + tc - 1) / tc);
     const pbfft::DevPlan dp = dev_plan(pl);
     const float thr = 0.99f;
+    ProfScope prof(ctx, PB_PROF_GRAD_COLS);
 #define PB_COLS(MODE, NORM)                                                                                      \
     do {                                                                                                         \
         int rc = allow_lds(ctx, grad_cols_kernel<MODE, NORM>, lds);                                              \
@@ -587,6 +589,8 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     const float *wts = pb_get_interp_weights(ctx, opt->n_angles, opt->n_interpolated_angles);
     if (!wts) return PB_ERR_NOMEM;
     const int ninit = B * PB_MAX_ANGLES;
+    {
+    ProfScope prof(ctx, PB_PROF_GRAY);
     hipLaunchKernelGGL(init_minmax_kernel, dim3((ninit + 255) / 256), dim3(256), 0, ctx->stream, mm, mags, B, PB_MAX_ANGLES);
     PB_LAUNCH_CHECK();
     int bpi = (int)((HW + NT * 8 - 1) / (NT * 8));
@@ -599,10 +603,12 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
         hipLaunchKernelGGL(gray_minmax_kernel<__half>, dim3(B * bpi), dim3(NT), 0, ctx->stream,
                            static_cast<const __half *>(in), gray, mm, C, HW, bpi);
     PB_LAUNCH_CHECK();
+    }
     int rc = launch_rows(ctx, gray, gx, B, H, W, true, mm, 1);
     if (rc) return rc;
     rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, true, mm, 1, mags, opt->n_angles, opt->discard_saturation);
     if (rc) return rc;
+    ProfScope prof(ctx, PB_PROF_PARAMS);
     hipLaunchKernelGGL(blur_params_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg);
     PB_LAUNCH_CHECK();
@@ -610,6 +616,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 }
 
 int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps) {
+    ProfScope prof(ctx, PB_PROF_PARAMS);
     hipLaunchKernelGGL(make_kernels_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, support, from_taps);
     PB_LAUNCH_CHECK();
     return PB_OK;

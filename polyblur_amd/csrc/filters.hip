@@ -236,6 +236,7 @@ unsigned grid_for(long n, int per_block = NT, int cap = 8192) {
 
 // ---- internal entry points used by api.hip --------------------------------------------------
 int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int P, long HW) {
+    ProfScope prof(ctx, PB_PROF_HALO);
     PB_HIP(hipMemsetAsync(nM, 0, sizeof(float) * P, ctx->stream));
     int bpp = (int)((HW + NT * 16 - 1) / (NT * 16));
     if (bpp > 256) bpp = 256;
@@ -249,6 +250,7 @@ int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_p
                   const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
                   int clamp01) {
     dim3 grid(grid_for((long)H * W, NT, 2048), P);
+    ProfScope prof(ctx, PB_PROF_HALO);
 #define PB_HALO(TX, TO)                                                                                           \
     hipLaunchKernelGGL((halo_kernel<TX, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
                        x_plane, y, gx, gy, ox, nM, static_cast<TO *>(out), H, W, clamp01)
@@ -262,6 +264,7 @@ int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_p
 }
 
 int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, const float *smooth, void *out, int dtype, long n) {
+    ProfScope prof(ctx, PB_PROF_PREFILTER);
     if (dtype == PB_F32)
         hipLaunchKernelGGL(recombine_kernel<float>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, y,
                            static_cast<const float *>(cur), smooth, static_cast<float *>(out), n);
@@ -276,6 +279,7 @@ int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int
     const float sigma_color = 0.1f, sigma_space = 5.0f;
     const float ivc = 1.f / (2.f * sigma_color * sigma_color), ivs = 1.f / (2.f * sigma_space * sigma_space);
     dim3 grid((W + 63) / 64, (H + 15) / 16, P);
+    ProfScope prof(ctx, PB_PROF_PREFILTER);
 #define PB_BIL(TI, TO)                                                                                           \
     hipLaunchKernelGGL((bilateral5_kernel<TI, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TI *>(in),  \
                        static_cast<TO *>(out), H, W, ivc, ivs)
@@ -292,6 +296,7 @@ int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int
 int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype, float *out, int B, int C, int H, int W,
                       float sigma_s, float sigma_r, int num_iterations) {
     const long HW = (long)H * W, n = (long)B * C * HW;
+    ProfScope prof(ctx, PB_PROF_PREFILTER);
     float *domx = static_cast<float *>(pb_scratch(ctx, "dt.domx", sizeof(float) * B * HW));
     float *domy = static_cast<float *>(pb_scratch(ctx, "dt.domy", sizeof(float) * B * HW));
     if (!domx || !domy) return PB_ERR_NOMEM;

@@ -244,6 +244,16 @@ class Engine:
         self.synchronize()
         return dout.download(x.shape, x.dtype)
 
+    def profile_begin(self):
+        self._check(self.lib.pb_profile_begin(self.ctx))
+
+    def profile_end(self):
+        """-> {tag: (total_ms, launches)} for the launches issued since profile_begin()."""
+        ms = (C.c_float * 8)()
+        cnt = (C.c_int * 8)()
+        self._check(self.lib.pb_profile_end(self.ctx, ms, cnt))
+        return {t: (float(ms[i]), int(cnt[i])) for i, t in enumerate(capi.PROF_TAGS)}
+
     def time_inner_loop(self, in_ptr: int, out_ptr: int, dtype: int, shape, info_ptr: int, alpha, beta,
                         boundary=capi.PB_WRAP, reps=10) -> float:
         B, Cc, H, W = (int(v) for v in shape)
