@@ -97,6 +97,7 @@ typedef struct pb_blur_info {
                                            the exact rank-1 factors when `separable` */
     float acorr_y[PB_KSIZE], acorr_x[PB_KSIZE]; /* autocorrelation of ky / kx at lags 0..24: the closed
                                            form of edgetaper_alpha's 1-D FFTs (edgetaper.py:11-21) */
+    float gtaps[PB_KSIZE * 32];         /* kernel rows re-laid for the tile stencil: row y = {0,0,0, k[y][0..24], 0,0,0,0} */
 } pb_blur_info;
 
 /* ---- context ------------------------------------------------------------------------- */

@@ -416,6 +416,16 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         info->ky[tid] = sy;
     }
     __syncthreads();
+    // Symmetrise the marginals (a Gaussian's are symmetric up to the rounding of the sums above):
+    // the streaming stencil body keeps only taps 0..12 of each in scalar registers.
+    float sxm = 0.f, sym = 0.f;
+    if (tid < PB_KSIZE) {
+        sxm = 0.5f * (info->kx[tid] + info->kx[PB_KSIZE - 1 - tid]);
+        sym = 0.5f * (info->ky[tid] + info->ky[PB_KSIZE - 1 - tid]);
+    }
+    __syncthreads();
+    if (tid < PB_KSIZE) { info->kx[tid] = sxm; info->ky[tid] = sym; }
+    __syncthreads();
     if (tid < PB_KSIZE) {
         float ax = 0.f, ay = 0.f;
         for (int n = 0; n + tid < PB_KSIZE; ++n) {
@@ -424,6 +434,10 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         }
         info->acorr_x[tid] = ax;
         info->acorr_y[tid] = ay;
+    }
+    for (int idx = tid; idx < PB_KSIZE * 32; idx += NT) {
+        const int y = idx >> 5, j = (idx & 31) - 3;
+        info->gtaps[idx] = (j >= 0 && j < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j] : 0.f;
     }
     // rank-1 residual  sum |k - ky (x) kx|  and the total mass (for arbitrary taps)
     float res = 0.f;
