@@ -21,289 +21,16 @@
 //   thread, the 25-tap rows of the kernel streamed through SGPRs.  fp32 VALU-bound by design.
 //
 // No MFMA anywhere: the pass is bound by HBM (rank-1) or by the fp32 vector rate (general).
+#include <cstdlib>
+
 #include "common.h"
+#include "conv_common.h"
+
+int pb_launch_conv_stream(pb_ctx *ctx, const ConvPass &p);
 
 namespace {
 
 constexpr int NT = 256;
-#define PB_CONSTANT __attribute__((address_space(4)))
-
-// loads through the constant address space become scalar (s_load) when the address is uniform
-template <typename T> __device__ __forceinline__ const PB_CONSTANT T *as_constant(const T *p) {
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-    return (const PB_CONSTANT T *)p;
-#pragma clang diagnostic pop
-}
-
-// compiler-only ordering of LDS traffic inside one wavefront (no instruction is emitted)
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ int wrap_idx(int v, int n) {
-    v %= n;
-    return v < 0 ? v + n : v;
-}
-
-// padded coordinate -> source index along one axis, or -1 for "reads as zero"
-__device__ __forceinline__ int map_axis(int p, int n_unpadded, int kind, int boundary) {
-    const int np = n_unpadded + 2 * PB_PAD;
-    if (boundary == PB_WRAP) p = wrap_idx(p, np);
-    else if (p < 0 || p >= np) return -1;
-    if (kind == SRC_VIRTUAL) return min(max(p - PB_PAD, 0), n_unpadded - 1);
-    return p;
-}
-
-__device__ __forceinline__ float taper_weight(const float *ac, int p, int n) {
-    // v[p] = 1 - z[p]/z[0], z = circular autocorrelation with period n-1, z[n-1] := z[0]
-    // (edgetaper.py:11-15): non-zero only within 24 samples of either end.
-    const int m = min(p, n - 1 - p);
-    const float z = (m < PB_KSIZE) ? ac[m] : 0.f;
-    return 1.f - z / ac[0];
-}
-
-template <typename T> __device__ __forceinline__ float4 ld4(const T *p);
-template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-template <> __device__ __forceinline__ float4 ld4<__half>(const __half *p) {
-    const uint2 u = *reinterpret_cast<const uint2 *>(p);
-    const __half2 a = *reinterpret_cast<const __half2 *>(&u.x), b = *reinterpret_cast<const __half2 *>(&u.y);
-    const float2 fa = __half22float2(a), fb = __half22float2(b);
-    return make_float4(fa.x, fa.y, fb.x, fb.y);
-}
-template <typename T> __device__ __forceinline__ void st4(T *p, float4 v);
-template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
-template <> __device__ __forceinline__ void st4<__half>(__half *p, float4 v) {
-    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
-    uint2 u;
-    u.x = *reinterpret_cast<const unsigned *>(&a);
-    u.y = *reinterpret_cast<const unsigned *>(&b);
-    *reinterpret_cast<uint2 *>(p) = u;
-}
-
-// Where the outputs of a pass live, in padded coordinates.
-struct OutRegion { int y_lo, y_hi, x_lo, x_hi; };
-__device__ __forceinline__ OutRegion out_region(const ConvPass &a) {
-    if (a.out_kind == OUT_INTERIOR) return OutRegion{PB_PAD, PB_PAD + a.H, PB_PAD, PB_PAD + a.W};
-    return OutRegion{0, a.H + 2 * PB_PAD, 0, a.W + 2 * PB_PAD};
-}
-
-// Epilogue + store of 4 horizontally adjacent outputs at padded (py, px..px+3).
-template <typename TX, typename TOut>
-__device__ __forceinline__ void finish4(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl,
-                                        const OutRegion &rg, int py, int px, float4 acc) {
-    if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi) return;
-    const int H = a.H, W = a.W;
-    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
-    float av[4] = {acc.x, acc.y, acc.z, acc.w};
-    float xv[4];
-    const bool full = px >= rg.x_lo && px + 3 < rg.x_hi;
-    // x operand: rows clamp uniformly; a 16-byte load when the four columns are contiguous in the source
-    const int xr = (a.x_kind == SRC_VIRTUAL) ? min(max(py - PB_PAD, 0), H - 1) : py;
-    const int xc0 = (a.x_kind == SRC_VIRTUAL) ? px - PB_PAD : px;
-    const int xcmax = (a.x_kind == SRC_VIRTUAL) ? W : Wp;
-    const TX *xrow = xpl + (long)xr * a.x_pitch;
-    if (full && xc0 >= 0 && xc0 + 3 < xcmax && ((a.x_pitch | xc0) & 3) == 0) {
-        const float4 t = ld4<TX>(xrow + xc0);
-        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = pb_ld(xrow + min(max(xc0 + i, 0), xcmax - 1));
-    }
-    float ty = 1.f;
-    if (a.epilogue == EPI_TAPER) ty = taper_weight(info->acorr_y, py, Hp);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v;
-        if (a.epilogue == EPI_TAPER) {
-            const float al = ty * taper_weight(info->acorr_x, px + i, Wp);
-            v = al * xv[i] + (1.f - al) * av[i];
-        } else {
-            v = a.scale * av[i] + a.coef * xv[i];
-        }
-        if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-        av[i] = v;
-    }
-    const int orow = (a.out_kind == OUT_INTERIOR) ? py - PB_PAD : py;
-    const int oc0 = (a.out_kind == OUT_INTERIOR) ? px - PB_PAD : px;
-    TOut *orow_p = opl + (long)orow * a.out_pitch;
-    if (full && ((a.out_pitch | oc0) & 3) == 0) {
-        st4<TOut>(orow_p + oc0, make_float4(av[0], av[1], av[2], av[3]));
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (px + i >= rg.x_lo && px + i < rg.x_hi) pb_st(orow_p + oc0 + i, av[i]);
-    }
-}
-
-// =============================================================================================
-// rank-1 kernels: wave-private streaming body
-// =============================================================================================
-constexpr int SR = PB_KRAD;                   // the streaming body always evaluates all 25 taps
-constexpr int SNT = 2 * SR + 1;
-constexpr int SOUT = 256 - 2 * SR;            // 232 output columns per strip: 58 lanes x 4 ...
-constexpr int SLANES = SOUT / 4;              // ... so that the 256-sample staged line is ONE float4 per lane
-constexpr int SU = 5;                         // rows per unrolled group == prefetch depth
-constexpr int SACC = SNT + SU - 1;            // accumulator rows alive inside a group
-constexpr int SLINE = 72 * 4;                 // LDS floats per wave (64 float4 + read-ahead slack)
-
-// one source row -> this lane's float4 of the staged line (columns c[0..3]; -1 reads as zero)
-template <typename T>
-__device__ __forceinline__ float4 load_line(const T *plane, int pitch, int iy, bool fast, const int (&c)[4]) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy < 0) return v;
-    const T *row = plane + (long)iy * pitch;
-    if (fast) return ld4<T>(row + c[0]);
-    if (c[0] >= 0) v.x = pb_ld(row + c[0]);
-    if (c[1] >= 0) v.y = pb_ld(row + c[1]);
-    if (c[2] >= 0) v.z = pb_ld(row + c[2]);
-    if (c[3] >= 0) v.w = pb_ld(row + c[3]);
-    return v;
-}
-
-// x operand of one output row for this lane (same addressing rules as finish4)
-template <typename TX>
-__device__ __forceinline__ float4 load_x4(const ConvPass &a, const TX *xpl, const OutRegion &rg, int py, int px) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi) return r;
-    const int H = a.H, W = a.W, Wp = W + 2 * PB_PAD;
-    const int xr = (a.x_kind == SRC_VIRTUAL) ? min(max(py - PB_PAD, 0), H - 1) : py;
-    const int xc0 = (a.x_kind == SRC_VIRTUAL) ? px - PB_PAD : px;
-    const int xcmax = (a.x_kind == SRC_VIRTUAL) ? W : Wp;
-    const TX *xrow = xpl + (long)xr * a.x_pitch;
-    if (xc0 >= 0 && xc0 + 3 < xcmax && ((a.x_pitch | xc0) & 3) == 0) return ld4<TX>(xrow + xc0);
-    r.x = pb_ld(xrow + min(max(xc0, 0), xcmax - 1));
-    r.y = pb_ld(xrow + min(max(xc0 + 1, 0), xcmax - 1));
-    r.z = pb_ld(xrow + min(max(xc0 + 2, 0), xcmax - 1));
-    r.w = pb_ld(xrow + min(max(xc0 + 3, 0), xcmax - 1));
-    return r;
-}
-
-// epilogue + store with the x operand already in registers
-template <typename TOut>
-__device__ __forceinline__ void finish4x(const ConvPass &a, const pb_blur_info *info, TOut *opl, const OutRegion &rg,
-                                         int py, int px, float4 acc, float4 x) {
-    if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi) return;
-    const int Hp = a.H + 2 * PB_PAD, Wp = a.W + 2 * PB_PAD;
-    float av[4] = {acc.x, acc.y, acc.z, acc.w};
-    const float xv[4] = {x.x, x.y, x.z, x.w};
-    float ty = 1.f;
-    if (a.epilogue == EPI_TAPER) ty = taper_weight(info->acorr_y, py, Hp);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v;
-        if (a.epilogue == EPI_TAPER) {
-            const float al = ty * taper_weight(info->acorr_x, px + i, Wp);
-            v = al * xv[i] + (1.f - al) * av[i];
-        } else {
-            v = a.scale * av[i] + a.coef * xv[i];
-        }
-        if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-        av[i] = v;
-    }
-    const int orow = (a.out_kind == OUT_INTERIOR) ? py - PB_PAD : py;
-    const int oc0 = (a.out_kind == OUT_INTERIOR) ? px - PB_PAD : px;
-    TOut *orow_p = opl + (long)orow * a.out_pitch;
-    if (px + 3 < rg.x_hi && ((a.out_pitch | oc0) & 3) == 0) {
-        st4<TOut>(orow_p + oc0, make_float4(av[0], av[1], av[2], av[3]));
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (px + i < rg.x_hi) pb_st(orow_p + oc0 + i, av[i]);
-    }
-}
-
-template <typename TIn, typename TX, typename TOut>
-__device__ __forceinline__ void body_stream(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
-                                            TOut *opl, int task, int nsx, int seg_h, float *line) {
-    const OutRegion rg = out_region(a);
-    const int lane = threadIdx.x & 63;
-    const int sy = task / nsx, sx = task - sy * nsx;
-    const int x0 = rg.x_lo + sx * SOUT;
-    const int y0 = rg.y_lo + sy * seg_h;
-    const int rows_out = min(seg_h, rg.y_hi - y0);
-    if (rows_out <= 0) return;
-    const int H = a.H, W = a.W;
-    // taps -> SGPRs.  Rank-1 records carry symmetric marginals (kx[t] == kx[24-t], enforced when the
-    // record is built), so 13 + 13 scalars are enough and the whole walk keeps them resident.
-    const PB_CONSTANT float *ckx = as_constant(info->kx), *cky = as_constant(info->ky);
-    float hx[SR + 1], hy[SR + 1];
-#pragma unroll
-    for (int t = 0; t <= SR; ++t) { hx[t] = ckx[t]; hy[t] = cky[t]; }
-#define KX(t) hx[(t) <= SR ? (t) : 2 * SR - (t)]
-#define KY(t) hy[(t) <= SR ? (t) : 2 * SR - (t)]
-    // source columns of this lane's float4 of the staged line (fixed for the whole walk)
-    int cs[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cs[e] = map_axis(x0 - SR + 4 * lane + e, W, a.in_kind, a.boundary);
-    const bool fast = (a.in_pitch & 3) == 0 && cs[0] >= 0 && (cs[0] & 3) == 0 && cs[1] == cs[0] + 1 &&
-                      cs[2] == cs[0] + 2 && cs[3] == cs[0] + 3;
-    const int px = (lane < SLANES) ? x0 + 4 * lane : rg.x_hi;      // lanes 58..63 only help loading
-    float4 *line4 = reinterpret_cast<float4 *>(line);
-    float4 acc[SACC];
-#pragma unroll
-    for (int t = 0; t < SACC; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int n_in = rows_out + 2 * SR;
-    // software pipeline: SU source rows and SU x rows in flight
-    float4 pf[SU], xq[SU];
-#pragma unroll
-    for (int k = 0; k < SU; ++k) {
-        pf[k] = load_line<TIn>(ipl, a.in_pitch, k < n_in ? map_axis(y0 - SR + k, H, a.in_kind, a.boundary) : -1, fast, cs);
-        xq[k] = load_x4<TX>(a, xpl, rg, y0 + k - 2 * SR, px);
-    }
-    for (int i0 = 0; i0 < n_in; i0 += SU) {
-#pragma unroll
-        for (int s = 0; s < SU; ++s) {
-            const int i = i0 + s;
-            if (i < n_in) {                                           // uniform
-                const float4 cur = pf[s];
-                const float4 xcur = xq[s];
-                const int inext = i + SU;
-                pf[s] = load_line<TIn>(ipl, a.in_pitch, inext < n_in ? map_axis(y0 - SR + inext, H, a.in_kind, a.boundary) : -1,
-                                       fast, cs);
-                xq[s] = load_x4<TX>(a, xpl, rg, y0 + inext - 2 * SR, px);
-                // The staged line is exchanged between LANES of this wave: the LDS unit executes a wave's
-                // accesses in order, but the compiler must be told not to move them across each other.
-                wave_lds_fence();
-                line4[lane] = cur;
-                wave_lds_fence();
-                float seg[4 + 2 * SR];
-#pragma unroll
-                for (int q = 0; q < 1 + SR / 2; ++q) {
-                    const float4 t = line4[lane + q];
-                    seg[4 * q] = t.x; seg[4 * q + 1] = t.y; seg[4 * q + 2] = t.z; seg[4 * q + 3] = t.w;
-                }
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int t = 0; t < SNT; ++t) {
-                    v.x = fmaf(KX(t), seg[t], v.x);
-                    v.y = fmaf(KX(t), seg[t + 1], v.y);
-                    v.z = fmaf(KX(t), seg[t + 2], v.z);
-                    v.w = fmaf(KX(t), seg[t + 3], v.w);
-                }
-                // input row i feeds output rows i-t with tap ky[t]; inside the group output row o
-                // lives in slot o - (i0 - 2R), so row i touches slots s .. s+2R
-#pragma unroll
-                for (int t = 0; t < SNT; ++t) {
-                    const int slot = s + 2 * SR - t;
-                    acc[slot].x = fmaf(KY(t), v.x, acc[slot].x);
-                    acc[slot].y = fmaf(KY(t), v.y, acc[slot].y);
-                    acc[slot].z = fmaf(KY(t), v.z, acc[slot].z);
-                    acc[slot].w = fmaf(KY(t), v.w, acc[slot].w);
-                }
-                const int o = i - 2 * SR;                              // complete now: slot s
-                if (o >= 0) finish4x<TOut>(a, info, opl, rg, y0 + o, px, acc[s], xcur);
-            }
-        }
-        // slide the accumulator window down by SU rows
-#pragma unroll
-        for (int j = 0; j < SACC; ++j) acc[j] = (j + SU < SACC) ? acc[j + SU] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#undef KX
-#undef KY
-}
 
 // =============================================================================================
 // general kernels: workgroup tile body
@@ -322,11 +49,22 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
     }
     const int tid = threadIdx.x;
     if (inside && ((pitch | sx0) & 3) == 0) {
+        // interior tile: every 16-byte load of the tile is issued before the first one is consumed
         const T *base = plane + (long)sy0 * pitch + sx0;
         constexpr int C4 = LW / 4;
-        for (int e = tid; e < LH * C4; e += NT) {
+        constexpr int NLD = (LH * C4 + NT - 1) / NT;
+        float4 buf[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
             const int r = e / C4, c = e - r * C4;
-            *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = ld4<T>(base + (long)r * pitch + 4 * c);
+            if (e < LH * C4) buf[k] = ld4<T>(base + (long)r * pitch + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int r = e / C4, c = e - r * C4;
+            if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
         }
     } else {
         for (int e = tid; e < LH * LW; e += NT) {
@@ -386,68 +124,162 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     for (int r = 0; r < PR; ++r) finish4<TX, TOut>(a, info, xpl, opl, rg, oy0 + rgp * PR + r, ox0 + 4 * g, acc[r]);
 }
 
-constexpr size_t kTileLds = sizeof(float) * (GT + 2 * PB_KRAD) * (GT + 2 * PB_KRAD + 4);
+// ---------------------------------------------------------------------------------------------
+// rank-1 kernels in the tile geometry: x pass in place in LDS, y pass into registers.
+// Both passes run on packed FMAs (conv_common.h); rank-1 records carry symmetric marginals.
+// ---------------------------------------------------------------------------------------------
+template <int R, int P> __device__ __forceinline__ void xtap(f2 &acc, const f2 (&TP)[R + 1], f2 dpair, int) {}
+template <int R, int P, int HI> struct XTapApply {
+    static __device__ __forceinline__ void run(f2 &acc, const f2 (&TP)[R + 1], f2 dpair) {
+        if constexpr (P <= R) pk_bcast_data<0, HI>(acc, TP[P], dpair);
+        else pk_bcast_data<1, HI>(acc, TP[2 * R + 1 - P], dpair);
+    }
+};
+// window element J (0 .. 2R+3) feeds (x,y) with the tap pair T[J] and (z,w) with T[J-2]
+template <int R, int J> struct XPassR {
+    static __device__ __forceinline__ void run(f2 &vxy, f2 &vzw, const f2 (&TP)[R + 1], const f2 (&d)[R + 2]) {
+        if constexpr (J <= 2 * R + 1) XTapApply<R, J, J & 1>::run(vxy, TP, d[J >> 1]);
+        if constexpr (J >= 2) XTapApply<R, J - 2, J & 1>::run(vzw, TP, d[J >> 1]);
+        if constexpr (J < 2 * R + 3) XPassR<R, J + 1>::run(vxy, vzw, TP, d);
+    }
+};
+// input row I (0 .. 2R+3) of the thread's window feeds output row r with tap I - r
+template <int R, int I> struct YPassR {
+    static __device__ __forceinline__ void run(f2 (&axy)[4], f2 (&azw)[4], const f2 (&HY)[(R + 2) / 2], const float *col,
+                                               int pitch) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(col + I * pitch);
+        const f2 vxy = (f2){v4.x, v4.y}, vzw = (f2){v4.z, v4.w};
+#define PB_YROW(RR)                                                                   \
+        if constexpr (I - RR >= 0 && I - RR <= 2 * R) {                               \
+            constexpr int t = I - RR, q = t <= R ? t : 2 * R - t;                     \
+            pk_bcast_tap<q & 1>(axy[RR], HY[q >> 1], vxy);                            \
+            pk_bcast_tap<q & 1>(azw[RR], HY[q >> 1], vzw);                            \
+        }
+        PB_YROW(0) PB_YROW(1) PB_YROW(2) PB_YROW(3)
+#undef PB_YROW
+        if constexpr (I < 2 * R + 3) YPassR<R, I + 1>::run(axy, azw, HY, col, pitch);
+    }
+};
+
+template <typename TIn, typename TX, typename TOut, int R>
+__device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
+                                              TOut *opl, int tile, int tiles_x, float *smem) {
+    constexpr int LW = GT + 2 * R, LH = GT + 2 * R;
+    constexpr int LP = (LW + 4 + 31) / 32 * 32;   // row pitch: a multiple of 32 floats keeps 4-row strides conflict-free
+    const OutRegion rg = out_region(a);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
+    if (oy0 >= rg.y_hi) return;
+    load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
+    // taps: TP[p] = (h[p], h[p-1]),  HY[m] = (hy[2m], hy[2m+1]),  h = marginal taps 0..R of the class
+    const PB_CONSTANT float *ckx = as_constant(info->kx) + (PB_KRAD - R), *cky = as_constant(info->ky) + (PB_KRAD - R);
+    f2 TP[R + 1], HY[(R + 2) / 2];
+#pragma unroll
+    for (int t = 0; t <= R; ++t) TP[t] = (f2){ckx[t], t ? ckx[t - 1] : 0.f};
+#pragma unroll
+    for (int m = 0; m < (R + 2) / 2; ++m) HY[m] = (f2){cky[2 * m], 2 * m + 1 <= R ? cky[2 * m + 1] : 0.f};
+    __syncthreads();
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    // ---- x pass, in place: each wave owns LH/4 rows; a wave instruction covers 4 rows x 16 groups ----
+    {
+        constexpr int RPW = (LH + 3) / 4;                  // rows per wave
+        const int g = lane & 15, rsub = lane >> 4;
+        for (int it = 0; it < (RPW + 3) / 4; ++it) {
+            const int rr = wave * RPW + it * 4 + rsub;
+            const bool ok = (it * 4 + rsub) < RPW && rr < LH;
+            float *row = smem + (ok ? rr : 0) * LP;
+            f2 d[R + 2];
+#pragma unroll
+            for (int q = 0; q < 1 + R / 2; ++q) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(row + 4 * (g + q));
+                d[2 * q] = (f2){t4.x, t4.y};
+                d[2 * q + 1] = (f2){t4.z, t4.w};
+            }
+            f2 vxy = (f2){0.f, 0.f}, vzw = (f2){0.f, 0.f};
+            XPassR<R, 0>::run(vxy, vzw, TP, d);
+            wave_lds_fence();          // every lane of the wave has read its window before the row is overwritten
+            if (ok) *reinterpret_cast<float4 *>(row + 4 * g) = make_float4(vxy.x, vxy.y, vzw.x, vzw.y);
+            wave_lds_fence();
+        }
+    }
+    __syncthreads();
+    // ---- y pass: 4 x 4 outputs per thread from the x-filtered tile ----
+    const int g = tid & 15, rgp = tid >> 4;
+    f2 axy[4], azw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { axy[r] = (f2){0.f, 0.f}; azw[r] = (f2){0.f, 0.f}; }
+    YPassR<R, 0>::run(axy, azw, HY, smem + (rgp * 4) * LP + 4 * g, LP);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        finish4<TX, TOut>(a, info, xpl, opl, rg, oy0 + rgp * 4 + r, ox0 + 4 * g,
+                          make_float4(axy[r].x, axy[r].y, azw[r].x, azw[r].y));
+}
+
+constexpr size_t kTileLds = sizeof(float) * (GT + 2 * PB_KRAD) * 96;   // 88 rows x max(LP) floats
 
 template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(NT) void conv_pass_kernel(const ConvPass a, int blocks_per_plane, int tiles_x, int nsx,
-                                                       int nsy, int seg_h) {
+__global__ __launch_bounds__(NT) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int sep_in_tile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int plane = blockIdx.x / blocks_per_plane;
-    const int local = blockIdx.x - plane * blocks_per_plane;
+    const int plane = blockIdx.x / tiles_per_plane;
+    const int local = blockIdx.x - plane * tiles_per_plane;
     const pb_blur_info *info = a.info + plane / a.C;
+    const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
+    const bool sep = cinfo->separable != 0;
+    if (sep && !sep_in_tile) return;                               // rank-1 images take the streaming kernel
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
-    const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
-    if (cinfo->separable) {
-        const int task = local * (NT / 64) + (threadIdx.x >> 6);
-        if (task < nsx * nsy) body_stream<TIn, TX, TOut>(a, info, ipl, xpl, opl, task, nsx, seg_h, smem + (threadIdx.x >> 6) * SLINE);
-    } else {
-        const int R = a.force_full ? PB_KRAD : cinfo->radius;
-        if (R <= 4) body_tile<TIn, TX, TOut, 4>(a, info, ipl, xpl, opl, local, tiles_x, smem);
-        else if (R <= 8) body_tile<TIn, TX, TOut, 8>(a, info, ipl, xpl, opl, local, tiles_x, smem);
-        else body_tile<TIn, TX, TOut, 12>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+    const int R = a.force_full ? PB_KRAD : cinfo->radius;
+    if (sep) {
+        if (R <= 4) body_tile_sep<TIn, TX, TOut, 4>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+        else if (R <= 8) body_tile_sep<TIn, TX, TOut, 8>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+        else body_tile_sep<TIn, TX, TOut, 12>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+        return;
     }
+    if (R <= 4) body_tile<TIn, TX, TOut, 4>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+    else if (R <= 8) body_tile<TIn, TX, TOut, 8>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+    else body_tile<TIn, TX, TOut, 12>(a, info, ipl, xpl, opl, local, tiles_x, smem);
 }
 
 template <typename TIn, typename TX, typename TOut>
-int launch_typed(pb_ctx *ctx, const ConvPass &p) {
+int launch_typed(pb_ctx *ctx, const ConvPass &p, int sep_in_tile) {
     const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * PB_PAD;
     const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * PB_PAD;
     const int tiles_x = (ow + GT - 1) / GT, tiles_y = (oh + GT - 1) / GT;
-    // streaming decomposition: strips of 256 columns, cut vertically until the launch has enough
-    // waves to fill 256 CUs x 12 waves (short segments re-read 24 halo rows each)
-    const int nsx = (ow + SOUT - 1) / SOUT;
-    const long want_waves = 256L * 14;
-    long nsy = (want_waves + (long)p.P * nsx - 1) / ((long)p.P * nsx);
-    const long nsy_max = (oh + 31) / 32;
-    if (nsy > nsy_max) nsy = nsy_max;
-    if (nsy < 1) nsy = 1;
-    const int seg_h = (int)((oh + nsy - 1) / nsy);
-    const int nsy_i = (oh + seg_h - 1) / seg_h;
-    const long stream_blocks = ((long)nsx * nsy_i + NT / 64 - 1) / (NT / 64);
-    const long tile_blocks = (long)tiles_x * tiles_y;
-    const long bpp = stream_blocks > tile_blocks ? stream_blocks : tile_blocks;
-    const long blocks = bpp * p.P;
+    const long tpp = (long)tiles_x * tiles_y;
+    const long blocks = tpp * p.P;
     if (blocks <= 0 || blocks > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "conv pass: bad grid");
-    ProfScope prof(ctx, PB_PROF_CONV);
-    hipLaunchKernelGGL((conv_pass_kernel<TIn, TX, TOut>), dim3((unsigned)blocks), dim3(NT), kTileLds, ctx->stream, p,
-                       (int)bpp, tiles_x, nsx, nsy_i, seg_h);
+    hipLaunchKernelGGL((conv_tile_kernel<TIn, TX, TOut>), dim3((unsigned)blocks), dim3(NT), kTileLds, ctx->stream, p,
+                       (int)tpp, tiles_x, sep_in_tile);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
 
 }  // namespace
 
+// Both kernels are launched for every pass: each image's record decides on the device which of the
+// two does the work (the other's workgroups for that image exit at once), so a batch may mix
+// rank-1 and general kernels and the host never has to read the estimates back.
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
+    ProfScope prof(ctx, PB_PROF_CONV);
+    static int sep_in_tile = -1;          // PB_SEP_BODY=stream|tile selects the rank-1 body (default: tile)
+    if (sep_in_tile < 0) {
+        const char *e = getenv("PB_SEP_BODY");
+        sep_in_tile = (e && e[0] == 's') ? 0 : 1;
+    }
+    if (!sep_in_tile) {
+        int rc = pb_launch_conv_stream(ctx, p);
+        if (rc) return rc;
+    }
     const int key = p.in_dtype * 4 + p.x_dtype * 2 + p.out_dtype;
     switch (key) {
-        case 0: return launch_typed<float, float, float>(ctx, p);
-        case 1: return launch_typed<float, float, __half>(ctx, p);
-        case 2: return launch_typed<float, __half, float>(ctx, p);
-        case 3: return launch_typed<float, __half, __half>(ctx, p);
-        case 6: return launch_typed<__half, __half, float>(ctx, p);
-        case 7: return launch_typed<__half, __half, __half>(ctx, p);
+        case 0: return launch_typed<float, float, float>(ctx, p, sep_in_tile);
+        case 1: return launch_typed<float, float, __half>(ctx, p, sep_in_tile);
+        case 2: return launch_typed<float, __half, float>(ctx, p, sep_in_tile);
+        case 3: return launch_typed<float, __half, __half>(ctx, p, sep_in_tile);
+        case 6: return launch_typed<__half, __half, float>(ctx, p, sep_in_tile);
+        case 7: return launch_typed<__half, __half, __half>(ctx, p, sep_in_tile);
         default: return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: unsupported dtype combination %d", key);
     }
 }

@@ -1,0 +1,137 @@
+// Device helpers shared by the two bodies of the stencil pass (conv.hip, conv_stream.hip).
+#pragma once
+#include "common.h"
+
+namespace {
+
+#define PB_CONSTANT __attribute__((address_space(4)))
+
+// loads through the constant address space become scalar (s_load) when the address is uniform
+template <typename T> __device__ __forceinline__ const PB_CONSTANT T *as_constant(const T *p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const PB_CONSTANT T *)p;
+#pragma clang diagnostic pop
+}
+
+// compiler-only ordering of LDS traffic inside one wavefront (no instruction is emitted)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wrap_idx(int v, int n) {
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+// padded coordinate -> source index along one axis, or -1 for "reads as zero"
+__device__ __forceinline__ int map_axis(int p, int n_unpadded, int kind, int boundary) {
+    const int np = n_unpadded + 2 * PB_PAD;
+    if (boundary == PB_WRAP) p = wrap_idx(p, np);
+    else if (p < 0 || p >= np) return -1;
+    if (kind == SRC_VIRTUAL) return min(max(p - PB_PAD, 0), n_unpadded - 1);
+    return p;
+}
+
+__device__ __forceinline__ float taper_weight(const float *ac, int p, int n) {
+    // v[p] = 1 - z[p]/z[0], z = circular autocorrelation with period n-1, z[n-1] := z[0]
+    // (edgetaper.py:11-15): non-zero only within 24 samples of either end.
+    const int m = min(p, n - 1 - p);
+    const float z = (m < PB_KSIZE) ? ac[m] : 0.f;
+    return 1.f - z / ac[0];
+}
+
+template <typename T> __device__ __forceinline__ float4 ld4(const T *p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 ld4<__half>(const __half *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    const __half2 a = *reinterpret_cast<const __half2 *>(&u.x), b = *reinterpret_cast<const __half2 *>(&u.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+template <typename T> __device__ __forceinline__ void st4(T *p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+template <> __device__ __forceinline__ void st4<__half>(__half *p, float4 v) {
+    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+    uint2 u;
+    u.x = *reinterpret_cast<const unsigned *>(&a);
+    u.y = *reinterpret_cast<const unsigned *>(&b);
+    *reinterpret_cast<uint2 *>(p) = u;
+}
+
+// Where the outputs of a pass live, in padded coordinates.
+struct OutRegion { int y_lo, y_hi, x_lo, x_hi; };
+__device__ __forceinline__ OutRegion out_region(const ConvPass &a) {
+    if (a.out_kind == OUT_INTERIOR) return OutRegion{PB_PAD, PB_PAD + a.H, PB_PAD, PB_PAD + a.W};
+    return OutRegion{0, a.H + 2 * PB_PAD, 0, a.W + 2 * PB_PAD};
+}
+
+// Epilogue + store of 4 horizontally adjacent outputs at padded (py, px..px+3).
+template <typename TX, typename TOut>
+__device__ __forceinline__ void finish4(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl,
+                                        const OutRegion &rg, int py, int px, float4 acc) {
+    if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi) return;
+    const int H = a.H, W = a.W;
+    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
+    float av[4] = {acc.x, acc.y, acc.z, acc.w};
+    float xv[4];
+    const bool full = px >= rg.x_lo && px + 3 < rg.x_hi;
+    // x operand: rows clamp uniformly; a 16-byte load when the four columns are contiguous in the source
+    const int xr = (a.x_kind == SRC_VIRTUAL) ? min(max(py - PB_PAD, 0), H - 1) : py;
+    const int xc0 = (a.x_kind == SRC_VIRTUAL) ? px - PB_PAD : px;
+    const int xcmax = (a.x_kind == SRC_VIRTUAL) ? W : Wp;
+    const TX *xrow = xpl + (long)xr * a.x_pitch;
+    if (full && xc0 >= 0 && xc0 + 3 < xcmax && ((a.x_pitch | xc0) & 3) == 0) {
+        const float4 t = ld4<TX>(xrow + xc0);
+        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = pb_ld(xrow + min(max(xc0 + i, 0), xcmax - 1));
+    }
+    float ty = 1.f;
+    if (a.epilogue == EPI_TAPER) ty = taper_weight(info->acorr_y, py, Hp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v;
+        if (a.epilogue == EPI_TAPER) {
+            const float al = ty * taper_weight(info->acorr_x, px + i, Wp);
+            v = al * xv[i] + (1.f - al) * av[i];
+        } else {
+            v = a.scale * av[i] + a.coef * xv[i];
+        }
+        if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        av[i] = v;
+    }
+    const int orow = (a.out_kind == OUT_INTERIOR) ? py - PB_PAD : py;
+    const int oc0 = (a.out_kind == OUT_INTERIOR) ? px - PB_PAD : px;
+    TOut *orow_p = opl + (long)orow * a.out_pitch;
+    if (full && ((a.out_pitch | oc0) & 3) == 0) {
+        st4<TOut>(orow_p + oc0, make_float4(av[0], av[1], av[2], av[3]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (px + i >= rg.x_lo && px + i < rg.x_hi) pb_st(orow_p + oc0 + i, av[i]);
+    }
+}
+
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// acc.lo += taps.(SWAP ? hi : lo) * d,  acc.hi += taps.(SWAP ? lo : hi) * d,  d = data.(HI ? hi : lo)
+// One v_pk_fma_f32 = two FMAs; the tap pair sits in an aligned SGPR pair, op_sel does the rest.
+template <int SWAP, int HI> __device__ __forceinline__ void pk_bcast_data(f2 &acc, f2 taps, f2 data) {
+    if (!SWAP && !HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(taps), "v"(data));
+    if (!SWAP && HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(taps), "v"(data));
+    if (SWAP && !HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "s"(taps), "v"(data));
+    if (SWAP && HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(taps), "v"(data));
+}
+// acc += taps.(HI ? hi : lo) * data   (both halves use the same tap)
+template <int HI> __device__ __forceinline__ void pk_bcast_tap(f2 &acc, f2 taps, f2 data) {
+    if (!HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(taps), "v"(data));
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(taps), "v"(data));
+}
+
+
+}  // namespace
