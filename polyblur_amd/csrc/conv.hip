@@ -75,6 +75,49 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
     }
 }
 
+// Per-thread epilogue of a 4 x 4 output block.  `prefetch` is called right after the tile loads have
+// been issued so that the x operand arrives while the stencil is evaluated; blocks that touch the
+// border of the output region (or a clamped / unaligned x operand, or the taper blend) take finish4.
+template <typename TX, typename TOut> struct Block4x4Epilogue {
+    bool fast;
+    float4 xr[4];
+    const TX *xp;
+    TOut *op;
+    __device__ __forceinline__ void prefetch(const ConvPass &a, const TX *xpl, TOut *opl, const OutRegion &rg, int py, int px) {
+        const int xo = a.x_kind == SRC_VIRTUAL ? PB_PAD : 0, oo = a.out_kind == OUT_INTERIOR ? PB_PAD : 0;
+        const int xrows = a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * PB_PAD, xcols = a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * PB_PAD;
+        fast = a.epilogue == EPI_HORNER && py + 3 < rg.y_hi && px + 3 < rg.x_hi && py - xo >= 0 && py - xo + 3 < xrows &&
+               px - xo >= 0 && px - xo + 3 < xcols && ((a.x_pitch | a.out_pitch) & 3) == 0;
+        if (fast) {
+            xp = xpl + (long)(py - xo) * a.x_pitch + (px - xo);
+            op = opl + (long)(py - oo) * a.out_pitch + (px - oo);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xr[r] = ld4<TX>(xp + (long)r * a.x_pitch);
+        }
+    }
+    __device__ __forceinline__ void finish(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl,
+                                           const OutRegion &rg, int py, int px, const float4 (&acc)[4]) {
+        if (fast) {
+            const float sc = a.scale, cf = a.coef;
+            const bool cl = a.clamp01 != 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 v;
+                v.x = fmaf(sc, acc[r].x, cf * xr[r].x); v.y = fmaf(sc, acc[r].y, cf * xr[r].y);
+                v.z = fmaf(sc, acc[r].z, cf * xr[r].z); v.w = fmaf(sc, acc[r].w, cf * xr[r].w);
+                if (cl) {
+                    v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                    v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                }
+                st4<TOut>(op + (long)r * a.out_pitch, v);
+            }
+        } else {
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) finish4<TX, TOut>(a, info, xpl, opl, rg, py + r, px, acc[r]);
+        }
+    }
+};
+
 template <typename TIn, typename TX, typename TOut, int R>
 __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
                                           TOut *opl, int tile, int tiles_x, float *smem) {
@@ -87,10 +130,10 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
-    load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
-    __syncthreads();
     const int tid = threadIdx.x;
     const int g = tid & 15, rgp = tid >> 4;    // 16 column groups x 16 row groups
+    load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
+    __syncthreads();
     float4 acc[PR];
 #pragma unroll
     for (int r = 0; r < PR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -120,8 +163,10 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < PR; ++r) finish4<TX, TOut>(a, info, xpl, opl, rg, oy0 + rgp * PR + r, ox0 + 4 * g, acc[r]);
+    // VALU-bound body: fetch the x operand only now (keeps 16 registers free during the stencil)
+    Block4x4Epilogue<TX, TOut> epi;
+    epi.prefetch(a, xpl, opl, rg, oy0 + rgp * PR, ox0 + 4 * g);
+    epi.finish(a, info, xpl, opl, rg, oy0 + rgp * PR, ox0 + 4 * g, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,6 +215,8 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
+    Block4x4Epilogue<TX, TOut> epi;
+    epi.prefetch(a, xpl, opl, rg, oy0 + (threadIdx.x >> 4) * 4, ox0 + 4 * (threadIdx.x & 15));
     load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
     // taps: TP[p] = (h[p], h[p-1]),  HY[m] = (hy[2m], hy[2m+1]),  h = marginal taps 0..R of the class
     const PB_CONSTANT float *ckx = as_constant(info->kx) + (PB_KRAD - R), *cky = as_constant(info->ky) + (PB_KRAD - R);
@@ -184,7 +231,9 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     // ---- x pass, in place: each wave owns LH/4 rows; a wave instruction covers 4 rows x 16 groups ----
     {
         constexpr int RPW = (LH + 3) / 4;                  // rows per wave
-        const int g = lane & 15, rsub = lane >> 4;
+        // LP = 96 floats puts consecutive rows 8 sixteen-byte slots apart; the two rows that share a
+        // 32-lane half are read conflict-free when the odd one starts 8 groups further along the row
+        const int rsub = lane >> 4, g = ((lane & 15) + 8 * (rsub & 1)) & 15;
         for (int it = 0; it < (RPW + 3) / 4; ++it) {
             const int rr = wave * RPW + it * 4 + rsub;
             const bool ok = (it * 4 + rsub) < RPW && rr < LH;
@@ -210,19 +259,25 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
 #pragma unroll
     for (int r = 0; r < 4; ++r) { axy[r] = (f2){0.f, 0.f}; azw[r] = (f2){0.f, 0.f}; }
     YPassR<R, 0>::run(axy, azw, HY, smem + (rgp * 4) * LP + 4 * g, LP);
+    float4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        finish4<TX, TOut>(a, info, xpl, opl, rg, oy0 + rgp * 4 + r, ox0 + 4 * g,
-                          make_float4(axy[r].x, axy[r].y, azw[r].x, azw[r].y));
+    for (int r = 0; r < 4; ++r) acc[r] = make_float4(axy[r].x, axy[r].y, azw[r].x, azw[r].y);
+    epi.finish(a, info, xpl, opl, rg, oy0 + rgp * 4, ox0 + 4 * g, acc);
 }
 
 constexpr size_t kTileLds = sizeof(float) * (GT + 2 * PB_KRAD) * 96;   // 88 rows x max(LP) floats
 
 template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(NT) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int sep_in_tile) {
+__global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int sep_in_tile, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int plane = blockIdx.x / tiles_per_plane;
-    const int local = blockIdx.x - plane * tiles_per_plane;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), so
+    // give every XCD one contiguous run of tiles -- row-neighbours then share their halos in that
+    // XCD's L2 instead of each fetching them from memory.  The grid is padded to a multiple of 8.
+    const int chunk = gridDim.x >> 3;
+    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile_id >= total_tiles) return;
+    const int plane = tile_id / tiles_per_plane;
+    const int local = tile_id - plane * tiles_per_plane;
     const pb_blur_info *info = a.info + plane / a.C;
     const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
     const bool sep = cinfo->separable != 0;
@@ -250,8 +305,9 @@ int launch_typed(pb_ctx *ctx, const ConvPass &p, int sep_in_tile) {
     const long tpp = (long)tiles_x * tiles_y;
     const long blocks = tpp * p.P;
     if (blocks <= 0 || blocks > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "conv pass: bad grid");
-    hipLaunchKernelGGL((conv_tile_kernel<TIn, TX, TOut>), dim3((unsigned)blocks), dim3(NT), kTileLds, ctx->stream, p,
-                       (int)tpp, tiles_x, sep_in_tile);
+    const long grid = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((conv_tile_kernel<TIn, TX, TOut>), dim3((unsigned)grid), dim3(NT), kTileLds, ctx->stream, p,
+                       (int)tpp, tiles_x, sep_in_tile, (int)blocks);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

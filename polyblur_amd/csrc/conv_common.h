@@ -40,7 +40,7 @@ __device__ __forceinline__ float taper_weight(const float *ac, int p, int n) {
     // (edgetaper.py:11-15): non-zero only within 24 samples of either end.
     const int m = min(p, n - 1 - p);
     const float z = (m < PB_KSIZE) ? ac[m] : 0.f;
-    return 1.f - z / ac[0];
+    return 1.f - z * __frcp_rn(ac[0]);
 }
 
 template <typename T> __device__ __forceinline__ float4 ld4(const T *p);
