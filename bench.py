@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="1080x1920", help="HxW crop the CPU baseline is timed on")
+    ap.add_argument("--cpu-sample", default="2160x3840", help="HxW crop the CPU baseline is timed on")
     return ap.parse_args()
 
 
