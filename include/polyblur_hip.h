@@ -98,6 +98,8 @@ typedef struct pb_blur_info {
     float acorr_y[PB_KSIZE], acorr_x[PB_KSIZE]; /* autocorrelation of ky / kx at lags 0..24: the closed
                                            form of edgetaper_alpha's 1-D FFTs (edgetaper.py:11-21) */
     float gtaps[PB_KSIZE * 32];         /* kernel rows re-laid for the tile stencil: row y = {0,0,0, k[y][0..24], 0,0,0,0} */
+    float gtaps_odd[PB_KSIZE * 32];     /* the same rows shifted by one tap (gtaps_odd[y][n] = gtaps[y][n+1]): the second
+                                           alignment of tap pairs for the packed-FMA stencil */
 } pb_blur_info;
 
 /* ---- context ------------------------------------------------------------------------- */

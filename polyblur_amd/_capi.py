@@ -51,7 +51,7 @@ class pb_blur_info(C.Structure):
         ("sigma", C.c_float), ("rho", C.c_float), ("separable", C.c_int32), ("radius", C.c_int32),
         ("kernel", C.c_float * (PB_KSIZE * PB_KSIZE)), ("kx", C.c_float * PB_KSIZE), ("ky", C.c_float * PB_KSIZE),
         ("acorr_y", C.c_float * PB_KSIZE), ("acorr_x", C.c_float * PB_KSIZE),
-        ("gtaps", C.c_float * (PB_KSIZE * 32)),
+        ("gtaps", C.c_float * (PB_KSIZE * 32)), ("gtaps_odd", C.c_float * (PB_KSIZE * 32)),
     ]
 
 
@@ -60,6 +60,7 @@ INFO_DTYPE = np.dtype([
     ("i_min", "<i4"), ("theta", "<f4"), ("sigma", "<f4"), ("rho", "<f4"), ("separable", "<i4"), ("radius", "<i4"),
     ("kernel", "<f4", (PB_KSIZE, PB_KSIZE)), ("kx", "<f4", (PB_KSIZE,)), ("ky", "<f4", (PB_KSIZE,)),
     ("acorr_y", "<f4", (PB_KSIZE,)), ("acorr_x", "<f4", (PB_KSIZE,)), ("gtaps", "<f4", (PB_KSIZE, 32)),
+    ("gtaps_odd", "<f4", (PB_KSIZE, 32)),
 ])
 assert INFO_DTYPE.itemsize == C.sizeof(pb_blur_info)
 

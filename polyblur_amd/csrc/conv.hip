@@ -118,13 +118,34 @@ template <typename TX, typename TOut> struct Block4x4Epilogue {
     }
 };
 
+// One window row of the general stencil: element m of the thread's window (column c0 - R + m) feeds
+// the four outputs c0 .. c0+3 with taps t[m+3], t[m+2], t[m+1], t[m] (t = the kernel row, zero padded by
+// 3).  Two packed FMAs per element: (x,y) += (t[m+3], t[m+2]) * s,  (z,w) += (t[m+1], t[m]) * s, with
+// the tap pair in an aligned SGPR pair -- TA[i] = (t[2i], t[2i+1]) or TB[i] = (t[2i+1], t[2i+2]) -- read
+// swapped through op_sel, and the sample broadcast from its register pair.
+template <int R, int M, int NP> struct GenRow {
+    static __device__ __forceinline__ void run(f2 &axy, f2 &azw, const f2 (&TA)[NP], const f2 (&TB)[NP], const f2 (&d)[R + 2]) {
+        constexpr bool full = R == PB_KRAD;              // at R = 12 the padding taps are exact zeros: skip them
+        if constexpr (!(full && M >= 2 * R + 2)) {       // (t[m+3], t[m+2])
+            constexpr int n = M + 2;
+            if constexpr ((n & 1) == 0) pk_bcast_data<1, M & 1>(axy, TA[n >> 1], d[M >> 1]);
+            else pk_bcast_data<1, M & 1>(axy, TB[(n - 1) >> 1], d[M >> 1]);
+        }
+        if constexpr (!(full && M < 2)) {                // (t[m+1], t[m])
+            if constexpr ((M & 1) == 0) pk_bcast_data<1, M & 1>(azw, TA[M >> 1], d[M >> 1]);
+            else pk_bcast_data<1, M & 1>(azw, TB[(M - 1) >> 1], d[M >> 1]);
+        }
+        if constexpr (M + 1 < 2 * R + 4) GenRow<R, M + 1, NP>::run(axy, azw, TA, TB, d);
+    }
+};
+
 template <typename TIn, typename TX, typename TOut, int R>
 __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
                                           TOut *opl, int tile, int tiles_x, float *smem) {
     constexpr int LW = GT + 2 * R, LH = GT + 2 * R, NTAP = 2 * R + 1;
-    constexpr int LP = LW + 4;                 // row pitch in LDS (floats), keeps 16-byte alignment
+    constexpr int LP = 96;                     // LDS row pitch (floats): 4-row strides land on distinct banks
     constexpr int WCH = 1 + R / 2;             // float4 chunks per window row
-    constexpr int NTP = 4 * WCH + 3;           // taps that can touch a window (3 zeros either side at R = 12)
+    constexpr int NP = 2 * WCH + 2;            // tap pairs per copy (taps n = 0 .. 4 WCH + 3)
     constexpr int PR = 4;
     const OutRegion rg = out_region(a);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -134,35 +155,37 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     const int g = tid & 15, rgp = tid >> 4;    // 16 column groups x 16 row groups
     load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
     __syncthreads();
-    float4 acc[PR];
+    f2 axy[PR], azw[PR];
 #pragma unroll
-    for (int r = 0; r < PR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // gtaps[dy] = {0,0,0, k[dy][0..24], 0,0,0,0}: window element m feeds output i with tap t[m - i + 3]
-    const PB_CONSTANT float *taps = as_constant(info->gtaps) + (PB_KRAD - R) * 32 + (PB_KRAD - R);
+    for (int r = 0; r < PR; ++r) { axy[r] = (f2){0.f, 0.f}; azw[r] = (f2){0.f, 0.f}; }
+    // gtaps[y] = {0,0,0, k[y][0..24], 0,0,0,0}, gtaps_odd[y][n] = gtaps[y][n+1]; class R reads from column 12-R
+    const PB_CONSTANT float *ta = as_constant(info->gtaps) + (PB_KRAD - R) * 32 + (PB_KRAD - R);
+    const PB_CONSTANT float *tb = as_constant(info->gtaps_odd) + (PB_KRAD - R) * 32 + (PB_KRAD - R);
     const float *base = smem + (rgp * PR) * LP + 4 * g;
 #pragma unroll 1
     for (int dy = 0; dy < NTAP; ++dy) {
-        float t[NTP];
+        f2 TA[NP], TB[NP];
 #pragma unroll
-        for (int n = 0; n < NTP; ++n) t[n] = taps[dy * 32 + n];
+        for (int i = 0; i < NP; ++i) {
+            TA[i] = (f2){ta[dy * 32 + 2 * i], ta[dy * 32 + 2 * i + 1]};
+            TB[i] = (f2){tb[dy * 32 + 2 * i], tb[dy * 32 + 2 * i + 1]};
+        }
 #pragma unroll
         for (int r = 0; r < PR; ++r) {
             const float4 *src = reinterpret_cast<const float4 *>(base + (r + dy) * LP);
-            float seg[4 * WCH];
+            f2 d[R + 2];
 #pragma unroll
             for (int q = 0; q < WCH; ++q) {
                 const float4 v = src[q];
-                seg[4 * q] = v.x; seg[4 * q + 1] = v.y; seg[4 * q + 2] = v.z; seg[4 * q + 3] = v.w;
+                d[2 * q] = (f2){v.x, v.y};
+                d[2 * q + 1] = (f2){v.z, v.w};
             }
-#pragma unroll
-            for (int m = 0; m < 4 * WCH; ++m) {
-                acc[r].x = fmaf(t[m + 3], seg[m], acc[r].x);
-                acc[r].y = fmaf(t[m + 2], seg[m], acc[r].y);
-                acc[r].z = fmaf(t[m + 1], seg[m], acc[r].z);
-                acc[r].w = fmaf(t[m], seg[m], acc[r].w);
-            }
+            GenRow<R, 0, NP>::run(axy[r], azw[r], TA, TB, d);
         }
     }
+    float4 acc[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) acc[r] = make_float4(axy[r].x, axy[r].y, azw[r].x, azw[r].y);
     // VALU-bound body: fetch the x operand only now (keeps 16 registers free during the stencil)
     Block4x4Epilogue<TX, TOut> epi;
     epi.prefetch(a, xpl, opl, rg, oy0 + rgp * PR, ox0 + 4 * g);

@@ -190,22 +190,57 @@ pbfft::DevPlan dev_plan(const FftPlan *pl) {
 // ------------------------------------------------------------------------------------
 // gray + min/max
 // ------------------------------------------------------------------------------------
-template <typename T>
+template <typename T> __device__ __forceinline__ float4 ld4e(const T *p);
+template <> __device__ __forceinline__ float4 ld4e<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 ld4e<__half>(const __half *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&u.x)), b = __half22float2(*reinterpret_cast<const __half2 *>(&u.y));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
+// VEC: HW % 4 == 0, so every plane starts 16-byte aligned and the image is walked in float4 units.
+// CC: compile-time channel count (1 or 3; 0 = run-time C) so that all channel loads of a sample
+// group are independent and in flight together.
+template <typename T, bool VEC, int CC>
 __global__ __launch_bounds__(NT) void gray_minmax_kernel(const T *__restrict__ in, float *__restrict__ gray,
-                                                         unsigned *__restrict__ mm, int C, long HW, int blocks_per_image) {
+                                                         float2 *__restrict__ part, int Crt, long HW, int blocks_per_image) {
+    const int C = CC ? CC : Crt;
     const int b = blockIdx.x / blocks_per_image;
     const int blk = blockIdx.x - b * blocks_per_image;
     const T *src = in + (long)b * C * HW;
     float *dst = gray + (long)b * HW;
     float lo = INFINITY, hi = -INFINITY;
     const float invc = 1.f / (float)C;
-    for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)blocks_per_image * NT) {
-        float s = pb_ld(src + i);
-        for (int c = 1; c < C; ++c) s += pb_ld(src + c * HW + i);
-        const float g = (C == 1) ? s : ((C == 3) ? s / 3.0f : s * invc);
-        dst[i] = g;
-        lo = fminf(lo, g);
-        hi = fmaxf(hi, g);
+    if (VEC) {
+        const long n4 = HW >> 2;
+        for (long i = (long)blk * NT + threadIdx.x; i < n4; i += (long)blocks_per_image * NT) {
+            float4 s4 = ld4e<T>(src + 4 * i);
+            if (CC == 3) {
+                const float4 t1 = ld4e<T>(src + HW + 4 * i), t2 = ld4e<T>(src + 2 * HW + 4 * i);
+                s4.x = s4.x + t1.x + t2.x; s4.y = s4.y + t1.y + t2.y; s4.z = s4.z + t1.z + t2.z; s4.w = s4.w + t1.w + t2.w;
+            } else {
+                for (int c = 1; c < C; ++c) {
+                    const float4 t = ld4e<T>(src + c * HW + 4 * i);
+                    s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
+                }
+            }
+            float4 g;
+            if (C == 1) g = s4;
+            else if (C == 3) g = make_float4(s4.x / 3.0f, s4.y / 3.0f, s4.z / 3.0f, s4.w / 3.0f);
+            else g = make_float4(s4.x * invc, s4.y * invc, s4.z * invc, s4.w * invc);
+            *reinterpret_cast<float4 *>(dst + 4 * i) = g;
+            lo = fminf(fminf(lo, fminf(g.x, g.y)), fminf(g.z, g.w));
+            hi = fmaxf(fmaxf(hi, fmaxf(g.x, g.y)), fmaxf(g.z, g.w));
+        }
+    } else {
+        for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)blocks_per_image * NT) {
+            float s = pb_ld(src + i);
+            for (int c = 1; c < C; ++c) s += pb_ld(src + c * HW + i);
+            const float g = (C == 1) ? s : ((C == 3) ? s / 3.0f : s * invc);
+            dst[i] = g;
+            lo = fminf(lo, g);
+            hi = fmaxf(hi, g);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -217,15 +252,34 @@ __global__ __launch_bounds__(NT) void gray_minmax_kernel(const T *__restrict__ i
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < NT / 64; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
-        atomicMin(mm + 2 * b, pb_f2ord(lo));
-        atomicMax(mm + 2 * b + 1, pb_f2ord(hi));
+        // one partial per workgroup, folded by minmax_reduce_kernel: atomics on one address serialise at
+        // ~20 ns each (measured, tools/ubench3.hip) and would cost 3x the whole image read
+        part[(long)b * blocks_per_image + blk] = make_float2(lo, hi);
     }
 }
 
-__global__ void init_minmax_kernel(unsigned *mm, unsigned *mags, int B, int na) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) { mm[2 * i] = 0xffffffffu; mm[2 * i + 1] = 0u; }
-    if (i < B * na) mags[i] = 0u;
+__global__ __launch_bounds__(NT) void minmax_reduce_kernel(const float2 *__restrict__ part, unsigned *__restrict__ mm,
+                                                           int blocks_per_image) {
+    const int b = blockIdx.x;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < blocks_per_image; i += NT) {
+        const float2 p = part[(long)b * blocks_per_image + i];
+        lo = fminf(lo, p.x);
+        hi = fmaxf(hi, p.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    __shared__ float slo[NT / 64], shi[NT / 64];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NT / 64; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+        mm[2 * b] = pb_f2ord(lo);
+        mm[2 * b + 1] = pb_f2ord(hi);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -277,13 +331,18 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
                                                        float *__restrict__ gy, int H, int W, int lognb,
                                                        const unsigned *__restrict__ mm, int planes_per_image,
                                                        unsigned *__restrict__ mags, int n_angles, int discard_sat,
-                                                       float sat_threshold, pbfft::DevPlan plan) {
+                                                       float sat_threshold, int total_tiles, pbfft::DevPlan plan) {
     extern __shared__ __attribute__((aligned(16))) float2 sfft[];
     const int nb = 1 << lognb;
     const int tc = 2 * nb;
     const int tiles = (W + tc - 1) / tc;
-    const int plane = blockIdx.x / tiles;
-    const int c0 = (blockIdx.x - plane * tiles) * tc;
+    // adjacent column tiles share 128-byte lines: give each XCD (= blockIdx % 8, speed only) a contiguous
+    // run of tiles so that those lines are fetched into one L2 once (grid padded to a multiple of 8)
+    const int chunk = gridDim.x >> 3;
+    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile_id >= total_tiles) return;
+    const int plane = tile_id / tiles;
+    const int c0 = (tile_id - plane * tiles) * tc;
     const float *src = planes + (long)plane * H * W;
     float lo = 0.f, scale = 1.f;
     if (NORMALIZE) {
@@ -353,8 +412,8 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
         if ((int)threadIdx.x <= n_angles) {
             float m = red[threadIdx.x];
             for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w * PB_MAX_ANGLES + threadIdx.x]);
-            const int img = plane / planes_per_image;
-            atomicMax(mags + img * PB_MAX_ANGLES + threadIdx.x, __float_as_uint(m));   // m >= 0
+            // one partial row per column tile; blur_params_kernel folds them (no contended atomics)
+            mags[(long)tile_id * PB_MAX_ANGLES + threadIdx.x] = __float_as_uint(m);   // m >= 0
         }
     }
 }
@@ -438,6 +497,7 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     for (int idx = tid; idx < PB_KSIZE * 32; idx += NT) {
         const int y = idx >> 5, j = (idx & 31) - 3;
         info->gtaps[idx] = (j >= 0 && j < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j] : 0.f;
+        info->gtaps_odd[idx] = (j + 1 >= 0 && j + 1 < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j + 1] : 0.f;
     }
     // rank-1 residual  sum |k - ky (x) kx|  and the total mass (for arbitrary taps)
     float res = 0.f;
@@ -463,39 +523,57 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
 __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, const unsigned *__restrict__ mm,
                                                          const unsigned *__restrict__ mags_u,
                                                          const float *__restrict__ wts, int n_angles, int n_interp,
-                                                         float c, float b, int support, float force_theta_deg) {
+                                                         float c, float b, int support, float force_theta_deg,
+                                                         int tiles_per_image) {
     __shared__ float red[NT / 64];
+    __shared__ float s_mags[PB_MAX_ANGLES], s_interp[PB_MAX_INTERP];
     pb_blur_info *info = infos + blockIdx.x;
+    const int na = n_angles + 1;
+    {
+        // fold the per-tile partial maxima of this image: thread t handles angle t % 16, tiles t/16, t/16+16, ...
+        __shared__ float s_part[NT];
+        const int k = threadIdx.x & 15, lane_t = threadIdx.x >> 4;
+        float m = 0.f;
+        if (k < na)
+            for (int t = lane_t; t < tiles_per_image; t += NT / 16)
+                m = fmaxf(m, __uint_as_float(mags_u[((long)blockIdx.x * tiles_per_image + t) * PB_MAX_ANGLES + k]));
+        s_part[threadIdx.x] = m;
+        __syncthreads();
+        if (threadIdx.x < PB_MAX_ANGLES) {
+            float v = 0.f;
+            if ((int)threadIdx.x < na)
+                for (int j = 0; j < NT / 16; ++j) v = fmaxf(v, s_part[j * 16 + threadIdx.x]);
+            s_mags[threadIdx.x] = v;
+            info->mags[threadIdx.x] = v;
+        }
+    }
+    __syncthreads();
+    // cubic interpolation to n_interp angles (blur_estimation.py:156-157): one lane per angle
+    if (threadIdx.x < PB_MAX_INTERP) {
+        float v = 0.f;
+        if ((int)threadIdx.x < n_interp)
+            for (int k = 0; k < na; ++k) v += wts[threadIdx.x * na + k] * s_mags[k];
+        s_interp[threadIdx.x] = v;
+        info->interp[threadIdx.x] = v;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const int na = n_angles + 1;
         info->gray_min = pb_ord2f(mm[2 * blockIdx.x]);
         info->gray_max = pb_ord2f(mm[2 * blockIdx.x + 1]);
-        float mags[PB_MAX_ANGLES];
-        for (int k = 0; k < PB_MAX_ANGLES; ++k) {
-            mags[k] = k < na ? __uint_as_float(mags_u[blockIdx.x * PB_MAX_ANGLES + k]) : 0.f;
-            info->mags[k] = mags[k];
-        }
-        // cubic interpolation to n_interp angles + argmin (blur_estimation.py:156-160)
-        int i_min = 0;
+        int i_min = 0;                                           // argmin, first minimum (:160)
         float vmin = INFINITY;
-        for (int i = 0; i < PB_MAX_INTERP; ++i) {
-            float v = 0.f;
-            if (i < n_interp) {
-                for (int k = 0; k < na; ++k) v += wts[i * na + k] * mags[k];
-                if (v < vmin) { vmin = v; i_min = i; }
-            }
-            info->interp[i] = v;
-        }
+        for (int i = 0; i < n_interp; ++i)
+            if (s_interp[i] < vmin) { vmin = s_interp[i]; i_min = i; }
         const float step = 180.0f / (float)n_interp;
         int theta_deg = (int)((float)i_min * step);            // interpolated_thetas.long()
         if (force_theta_deg >= 0.f) {
             theta_deg = (int)force_theta_deg;
             i_min = (int)((float)theta_deg / step);
-            vmin = info->interp[i_min];
+            vmin = s_interp[i_min];
         }
         const int ortho_deg = (theta_deg + 90) % 180;
         const int i_ortho = (int)((float)ortho_deg / step);
-        const float m_n = vmin, m_o = info->interp[i_ortho];
+        const float m_n = vmin, m_o = s_interp[i_ortho];
         const float cc = c * c, bb = b * b;
         info->sigma = sqrtf(fminf(fmaxf(cc / (m_n * m_n + 1e-8f) - bb, 0.09f), 16.0f));
         info->rho = sqrtf(fminf(fmaxf(cc / (m_o * m_o + 1e-8f) - bb, 0.09f), 16.0f));
@@ -569,8 +647,9 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     do {                                                                                                         \
         int rc = allow_lds(ctx, grad_cols_kernel<MODE, NORM>, lds);                                              \
         if (rc) return rc;                                                                                       \
-        hipLaunchKernelGGL((grad_cols_kernel<MODE, NORM>), dim3((unsigned)blocks), dim3(NT), lds, ctx->stream,    \
-                           planes, gx, gy, H, W, lognb, mm, planes_per_image, mags, n_angles, discard_sat, thr, dp); \
+        hipLaunchKernelGGL((grad_cols_kernel<MODE, NORM>), dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(NT), lds,  \
+                           ctx->stream, planes, gx, gy, H, W, lognb, mm, planes_per_image, mags, n_angles,        \
+                           discard_sat, thr, (int)blocks, dp);                                                    \
     } while (0)
     if (mode == 0) { if (normalize) PB_COLS(0, true); else PB_COLS(0, false); }
     else { if (normalize) PB_COLS(1, true); else PB_COLS(1, false); }
@@ -595,27 +674,34 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
         opt->n_interpolated_angles > PB_MAX_INTERP)
         return pb_fail(ctx, PB_ERR_BADARG, "n_angles / n_interpolated_angles out of range");
     const long HW = (long)H * W;
+    const FftPlan *plh = pb_get_plan(ctx, H);
+    if (!plh) return PB_ERR_NOMEM;
+    const int col_tiles = (W + (2 << pick_lognb(plh, W)) - 1) / (2 << pick_lognb(plh, W));   // as launch_cols
     float *gray = static_cast<float *>(pb_scratch(ctx, "est.gray", sizeof(float) * B * HW));
     float *gx = static_cast<float *>(pb_scratch(ctx, "est.gx", sizeof(float) * B * HW));
-    unsigned *mm = static_cast<unsigned *>(pb_scratch(ctx, "est.mm", sizeof(unsigned) * (2 * B + (size_t)B * PB_MAX_ANGLES)));
-    if (!gray || !gx || !mm) return PB_ERR_NOMEM;
-    unsigned *mags = mm + 2 * B;
+    unsigned *mm = static_cast<unsigned *>(pb_scratch(ctx, "est.mm", sizeof(unsigned) * 2 * B));
+    unsigned *mags = static_cast<unsigned *>(pb_scratch(ctx, "est.mags", sizeof(unsigned) * (size_t)B * col_tiles * PB_MAX_ANGLES));
+    if (!gray || !gx || !mm || !mags) return PB_ERR_NOMEM;
     const float *wts = pb_get_interp_weights(ctx, opt->n_angles, opt->n_interpolated_angles);
     if (!wts) return PB_ERR_NOMEM;
-    const int ninit = B * PB_MAX_ANGLES;
     {
     ProfScope prof(ctx, PB_PROF_GRAY);
-    hipLaunchKernelGGL(init_minmax_kernel, dim3((ninit + 255) / 256), dim3(256), 0, ctx->stream, mm, mags, B, PB_MAX_ANGLES);
-    PB_LAUNCH_CHECK();
-    int bpi = (int)((HW + NT * 8 - 1) / (NT * 8));
-    if (bpi > 1024) bpi = 1024;
+    const bool vec = (HW & 3) == 0;
+    int bpi = (int)((HW / (vec ? 4 : 1) + NT * 4 - 1) / (NT * 4));
+    const int bpi_max = (2048 + B - 1) / B;
+    if (bpi > bpi_max) bpi = bpi_max;
     if (bpi < 1) bpi = 1;
-    if (dtype == PB_F32)
-        hipLaunchKernelGGL(gray_minmax_kernel<float>, dim3(B * bpi), dim3(NT), 0, ctx->stream,
-                           static_cast<const float *>(in), gray, mm, C, HW, bpi);
-    else
-        hipLaunchKernelGGL(gray_minmax_kernel<__half>, dim3(B * bpi), dim3(NT), 0, ctx->stream,
-                           static_cast<const __half *>(in), gray, mm, C, HW, bpi);
+    float2 *part = static_cast<float2 *>(pb_scratch(ctx, "est.part", sizeof(float2) * ((size_t)B * bpi)));
+    if (!part) return PB_ERR_NOMEM;
+#define PB_GRAY(T, V, CC)                                                                                           \
+    hipLaunchKernelGGL((gray_minmax_kernel<T, V, CC>), dim3(B * bpi), dim3(NT), 0, ctx->stream,                     \
+                       static_cast<const T *>(in), gray, part, C, HW, bpi)
+#define PB_GRAY_C(T, V) do { if (C == 3) PB_GRAY(T, V, 3); else if (C == 1) PB_GRAY(T, V, 1); else PB_GRAY(T, V, 0); } while (0)
+    if (dtype == PB_F32) { if (vec) PB_GRAY_C(float, true); else PB_GRAY_C(float, false); }
+    else { if (vec) PB_GRAY_C(__half, true); else PB_GRAY_C(__half, false); }
+#undef PB_GRAY_C
+#undef PB_GRAY
+    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(B), dim3(NT), 0, ctx->stream, part, mm, bpi);
     PB_LAUNCH_CHECK();
     }
     int rc = launch_rows(ctx, gray, gx, B, H, W, true, mm, 1);
@@ -624,7 +710,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (rc) return rc;
     ProfScope prof(ctx, PB_PROF_PARAMS);
     hipLaunchKernelGGL(blur_params_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
-                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg);
+                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
