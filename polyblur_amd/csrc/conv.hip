@@ -143,7 +143,8 @@ template <typename TIn, typename TX, typename TOut, int R>
 __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
                                           TOut *opl, int tile, int tiles_x, float *smem) {
     constexpr int LW = GT + 2 * R, LH = GT + 2 * R, NTAP = 2 * R + 1;
-    constexpr int LP = 96;                     // LDS row pitch (floats): 4-row strides land on distinct banks
+    constexpr int LP = LW;                     // unpadded LDS rows (5 workgroups per CU); conflicts avoided by YROT
+    constexpr int YROT = (16 - (LP % 16)) % 16;  // odd row groups start YROT column groups further along the row
     constexpr int WCH = 1 + R / 2;             // float4 chunks per window row
     constexpr int NP = 2 * WCH + 2;            // tap pairs per copy (taps n = 0 .. 4 WCH + 3)
     constexpr int PR = 4;
@@ -152,7 +153,9 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
     const int tid = threadIdx.x;
-    const int g = tid & 15, rgp = tid >> 4;    // 16 column groups x 16 row groups
+    // 16 column groups x 16 row groups.  The two row groups that share a 32-lane half are 4 LDS rows
+    // (4 * LP floats) apart; rotating the odd one's column group keeps every ds_read_b128 conflict-free.
+    const int rgp = tid >> 4, g = ((tid & 15) + YROT * (rgp & 1)) & 15;
     load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
     __syncthreads();
     f2 axy[PR], azw[PR];
@@ -233,13 +236,15 @@ template <typename TIn, typename TX, typename TOut, int R>
 __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
                                               TOut *opl, int tile, int tiles_x, float *smem) {
     constexpr int LW = GT + 2 * R, LH = GT + 2 * R;
-    constexpr int LP = (LW + 4 + 31) / 32 * 32;   // row pitch: a multiple of 32 floats keeps 4-row strides conflict-free
+    constexpr int LP = LW;                        // unpadded LDS rows: 30 976 B at R = 12 -> 5 workgroups per CU
+    constexpr int XROT = (16 - ((LP / 4) % 16)) % 16, YROT = (16 - (LP % 16)) % 16;   // lane -> column-group rotations
     const OutRegion rg = out_region(a);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
     Block4x4Epilogue<TX, TOut> epi;
-    epi.prefetch(a, xpl, opl, rg, oy0 + (threadIdx.x >> 4) * 4, ox0 + 4 * (threadIdx.x & 15));
+    const int rgp = threadIdx.x >> 4, gy = ((threadIdx.x & 15) + YROT * (rgp & 1)) & 15;   // y-pass / output mapping
+    epi.prefetch(a, xpl, opl, rg, oy0 + rgp * 4, ox0 + 4 * gy);
     load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
     // taps: TP[p] = (h[p], h[p-1]),  HY[m] = (hy[2m], hy[2m+1]),  h = marginal taps 0..R of the class
     const PB_CONSTANT float *ckx = as_constant(info->kx) + (PB_KRAD - R), *cky = as_constant(info->ky) + (PB_KRAD - R);
@@ -254,9 +259,9 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     // ---- x pass, in place: each wave owns LH/4 rows; a wave instruction covers 4 rows x 16 groups ----
     {
         constexpr int RPW = (LH + 3) / 4;                  // rows per wave
-        // LP = 96 floats puts consecutive rows 8 sixteen-byte slots apart; the two rows that share a
-        // 32-lane half are read conflict-free when the odd one starts 8 groups further along the row
-        const int rsub = lane >> 4, g = ((lane & 15) + 8 * (rsub & 1)) & 15;
+        // consecutive rows are LP/4 sixteen-byte slots apart; the two rows that share a 32-lane half are
+        // read conflict-free when the odd one starts XROT groups further along the row
+        const int rsub = lane >> 4, g = ((lane & 15) + XROT * (rsub & 1)) & 15;
         for (int it = 0; it < (RPW + 3) / 4; ++it) {
             const int rr = wave * RPW + it * 4 + rsub;
             const bool ok = (it * 4 + rsub) < RPW && rr < LH;
@@ -277,7 +282,7 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     }
     __syncthreads();
     // ---- y pass: 4 x 4 outputs per thread from the x-filtered tile ----
-    const int g = tid & 15, rgp = tid >> 4;
+    const int g = gy;
     f2 axy[4], azw[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { axy[r] = (f2){0.f, 0.f}; azw[r] = (f2){0.f, 0.f}; }
@@ -288,10 +293,10 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     epi.finish(a, info, xpl, opl, rg, oy0 + rgp * 4, ox0 + 4 * g, acc);
 }
 
-constexpr size_t kTileLds = sizeof(float) * (GT + 2 * PB_KRAD) * 96;   // 88 rows x max(LP) floats
+constexpr size_t kTileLds = sizeof(float) * (GT + 2 * PB_KRAD) * (GT + 2 * PB_KRAD);   // 88 x 88 floats
 
 template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int sep_in_tile, int total_tiles) {
+__global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int sep_in_tile, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), so
     // give every XCD one contiguous run of tiles -- row-neighbours then share their halos in that
