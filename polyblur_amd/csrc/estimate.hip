@@ -22,12 +22,15 @@ constexpr int NT = 256;
 // FFT plans (host)
 // ------------------------------------------------------------------------------------
 static void factorize(int n, std::vector<int> &radix, int &rest) {
+    // greedy: the largest in-register radix that divides what is left (fewer LDS passes and barriers)
+    static const int pref[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 7, 3, 2};
     radix.clear();
-    while (n % 4 == 0) { radix.push_back(4); n /= 4; }
-    while (n % 2 == 0) { radix.push_back(2); n /= 2; }
-    while (n % 3 == 0) { radix.push_back(3); n /= 3; }
-    while (n % 5 == 0) { radix.push_back(5); n /= 5; }
-    while (n % 7 == 0) { radix.push_back(7); n /= 7; }
+    bool found = true;
+    while (n > 1 && found) {
+        found = false;
+        for (int r : pref)
+            if (n % r == 0) { radix.push_back(r); n /= r; found = true; break; }
+    }
     rest = n;
 }
 
@@ -304,21 +307,61 @@ __global__ __launch_bounds__(NT) void grad_rows_kernel(const float *__restrict__
         lo = pb_ord2f(mm[2 * img]);
         scale = pb_ord2f(mm[2 * img + 1]) - lo;
     }
-    for (int n = threadIdx.x; n < W; n += NT) {
-        float a = row0[n], b = has1 ? row1[n] : 0.f;
-        if (NORMALIZE) {
-            a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
-            b = has1 ? fminf(fmaxf((b - lo) / scale, 0.f), 1.f) : 0.f;
+    const bool vec = (W & 3) == 0;                 // rows are 16-byte aligned: whole-row float4 traffic
+    if (vec) {
+        const int W4 = W >> 2;
+        const float4 *r0 = reinterpret_cast<const float4 *>(row0), *r1 = reinterpret_cast<const float4 *>(row1);
+        for (int base = 0; base < W4; base += 4 * NT) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                      // all loads of the batch in flight together
+                const int i = base + u * NT + threadIdx.x;
+                a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b[u] = a[u];
+                if (i < W4) { a[u] = r0[i]; if (has1) b[u] = r1[i]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * NT + threadIdx.x;
+                if (i < W4) {
+                    float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (NORMALIZE) {
+                            av[e] = fminf(fmaxf((av[e] - lo) / scale, 0.f), 1.f);
+                            bv[e] = has1 ? fminf(fmaxf((bv[e] - lo) / scale, 0.f), 1.f) : 0.f;
+                        }
+                        sfft[4 * i + e] = make_float2(av[e], bv[e]);
+                    }
+                }
+            }
         }
-        sfft[n] = make_float2(a, b);
+    } else {
+        for (int n = threadIdx.x; n < W; n += NT) {
+            float a = row0[n], b = has1 ? row1[n] : 0.f;
+            if (NORMALIZE) {
+                a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
+                b = has1 ? fminf(fmaxf((b - lo) / scale, 0.f), 1.f) : 0.f;
+            }
+            sfft[n] = make_float2(a, b);
+        }
     }
     __syncthreads();
     pbfft::spectral_derivative(sfft, plan, 0);
     float *o0 = gx + ((long)plane * H + r0) * W;
-    for (int n = threadIdx.x; n < W; n += NT) {
-        const float2 v = sfft[n];
-        o0[n] = v.x;
-        if (has1) o0[W + n] = -v.y;
+    if (vec) {
+        const int W4 = W >> 2;
+        for (int i = threadIdx.x; i < W4; i += NT) {
+            const float2 v0 = sfft[4 * i], v1 = sfft[4 * i + 1], v2 = sfft[4 * i + 2], v3 = sfft[4 * i + 3];
+            reinterpret_cast<float4 *>(o0)[i] = make_float4(v0.x, v1.x, v2.x, v3.x);
+            if (has1) reinterpret_cast<float4 *>(o0 + W)[i] = make_float4(-v0.y, -v1.y, -v2.y, -v3.y);
+        }
+    } else {
+        for (int n = threadIdx.x; n < W; n += NT) {
+            const float2 v = sfft[n];
+            o0[n] = v.x;
+            if (has1) o0[W + n] = -v.y;
+        }
     }
 }
 
@@ -351,17 +394,35 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
         scale = pb_ord2f(mm[2 * img + 1]) - lo;
     }
     // element e = p*nb + j  <->  row p, columns c0+2j, c0+2j+1
-    for (int e = threadIdx.x; e < (H << lognb); e += NT) {
-        const int p = e >> lognb, j = e & (nb - 1);
-        const int c = c0 + 2 * j;
-        float a = 0.f, b = 0.f;
-        if (c < W) a = src[(long)p * W + c];
-        if (c + 1 < W) b = src[(long)p * W + c + 1];
-        if (NORMALIZE) {
-            a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
-            b = fminf(fmaxf((b - lo) / scale, 0.f), 1.f);
+    const bool vec2 = (W & 1) == 0 && c0 + tc <= W;          // every pair is an aligned, in-range float2
+    for (int base = 0; base < (H << lognb); base += 8 * NT) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                          // 8 independent loads in flight per thread
+            const int e = base + u * NT + threadIdx.x;
+            v[u] = make_float2(0.f, 0.f);
+            if (e < (H << lognb)) {
+                const int p = e >> lognb, j = e & (nb - 1);
+                const int c = c0 + 2 * j;
+                if (vec2) v[u] = *reinterpret_cast<const float2 *>(src + (long)p * W + c);
+                else {
+                    if (c < W) v[u].x = src[(long)p * W + c];
+                    if (c + 1 < W) v[u].y = src[(long)p * W + c + 1];
+                }
+            }
         }
-        sfft[e] = make_float2(a, b);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + u * NT + threadIdx.x;
+            if (e < (H << lognb)) {
+                float a = v[u].x, b = v[u].y;
+                if (NORMALIZE) {
+                    a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
+                    b = fminf(fmaxf((b - lo) / scale, 0.f), 1.f);
+                }
+                sfft[e] = make_float2(a, b);
+            }
+        }
     }
     __syncthreads();
     pbfft::spectral_derivative(sfft, plan, lognb);
@@ -383,20 +444,42 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
             cs[k] = cosf(t); sn[k] = sinf(t); best[k] = 0.f;
         }
         const float *gxp = gx + (long)plane * H * W;
-        for (int e = threadIdx.x; e < (H << lognb); e += NT) {
-            const int p = e >> lognb, j = e & (nb - 1);
-            const int c = c0 + 2 * j;
-            const float2 v = sfft[e];
+        for (int base = 0; base < (H << lognb); base += 8 * NT) {
+            float2 dxv[8], gv[8];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (c + h >= W) continue;
-                const long idx = (long)p * W + c + h;
-                if (discard_sat && src[idx] > sat_threshold) continue;   // gradients zeroed under the mask
-                const float dx = gxp[idx];
-                const float dy = h ? -v.y : v.x;
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NT + threadIdx.x;
+                dxv[u] = make_float2(0.f, 0.f);
+                gv[u] = make_float2(0.f, 0.f);
+                if (e < (H << lognb)) {
+                    const int p = e >> lognb, j = e & (nb - 1);
+                    const long idx = (long)p * W + c0 + 2 * j;
+                    if (vec2) {
+                        dxv[u] = *reinterpret_cast<const float2 *>(gxp + idx);
+                        if (discard_sat) gv[u] = *reinterpret_cast<const float2 *>(src + idx);
+                    } else {
+                        if (c0 + 2 * j < W) { dxv[u].x = gxp[idx]; if (discard_sat) gv[u].x = src[idx]; }
+                        if (c0 + 2 * j + 1 < W) { dxv[u].y = gxp[idx + 1]; if (discard_sat) gv[u].y = src[idx + 1]; }
+                    }
+                }
+            }
 #pragma unroll
-                for (int k = 0; k < PB_MAX_ANGLES; ++k)
-                    if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(cs[k] * dx - sn[k] * dy));
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NT + threadIdx.x;
+                if (e >= (H << lognb)) continue;
+                const int j = e & (nb - 1);
+                const int c = c0 + 2 * j;
+                const float2 vv = sfft[e];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (c + h >= W) continue;
+                    if (discard_sat && (h ? gv[u].y : gv[u].x) > sat_threshold) continue;   // gradients zeroed under the mask
+                    const float dx = h ? dxv[u].y : dxv[u].x;
+                    const float dy = h ? -vv.y : vv.x;
+#pragma unroll
+                    for (int k = 0; k < PB_MAX_ANGLES; ++k)
+                        if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(cs[k] * dx - sn[k] * dy));
+                }
             }
         }
         __syncthreads();

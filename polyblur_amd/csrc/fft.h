@@ -14,7 +14,8 @@
 // barrier per stage); NB interleaved lines are transformed together (element (p, j) lives at
 // s[p*NB + j]) so that consecutive lanes touch consecutive LDS words.
 //
-// Lengths whose prime factors are all <= 7 use radices 4/2/3/5/7 directly; any other length
+// Lengths whose prime factors are all <= 7 use radices up to 16 (composites 16/15/12/10/9/8/6 are evaluated
+// in registers as two-level Cooley-Tukey, so a 3840-point line needs 3 LDS passes, not 6); any other length
 // goes through Bluestein's chirp-z with a power-of-two inner length (plan.bluestein_m).
 #pragma once
 #include "common.h"
@@ -81,6 +82,55 @@ template <> __device__ __forceinline__ void dft_small<3>(float2 (&v)[3]) { dft_o
 template <> __device__ __forceinline__ void dft_small<5>(float2 (&v)[5]) { dft_odd<5>(v, kCos5, kSin5); }
 template <> __device__ __forceinline__ void dft_small<7>(float2 (&v)[7]) { dft_odd<7>(v, kCos7, kSin7); }
 
+
+// ---- composite radices, evaluated in registers as A x B Cooley-Tukey with constant twiddles -------------
+// X[k1 + A k2] = sum_{n2} W_N^{n2 k1} ( sum_{n1} x[n1 B + n2] W_A^{n1 k1} ) W_B^{n2 k2},  N = A B
+static __device__ const float kCos6[6] = {1.0f, 0.5f, -0.5f, -1.0f, -0.5f, 0.5f};
+static __device__ const float kSin6[6] = {0.0f, 0.8660254037844386f, 0.8660254037844387f, 0.0f, -0.8660254037844384f, -0.8660254037844386f};
+static __device__ const float kCos8[8] = {1.0f, 0.7071067811865476f, 0.0f, -0.7071067811865475f, -1.0f, -0.7071067811865477f, 0.0f, 0.7071067811865474f};
+static __device__ const float kSin8[8] = {0.0f, 0.7071067811865475f, 1.0f, 0.7071067811865476f, 0.0f, -0.7071067811865475f, -1.0f, -0.7071067811865477f};
+static __device__ const float kCos9[9] = {1.0f, 0.766044443118978f, 0.17364817766693041f, -0.5f, -0.9396926207859083f, -0.9396926207859084f, -0.5f, 0.17364817766692997f, 0.7660444431189778f};
+static __device__ const float kSin9[9] = {0.0f, 0.6427876096865393f, 0.984807753012208f, 0.8660254037844387f, 0.3420201433256689f, -0.34202014332566866f, -0.8660254037844384f, -0.9848077530122081f, -0.6427876096865396f};
+static __device__ const float kCos10[10] = {1.0f, 0.8090169943749475f, 0.30901699437494745f, -0.30901699437494734f, -0.8090169943749473f, -1.0f, -0.8090169943749476f, -0.30901699437494756f, 0.30901699437494723f, 0.8090169943749473f};
+static __device__ const float kSin10[10] = {0.0f, 0.5877852522924731f, 0.9510565162951535f, 0.9510565162951536f, 0.5877852522924732f, 0.0f, -0.587785252292473f, -0.9510565162951535f, -0.9510565162951536f, -0.5877852522924734f};
+static __device__ const float kCos12[12] = {1.0f, 0.8660254037844387f, 0.5f, 0.0f, -0.5f, -0.8660254037844387f, -1.0f, -0.8660254037844388f, -0.5f, 0.0f, 0.5f, 0.8660254037844384f};
+static __device__ const float kSin12[12] = {0.0f, 0.5f, 0.8660254037844386f, 1.0f, 0.8660254037844387f, 0.5f, 0.0f, -0.5f, -0.8660254037844384f, -1.0f, -0.8660254037844386f, -0.5f};
+static __device__ const float kCos15[15] = {1.0f, 0.9135454576426009f, 0.6691306063588582f, 0.30901699437494745f, -0.10452846326765333f, -0.5f, -0.8090169943749473f, -0.9781476007338057f, -0.9781476007338057f, -0.8090169943749476f, -0.5f, -0.10452846326765423f, 0.30901699437494723f, 0.6691306063588585f, 0.913545457642601f};
+static __device__ const float kSin15[15] = {0.0f, 0.40673664307580015f, 0.7431448254773941f, 0.9510565162951535f, 0.9945218953682734f, 0.8660254037844387f, 0.5877852522924732f, 0.20791169081775931f, -0.20791169081775907f, -0.587785252292473f, -0.8660254037844384f, -0.9945218953682733f, -0.9510565162951536f, -0.743144825477394f, -0.40673664307580015f};
+static __device__ const float kCos16[16] = {1.0f, 0.9238795325112867f, 0.7071067811865476f, 0.38268343236508984f, 0.0f, -0.3826834323650897f, -0.7071067811865475f, -0.9238795325112867f, -1.0f, -0.9238795325112868f, -0.7071067811865477f, -0.38268343236509034f, 0.0f, 0.38268343236509f, 0.7071067811865474f, 0.9238795325112865f};
+static __device__ const float kSin16[16] = {0.0f, 0.3826834323650898f, 0.7071067811865475f, 0.9238795325112867f, 1.0f, 0.9238795325112867f, 0.7071067811865476f, 0.3826834323650899f, 0.0f, -0.38268343236508967f, -0.7071067811865475f, -0.9238795325112865f, -1.0f, -0.9238795325112866f, -0.7071067811865477f, -0.3826834323650904f};
+template <int A, int B> __device__ __forceinline__ void dft_ct(float2 (&v)[A * B], const float *cs, const float *sn) {
+    float2 y[A * B];
+#pragma unroll
+    for (int n2 = 0; n2 < B; ++n2) {
+        float2 col[A];
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1) col[n1] = v[n1 * B + n2];
+        dft_small<A>(col);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            const int m = (n2 * k1) % (A * B);
+            y[k1 * B + n2] = (m == 0) ? col[k1] : cmul(col[k1], make_float2(cs[m], -sn[m]));
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) {
+        float2 row[B];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) row[n2] = y[k1 * B + n2];
+        dft_small<B>(row);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) v[k1 + A * k2] = row[k2];
+    }
+}
+template <> __device__ __forceinline__ void dft_small<6>(float2 (&v)[6]) { dft_ct<2, 3>(v, kCos6, kSin6); }
+template <> __device__ __forceinline__ void dft_small<8>(float2 (&v)[8]) { dft_ct<4, 2>(v, kCos8, kSin8); }
+template <> __device__ __forceinline__ void dft_small<9>(float2 (&v)[9]) { dft_ct<3, 3>(v, kCos9, kSin9); }
+template <> __device__ __forceinline__ void dft_small<10>(float2 (&v)[10]) { dft_ct<2, 5>(v, kCos10, kSin10); }
+template <> __device__ __forceinline__ void dft_small<12>(float2 (&v)[12]) { dft_ct<4, 3>(v, kCos12, kSin12); }
+template <> __device__ __forceinline__ void dft_small<15>(float2 (&v)[15]) { dft_ct<3, 5>(v, kCos15, kSin15); }
+template <> __device__ __forceinline__ void dft_small<16>(float2 (&v)[16]) { dft_ct<4, 4>(v, kCos16, kSin16); }
+
 // t / m and t % m for 0 <= t < 2^23 with a float reciprocal and a one-step fix-up
 __device__ __forceinline__ void divmod(int t, int m, float inv_m, int &q, int &r) {
     q = (int)((float)t * inv_m);
@@ -127,6 +177,13 @@ __device__ __forceinline__ void stage(float2 *s, int N, int lognb, int L, const 
 template <bool DIT>
 __device__ __forceinline__ void stage_any(float2 *s, int N, int lognb, int L, int radix, const float2 *tw) {
     switch (radix) {
+        case 16: stage<16, DIT>(s, N, lognb, L, tw); break;
+        case 15: stage<15, DIT>(s, N, lognb, L, tw); break;
+        case 12: stage<12, DIT>(s, N, lognb, L, tw); break;
+        case 10: stage<10, DIT>(s, N, lognb, L, tw); break;
+        case 9: stage<9, DIT>(s, N, lognb, L, tw); break;
+        case 8: stage<8, DIT>(s, N, lognb, L, tw); break;
+        case 6: stage<6, DIT>(s, N, lognb, L, tw); break;
         case 4: stage<4, DIT>(s, N, lognb, L, tw); break;
         case 2: stage<2, DIT>(s, N, lognb, L, tw); break;
         case 3: stage<3, DIT>(s, N, lognb, L, tw); break;
