@@ -112,8 +112,11 @@ template <typename TX, typename TOut> struct Block4x4Epilogue {
                 st4<TOut>(op + (long)r * a.out_pitch, v);
             }
         } else {
-#pragma unroll 1
-            for (int r = 0; r < 4; ++r) finish4<TX, TOut>(a, info, xpl, opl, rg, py + r, px, acc[r]);
+            // (statically indexed: a run-time index would push acc[] -- and a 64-byte store per thread -- to scratch)
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py, px, acc[0]);
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 1, px, acc[1]);
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 2, px, acc[2]);
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 3, px, acc[3]);
         }
     }
 };
