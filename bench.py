@@ -121,9 +121,22 @@ def main():
     alg_bytes_per_launch = 8.0 * s * samples / 3.0
     conv_avg_ms = conv_ms / max(conv_n, 1)
     achieved = alg_bytes_per_launch / (conv_avg_ms * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="conv_pass_kernel (stencil pass, estimated kernels, full support)",
+    # HBM-side bytes per launch of the same kernel from the rocprofv3 PMC passes of this same command
+    # (tools/profile_bench.sh -> profiles/*_traffic.json; separate runs, FETCH_SIZE x2 on gfx950)
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+        if cands and B == 1 and (H, W) == (2160, 3840) and s == 4:
+            tj = json.load(open(cands[-1]))
+            for k, v in tj.get("traffic", {}).items():
+                if k.startswith("conv_tile_kernel<float, float, float>"):
+                    traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.basename(cands[-1])
+    except Exception:
+        pass
+    roofline = dict(bound="hbm", kernel="conv_tile_kernel (stencil pass; taps as estimated, full 25x25 support)",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=None, launches=conv_n, avg_launch_ms=round(conv_avg_ms, 5),
+                    traffic=traffic, traffic_source=traffic_src, launches=conv_n, avg_launch_ms=round(conv_avg_ms, 5),
                     algorithmic_bytes_per_launch=int(alg_bytes_per_launch))
     stages_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]}
 
