@@ -286,6 +286,113 @@ __global__ __launch_bounds__(NT) void minmax_reduce_kernel(const float2 *__restr
 }
 
 // ------------------------------------------------------------------------------------
+// quantile normalisation (q > 0): exact order statistics by 3-level radix select
+// ------------------------------------------------------------------------------------
+// normalize() clips the image to its q / 1-q quantiles (blur_estimation.py:102-105, torch.quantile with
+// linear interpolation).  Each quantile needs two adjacent order statistics; the four targets per image
+// are found exactly on the order-preserving 32-bit keys in three passes over the gray image
+// (12 + 12 + 8 bits), each pass a histogram restricted to the prefixes chosen so far.
+struct QuantSel {
+    unsigned rank[4];      // residual rank of each target inside its current prefix
+    unsigned prefix[4];    // key bits fixed so far (left-aligned)
+    float weight[2];       // interpolation weights of the low / high quantile
+};
+
+template <int LEVEL>   // 0: bits 31..20, 1: bits 19..8, 2: bits 7..0
+__global__ __launch_bounds__(NT) void quant_hist_kernel(const float *__restrict__ gray, const QuantSel *__restrict__ sel,
+                                                        unsigned *__restrict__ hist, long HW, int blocks_per_image) {
+    constexpr int NB = LEVEL == 2 ? 256 : 4096;
+    constexpr int NTGT = LEVEL == 0 ? 1 : 4;
+    extern __shared__ unsigned sh[];                       // NTGT x NB counters
+    const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x - b * blocks_per_image;
+    for (int i = threadIdx.x; i < NTGT * NB; i += NT) sh[i] = 0u;
+    unsigned pre[4] = {0u, 0u, 0u, 0u};
+    if (LEVEL > 0)
+        for (int t = 0; t < 4; ++t) pre[t] = sel[b].prefix[t];
+    __syncthreads();
+    const float *src = gray + (long)b * HW;
+    for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)blocks_per_image * NT) {
+        const unsigned key = pb_f2ord(src[i]);
+        if (LEVEL == 0) atomicAdd(&sh[key >> 20], 1u);
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (LEVEL == 1 && (key >> 20) == (pre[t] >> 20)) atomicAdd(&sh[t * NB + ((key >> 8) & 0xfffu)], 1u);
+                if (LEVEL == 2 && (key >> 8) == (pre[t] >> 8)) atomicAdd(&sh[t * NB + (key & 0xffu)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned *dst = hist + (long)b * NTGT * NB;
+    for (int i = threadIdx.x; i < NTGT * NB; i += NT)
+        if (sh[i]) atomicAdd(dst + i, sh[i]);
+}
+
+// one workgroup per image: locate, for every target, the bin that holds its rank
+template <int LEVEL>
+__global__ __launch_bounds__(NT) void quant_scan_kernel(const unsigned *__restrict__ hist, QuantSel *__restrict__ sel,
+                                                        unsigned *__restrict__ mm, long HW, float q_lo, float q_hi) {
+    constexpr int NB = LEVEL == 2 ? 256 : 4096;
+    constexpr int NTGT = LEVEL == 0 ? 1 : 4;
+    constexpr int PER = NB / NT;
+    __shared__ unsigned part[NT];
+    __shared__ QuantSel s;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        if (LEVEL == 0) {
+            // torch.quantile: rank = q * (n - 1) in the input dtype, lerp between floor and floor + 1
+            const float n1 = (float)(HW - 1);
+            // the product must be rounded to fp32 BEFORE the floor is subtracted, like torch does;
+            // the empty asm keeps the compiler from contracting (q * n1 - floor) into one FMA
+            float r_lo = q_lo * n1, r_hi = q_hi * n1;
+            asm volatile("" : "+v"(r_lo), "+v"(r_hi));
+            const float f_lo = floorf(r_lo), f_hi = floorf(r_hi);
+            s.rank[0] = (unsigned)f_lo; s.rank[1] = (unsigned)fminf(f_lo + 1.f, n1);
+            s.rank[2] = (unsigned)f_hi; s.rank[3] = (unsigned)fminf(f_hi + 1.f, n1);
+            s.weight[0] = r_lo - f_lo; s.weight[1] = r_hi - f_hi;
+            for (int t = 0; t < 4; ++t) s.prefix[t] = 0u;
+        } else s = sel[b];
+    }
+    __syncthreads();
+    for (int t = 0; t < 4; ++t) {
+        const unsigned *h = hist + ((long)b * NTGT + (NTGT == 1 ? 0 : t)) * NB;
+        unsigned sum = 0;
+        for (int i = 0; i < PER; ++i) sum += h[threadIdx.x * PER + i];
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned rank = s.rank[t], acc = 0;
+            int seg = 0;
+            for (; seg < NT - 1; ++seg) {                      // find the 1/NT segment, then the bin
+                if (acc + part[seg] > rank) break;
+                acc += part[seg];
+            }
+            int bin = seg * PER;
+            for (; bin < seg * PER + PER - 1; ++bin) {
+                if (acc + h[bin] > rank) break;
+                acc += h[bin];
+            }
+            s.rank[t] = rank - acc;
+            s.prefix[t] |= LEVEL == 0 ? ((unsigned)bin << 20) : (LEVEL == 1 ? ((unsigned)bin << 8) : (unsigned)bin);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (LEVEL < 2) sel[b] = s;
+        else {
+            const float a0 = pb_ord2f(s.prefix[0]), a1 = pb_ord2f(s.prefix[1]);
+            const float b0 = pb_ord2f(s.prefix[2]), b1 = pb_ord2f(s.prefix[3]);
+            // torch.lerp
+            const float wl = s.weight[0], wh = s.weight[1];
+            const float lo = wl < 0.5f ? a0 + wl * (a1 - a0) : a1 - (a1 - a0) * (1.f - wl);
+            const float hi = wh < 0.5f ? b0 + wh * (b1 - b0) : b1 - (b1 - b0) * (1.f - wh);
+            mm[2 * b] = pb_f2ord(lo);
+            mm[2 * b + 1] = pb_f2ord(hi);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // spectral derivative along rows: one workgroup = two rows packed as one complex line
 // ------------------------------------------------------------------------------------
 // NORMALIZE: lines are range-normalised on load with the per-image (lo, hi) in mm
@@ -752,7 +859,7 @@ int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, in
 
 int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, const pb_options *opt,
                      pb_blur_info *dev_info) {
-    if (opt->q != 0.f) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "quantile normalisation (q > 0) is not implemented");
+    if (opt->q < 0.f || opt->q >= 0.5f) return pb_fail(ctx, PB_ERR_BADARG, "q must be in [0, 0.5)");
     if (opt->n_angles < 1 || opt->n_angles + 1 > PB_MAX_ANGLES || opt->n_interpolated_angles < 1 ||
         opt->n_interpolated_angles > PB_MAX_INTERP)
         return pb_fail(ctx, PB_ERR_BADARG, "n_angles / n_interpolated_angles out of range");
@@ -785,6 +892,29 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 #undef PB_GRAY_C
 #undef PB_GRAY
     hipLaunchKernelGGL(minmax_reduce_kernel, dim3(B), dim3(NT), 0, ctx->stream, part, mm, bpi);
+    if (opt->q > 0.f) {
+        // replace (min, max) by the (q, 1-q) quantiles: three histogram + scan rounds
+        const size_t hbytes = sizeof(unsigned) * (size_t)B * 4 * 4096;
+        unsigned *hist = static_cast<unsigned *>(pb_scratch(ctx, "est.qhist", hbytes));
+        QuantSel *sel = static_cast<QuantSel *>(pb_scratch(ctx, "est.qsel", sizeof(QuantSel) * (size_t)B));
+        if (!hist || !sel) return PB_ERR_NOMEM;
+        int hb = (int)((HW + NT * 16 - 1) / (NT * 16));
+        const int hb_max = (1024 + B - 1) / B;
+        if (hb > hb_max) hb = hb_max;
+        if (hb < 1) hb = 1;
+        const float q_lo = opt->q, q_hi = (float)(1.0 - (double)opt->q);
+        PB_HIP(hipMemsetAsync(hist, 0, hbytes, ctx->stream));
+        hipLaunchKernelGGL(quant_hist_kernel<0>, dim3(B * hb), dim3(NT), 4096 * sizeof(unsigned), ctx->stream, gray, sel, hist, HW, hb);
+        hipLaunchKernelGGL(quant_scan_kernel<0>, dim3(B), dim3(NT), 0, ctx->stream, hist, sel, mm, HW, q_lo, q_hi);
+        PB_HIP(hipMemsetAsync(hist, 0, hbytes, ctx->stream));
+        int rcq = allow_lds(ctx, quant_hist_kernel<1>, 4 * 4096 * sizeof(unsigned));
+        if (rcq) return rcq;
+        hipLaunchKernelGGL(quant_hist_kernel<1>, dim3(B * hb), dim3(NT), 4 * 4096 * sizeof(unsigned), ctx->stream, gray, sel, hist, HW, hb);
+        hipLaunchKernelGGL(quant_scan_kernel<1>, dim3(B), dim3(NT), 0, ctx->stream, hist, sel, mm, HW, q_lo, q_hi);
+        PB_HIP(hipMemsetAsync(hist, 0, hbytes, ctx->stream));
+        hipLaunchKernelGGL(quant_hist_kernel<2>, dim3(B * hb), dim3(NT), 4 * 256 * sizeof(unsigned), ctx->stream, gray, sel, hist, HW, hb);
+        hipLaunchKernelGGL(quant_scan_kernel<2>, dim3(B), dim3(NT), 0, ctx->stream, hist, sel, mm, HW, q_lo, q_hi);
+    }
     PB_LAUNCH_CHECK();
     }
     int rc = launch_rows(ctx, gray, gx, B, H, W, true, mm, 1);

@@ -51,8 +51,8 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
         raise ValueError("prefilter must be 'bilateral' or 'domain_transform'")
     if ker_size != capi.PB_KSIZE:
         raise NotImplementedError("only ker_size=25 (the reference default) is built")
-    if q != 0:
-        raise NotImplementedError("quantile normalisation (q > 0) is not built yet; use q=0")
+    if not (0 <= q < 0.5):
+        raise ValueError("q must be in [0, 0.5)")
     if multichannel_kernel and C not in (1, 3):
         raise NotImplementedError("per-channel kernels crash in the reference for C not in {1,3}")
     if not (1 <= n_angles <= capi.PB_MAX_ANGLES - 1 and 1 <= n_interpolated_angles <= capi.PB_MAX_INTERP):

@@ -56,8 +56,8 @@ def test_argument_validation_before_any_device_work():
     x = np.zeros((16, 16, 3), np.float32)
     with pytest.raises(ValueError):
         polyblur_deblurring(x, method="nope")
-    with pytest.raises(NotImplementedError):
-        polyblur_deblurring(x, q=1e-4)
+    with pytest.raises(ValueError):
+        polyblur_deblurring(x, q=0.5)
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=31)
     with pytest.raises(ValueError):

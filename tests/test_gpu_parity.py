@@ -67,6 +67,23 @@ def test_estimate_blur(eng, golden, name):
     assert maxabs(info["gray_max"], g["gray"].reshape(g["gray"].shape[0], -1).max(1)) == 0
 
 
+@pytest.mark.parametrize("shape,q", [((2, 3, 160, 224), 1e-4), ((1, 1, 97, 131), 0.01), ((1, 3, 1080, 1920), 1e-4)])
+def test_quantile_normalisation(eng, shape, q):
+    """q > 0: the clip values are torch.quantile's (linear interpolation between exact order statistics)"""
+    x, _ = synthetic_blurry_batch(shape[0], shape[1], shape[2], shape[3], seed0=55)
+    info = eng.estimate_blur(x, opts(c=0.362, b=0.468, q=q))
+    gray = x.mean(axis=1, dtype=np.float32) if shape[1] == 3 else x[:, 0]
+    flat = np.sort(gray.reshape(shape[0], -1), axis=1)
+    n1 = np.float32(flat.shape[1] - 1)
+    for which, qq, key in ((0, np.float32(q), "gray_min"), (1, np.float32(1.0 - q), "gray_max")):
+        r = qq * n1
+        f = np.floor(r)
+        lo_i, hi_i = int(f), int(min(f + 1, n1))
+        w = np.float32(r - f)
+        want = flat[:, lo_i] + w * (flat[:, hi_i] - flat[:, lo_i])
+        assert maxabs(info[key], want) < 2e-7, (which, info[key], want)
+
+
 def test_make_kernels_grid(eng, golden):
     g = golden("kernel_grid.npz")
     buf = eng.make_kernels(g["sigma"], g["rho"], g["theta"])
@@ -228,7 +245,7 @@ def test_pipeline_peacock(golden, method):
 
 VARIANTS = [("plain", {}), ("edgetaping", dict(edgetaping=True)), ("remove_halo", dict(remove_halo=True)),
             ("prefiltering", dict(prefiltering=True)), ("discard_saturation", dict(discard_saturation=True)),
-            ("all", dict(edgetaping=True, remove_halo=True, prefiltering=True))]
+            ("q1e-4", dict(q=1e-4)), ("all", dict(edgetaping=True, remove_halo=True, prefiltering=True))]
 
 
 @pytest.mark.parametrize("variant,o", VARIANTS)
@@ -313,8 +330,8 @@ def test_argument_errors():
     x = np.zeros((32, 32, 3), np.float32)
     with pytest.raises(ValueError):
         polyblur_deblurring(x, method="nope")
-    with pytest.raises(NotImplementedError):
-        polyblur_deblurring(x, q=1e-4)
+    with pytest.raises(ValueError):
+        polyblur_deblurring(x, q=0.7)
     with pytest.raises(NotImplementedError):
         PolyblurDeblurring(patch_decomposition=True)(x)
     with pytest.raises(ValueError):

@@ -1,22 +1,16 @@
 import numpy as np, sys
 sys.path.insert(0,'/root/repo')
-from oracle import polyblur_ref as ref
-from polyblur_amd import _capi as capi
-from polyblur_amd.engine import get_engine
+from polyblur_amd.engine import get_engine, Engine
+from polyblur_amd.synthetic import synthetic_blurry_batch
 eng=get_engine(0)
-th=np.float32(0)
-k=ref.gaussian_kernel_2d([th],[2.5],[1.0])
-buf=eng.make_kernels([2.5],[1.0],[th])
-info=eng.read_info(buf,1)
-print('kx sym', np.abs(info['kx'][0]-info['kx'][0][::-1]).max(), 'ky', np.abs(info['ky'][0]-info['ky'][0][::-1]).max())
-for cx in (100,101,102,103):
-    xp=np.zeros((1,1,174,234),np.float32); xp[0,0,80,cx]=1
-    out=eng.convolve2d(xp,buf,capi.PB_ZERO)
-    want=ref.correlate_same_zero(xp,k[:,None])
-    err=np.abs(out-want)[0,0]
-    print('impulse col',cx,'max err',err.max())
-    ys,xs=np.where(err>1e-7)
-    if len(ys): print('  rows',ys.min(),ys.max(),'cols',xs.min(),xs.max(), 'n',len(ys))
-    # effective vertical profile at column cx
-    print('  got ', np.round(out[0,0,74:87,cx]*1e3,3))
-    print('  want', np.round(want[0,0,74:87,cx]*1e3,3))
+x,_=synthetic_blurry_batch(2,3,160,224,seed0=55)
+q=1e-4
+info=eng.estimate_blur(x, Engine.make_options(c=0.362,b=0.468,q=q))
+gray=x.mean(axis=1,dtype=np.float32)
+flat=np.sort(gray.reshape(2,-1),axis=1)
+n1=np.float32(flat.shape[1]-1)
+r=np.float32(1.0-q)*n1; f=int(np.floor(r)); print('r',r,'f',f,'w',r-f)
+print('dev hi', info['gray_max'], 'dev lo', info['gray_min'])
+for b in range(2):
+    print('sorted around', flat[b,f-2:f+3], 'max', flat[b,-1])
+    d=info['gray_max'][b]; print(' position of dev value', np.searchsorted(flat[b], d))
