@@ -62,8 +62,9 @@ def blur_circular(img: np.ndarray, psf: np.ndarray) -> np.ndarray:
     h, w = img.shape[-2:]
     kh, kw = psf.shape
     big = np.zeros((h, w), np.float32)
-    big[:kh, :kw] = psf
-    big = np.roll(big, (-(kh // 2), -(kw // 2)), axis=(0, 1))
+    iy = (np.arange(kh) - kh // 2) % h                 # centred psf folded onto the torus (images may be
+    ix = (np.arange(kw) - kw // 2) % w                 # smaller than the psf)
+    np.add.at(big, (iy[:, None], ix[None, :]), psf)
     out = np.fft.irfft2(np.fft.rfft2(img) * np.fft.rfft2(big), s=(h, w))
     return out.astype(np.float32)
 

@@ -378,3 +378,64 @@ def test_4k_properties(eng):
     c = polyblur_deblurring(x, n_iter=3, support="adaptive", **KW)
     assert float((a - c).abs().max()) < 1e-5
     assert all(0.3 <= float(i["sigma"][0]) <= 4.0 for i in infos)
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases: ragged / tiny sizes, mixed batches, degenerate inputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 3, 8, 8), (1, 1, 16, 20), (2, 3, 33, 130), (1, 3, 65, 63), (1, 2, 40, 44)])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_small_and_ragged_sizes(shape, method):
+    """images smaller than the 25x25 support (the wrap boundary wraps more than once), widths that are
+    not multiples of 4 (no 16-byte path), tile-edge sizes, and a 2-channel input (gray = mean over C)"""
+    from polyblur_amd import polyblur_deblurring
+    import torch
+    x, _ = synthetic_blurry_batch(shape[0], shape[1], shape[2], shape[3], seed0=91)
+    out, infos = polyblur_deblurring(torch.from_numpy(x).cuda(), n_iter=2, method=method, return_info=True, **KW)
+    want, winfos = ref.polyblur_deblurring(x, n_iter=2, method=method, return_info=True, **KW)
+    for a, b in zip(infos, winfos):
+        assert np.array_equal(a["theta"], b["theta"])
+    assert maxabs(out.cpu().numpy(), want) < 3e-5
+
+
+def test_mixed_batch_rank1_and_general(eng):
+    """one launch, images with different bodies and support classes (device-side dispatch per image)"""
+    x, _ = synthetic_blurry_batch(5, 3, 140, 200, seed0=17)
+    sig = [2.5, 0.6, 1.3, 3.0, 0.4]
+    rho = [1.0, 0.6, 0.8, 3.0, 0.3]
+    deg = [0.0, 48.0, 60.0, 12.0, 90.0]
+    th = np.deg2rad(np.array(deg, np.float32)).astype(np.float32)
+    for support in (capi.PB_SUPPORT_FULL, capi.PB_SUPPORT_ADAPTIVE):
+        buf = eng.make_kernels(sig, rho, th, support=support)
+        info = eng.read_info(buf, 5)
+        assert list(info["separable"]) == [1, 1, 0, 1, 1]
+        out = eng.inverse_filter(x, buf, 6.0, 1.0, capi.PB_WRAP)
+        k = ref.gaussian_kernel_2d(th, np.array(sig, np.float32), np.array(rho, np.float32))
+        want = ref.inverse_filtering_rank3(x, k[:, None], 6.0, 1.0, method="fft")
+        assert maxabs(out, want) < 1e-5, support
+
+
+def test_constant_image_is_guarded():
+    """the reference returns NaN for a constant image (0/0 in normalize); the engine's
+    clamp maps the NaN to 0, the estimate saturates at sigma = rho = 4 and the image is returned unchanged"""
+    from polyblur_amd import polyblur_deblurring
+    x = np.full((48, 64, 3), 0.5, np.float32)
+    out = polyblur_deblurring(x, n_iter=2, **KW)
+    assert np.isfinite(out).all() and maxabs(out, x) < 1e-6
+
+
+def test_non_contiguous_and_stream(eng):
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    x, _ = synthetic_blurry_batch(2, 3, 64, 96, seed0=3)
+    xt = torch.from_numpy(x).cuda()
+    a = polyblur_deblurring(xt, n_iter=1, **KW)
+    xs = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 1, 3, 2))).cuda().permute(0, 1, 3, 2)   # strided view
+    assert not xs.is_contiguous()
+    b = polyblur_deblurring(xs, n_iter=1, **KW)
+    assert torch.equal(a, b)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        c = polyblur_deblurring(xt, n_iter=1, **KW)
+    st.synchronize()
+    assert torch.equal(a, c)
