@@ -72,7 +72,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -86,7 +87,7 @@ def main():
         return polyblur_deblurring(x, support=support, **KW)
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -100,16 +101,16 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                           # the slowest rank sets the time
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
     mp_per_step = B * H * W * world / 1e6
     value = mp_per_step / (ms_per_step / 1e3)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -206,7 +207,7 @@ def main():
         "context": side, "workspace_bytes": eng.workspace_bytes(),
     }
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
