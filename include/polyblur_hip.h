@@ -177,6 +177,20 @@ int pb_dt_recursive_filter(pb_ctx *ctx, const void *in, const void *joint, void 
 /* filters.bilateral_filter (filters.py:107-148), 5x5, sigma_spatial=5, sigma_color=0.1. */
 int pb_bilateral5(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W);
 
+/* ---- patch decomposition with windowed overlap-add (PolyblurDeblurring(patch_decomposition=True),
+ * deblurring.py:269-340; "next" row 1 of SURVEY 8f).  The image is (virtually) replicate-padded by
+ * (pad_top, pad_left) to a grid of n_i x n_j patches of ph x pw with strides (step_h, step_w).
+ * pb_extract_patches gathers patches [first, first+count) of every image into
+ * patches[(n-first)*B + b, c, y, x]; pb_overlap_add blends ALL n_i*n_j restored patches (laid out
+ * [n*B + b, c, y, x]) with the separable window dev_win_y (x) dev_win_x, normalises by the summed
+ * window (+1e-8), clamps to [0,1] and writes the H x W result.                               */
+int pb_extract_patches(pb_ctx *ctx, const void *img, void *patches, int dtype, int B, int C, int H, int W,
+                       int ph, int pw, int step_h, int step_w, int n_i, int n_j, int pad_top, int pad_left,
+                       int first, int count);
+int pb_overlap_add(pb_ctx *ctx, const void *patches, void *out, int dtype, int B, int C, int H, int W,
+                   int ph, int pw, int step_h, int step_w, int n_i, int n_j, int pad_top, int pad_left,
+                   const float *dev_win_y, const float *dev_win_x);
+
 /* ---- timing hooks used by bench.py ------------------------------------------------------
  * Runs only the polynomial inner loop (three stencil passes, the SURVEY 8d "inner loop")
  * `reps` times on resident data and returns the average milliseconds per repetition

@@ -549,24 +549,65 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
     return (out, infos) if return_info else out
 
 
+def kaiser_window_periodic(n: int, beta: float = 5.0) -> np.ndarray:
+    """torch.kaiser_window(n, periodic=True, beta=5) (deblurring.py:352)."""
+    if n == 1:
+        return np.ones(1, F32)
+    r = 2.0 * np.arange(n, dtype=np.float64) / n - 1.0
+    return (np.i0(beta * np.sqrt(np.maximum(0.0, 1.0 - r * r))) / np.i0(beta)).astype(F32)
+
+
+def patchwise_deblurring(images: np.ndarray, patch_size=(400, 400), patch_overlap=0.25, **kwargs) -> np.ndarray:
+    """The patch branch of PolyblurDeblurring.forward (deblurring.py:269-340), FIX-FORWARD: the reference
+    raises NameError on the undefined `handling_saturation` (:289,:315) and indexes a batch of restored
+    patches as [n::batch_size] (:335), which is only right for B == 1.  This restatement drops the
+    saturation branch and indexes per image; it is NOT pinned by reference goldens (the reference
+    cannot run this branch) -- parity for this piece is "unpinned"."""
+    x = np.asarray(images, dtype=F32)
+    h, w = x.shape[-2:]
+    if h % 2 == 1:
+        x, h = x[..., :-1, :], h - 1
+    if w % 2 == 1:
+        x, w = x[..., :, :-1], w - 1
+    ph, pw = patch_size
+    step_h, step_w = int(ph * (1 - patch_overlap)), int(pw * (1 - patch_overlap))
+    new_h = int(np.ceil((h - ph) / step_h) * step_h) + ph
+    new_w = int(np.ceil((w - pw) / step_w) * step_w) + pw
+    pl, pr = int(np.floor((new_w - w) / 2)), int(np.ceil((new_w - w) / 2))
+    pt, pb = int(np.floor((new_h - h) / 2)), int(np.ceil((new_h - h) / 2))
+    xp = np.pad(x, [(0, 0), (0, 0), (pt, pb), (pl, pr)], mode="edge")
+    window = (kaiser_window_periodic(ph)[:, None] * kaiser_window_periodic(pw)[None, :]).astype(F32)
+    acc = np.zeros_like(xp)
+    wsum = np.zeros(xp.shape[-2:], F32)
+    for i0 in range(0, new_h - ph + 1, step_h):
+        for j0 in range(0, new_w - pw + 1, step_w):
+            res = polyblur_deblurring(np.ascontiguousarray(xp[..., i0:i0 + ph, j0:j0 + pw]), **kwargs)
+            acc[..., i0:i0 + ph, j0:j0 + pw] += res * window
+            wsum[i0:i0 + ph, j0:j0 + pw] += window
+    out = np.clip(acc / (wsum + F32(1e-8)), F32(0), F32(1)).astype(F32)
+    return np.ascontiguousarray(out[..., pt:pt + h, pl:pl + w])
+
+
 class PolyblurDeblurring:
-    """deblurring.py:250-347, non-patch branch only (the patch branch raises NameError in
-    the reference).  Note the differing defaults (:266-268)."""
+    """deblurring.py:250-347.  The patch branch is the fix-forward restatement above (the reference's
+    raises NameError).  Note the differing defaults (:266-268)."""
 
     def __init__(self, patch_decomposition=False, patch_size=400, patch_overlap=0.25, batch_size=1):
-        if patch_decomposition:
-            raise NotImplementedError("patch decomposition is broken in the reference (handling_saturation)")
+        self.patch_decomposition = patch_decomposition
+        self.patch_size = (patch_size, patch_size)
+        self.patch_overlap = patch_overlap
         self.batch_size = batch_size
 
     def __call__(self, images, n_iter=1, c=0.352, b=0.468, alpha=2, beta=4, sigma_s=2, ker_size=25,
                  sigma_r=0.4, q=0.0, n_angles=6, n_interpolated_angles=30, remove_halo=False,
                  edgetaping=False, prefiltering=False, discard_saturation=False,
                  multichannel_kernel=False, method="fft", device=None):
-        return polyblur_deblurring(images, n_iter=n_iter, c=c, b=b, alpha=alpha, beta=beta, ker_size=ker_size,
-                                   sigma_s=sigma_s, sigma_r=sigma_r, remove_halo=remove_halo,
-                                   edgetaping=edgetaping, prefiltering=prefiltering,
-                                   discard_saturation=discard_saturation,
-                                   multichannel_kernel=multichannel_kernel, method=method, q=q,
-                                   n_angles=n_angles, n_interpolated_angles=n_interpolated_angles)
+        kw = dict(n_iter=n_iter, c=c, b=b, alpha=alpha, beta=beta, ker_size=ker_size, sigma_s=sigma_s, sigma_r=sigma_r,
+                  remove_halo=remove_halo, edgetaping=edgetaping, prefiltering=prefiltering,
+                  discard_saturation=discard_saturation, multichannel_kernel=multichannel_kernel, method=method, q=q,
+                  n_angles=n_angles, n_interpolated_angles=n_interpolated_angles)
+        if self.patch_decomposition:
+            return patchwise_deblurring(images, self.patch_size, self.patch_overlap, **kw)
+        return polyblur_deblurring(images, **kw)
 
     forward = __call__

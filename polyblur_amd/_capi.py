@@ -29,7 +29,8 @@ SYMBOLS = [
     "pb_default_options", "pb_workspace_bytes", "pb_malloc", "pb_free", "pb_memcpy_h2d", "pb_memcpy_d2h",
     "pb_polyblur_batch", "pb_estimate_blur", "pb_make_kernels", "pb_set_kernels", "pb_fourier_gradients",
     "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
-    "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end",
+    "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
+    "pb_overlap_add",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other"]
 
@@ -119,6 +120,8 @@ def load_library():
             "pb_dt_recursive_filter": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, ci]),
             "pb_bilateral5": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
             "pb_time_inner_loop": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, cf, cf, ci, ci, fp]),
+            "pb_extract_patches": (ci, [vp, vp, vp] + [ci] * 15),
+            "pb_overlap_add": (ci, [vp, vp, vp] + [ci] * 13 + [vp, vp]),
             "pb_profile_begin": (ci, [vp]),
             "pb_profile_end": (ci, [vp, fp, C.POINTER(ci)]),
         }

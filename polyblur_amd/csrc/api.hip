@@ -16,6 +16,11 @@ int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype,
                       float sigma_s, float sigma_r, int num_iterations);
 int pb_convert_from_float(pb_ctx *ctx, const float *in, void *out, int dtype, long n);
 int pb_convert_to_float(pb_ctx *ctx, const void *in, int dtype, float *out, long n);
+int pb_extract_patches_impl(pb_ctx *ctx, const void *img, void *patches, int dtype, int B, int C, int H, int W, int ph, int pw,
+                            int step_h, int step_w, int n_j, int pad_top, int pad_left, int first, int count);
+int pb_overlap_add_impl(pb_ctx *ctx, const void *patches, void *out, int dtype, int B, int C, int H, int W, int ph, int pw,
+                        int step_h, int step_w, int n_i, int n_j, int pad_top, int pad_left, const float *win_y,
+                        const float *win_x);
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -495,6 +500,29 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         PB_HIP(hipStreamSynchronize(ctx->stream));
     }
     return PB_OK;
+}
+
+int pb_extract_patches(pb_ctx *ctx, const void *img, void *patches, int dtype, int B, int C, int H, int W, int ph, int pw,
+                       int step_h, int step_w, int n_i, int n_j, int pad_top, int pad_left, int first, int count) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!img || !patches || ph < 1 || pw < 1 || step_h < 1 || step_w < 1 || n_i < 1 || n_j < 1 || first < 0 || count < 1 ||
+        first + count > n_i * n_j)
+        return pb_fail(ctx, PB_ERR_BADARG, "extract_patches: bad argument");
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_extract_patches_impl(ctx, img, patches, dtype, B, C, H, W, ph, pw, step_h, step_w, n_j, pad_top, pad_left, first, count);
+}
+
+int pb_overlap_add(pb_ctx *ctx, const void *patches, void *out, int dtype, int B, int C, int H, int W, int ph, int pw,
+                   int step_h, int step_w, int n_i, int n_j, int pad_top, int pad_left, const float *dev_win_y,
+                   const float *dev_win_x) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!patches || !out || !dev_win_y || !dev_win_x || ph < 1 || pw < 1 || step_h < 1 || step_w < 1 || n_i < 1 || n_j < 1)
+        return pb_fail(ctx, PB_ERR_BADARG, "overlap_add: bad argument");
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_overlap_add_impl(ctx, patches, out, dtype, B, C, H, W, ph, pw, step_h, step_w, n_i, n_j, pad_top, pad_left,
+                               dev_win_y, dev_win_x);
 }
 
 int pb_profile_begin(pb_ctx *ctx) {

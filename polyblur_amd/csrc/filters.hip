@@ -342,3 +342,100 @@ int pb_convert_from_float(pb_ctx *ctx, const float *in, void *out, int dtype, lo
     }
     return PB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// patch decomposition with windowed overlap-add (reference deblurring.py:269-340, fix-forward:
+// the undefined `handling_saturation` branch is dropped and patches of a batch are indexed
+// [n*B, (n+1)*B) instead of the reference's [n::batch_size], which is only right for B == 1)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// patches[(n*B + b), c, y, x] = img[b, c, clamp(i0 + y - pad_top), clamp(j0 + x - pad_left)],
+// n = first + local patch index, (i0, j0) = (n / n_j * step_h, n % n_j * step_w): pad_with_new_size
+// (replicate, deblurring.py:368-377) and the slicing (:312-313) in one pass.
+template <typename T>
+__global__ __launch_bounds__(NT) void extract_patches_kernel(const T *__restrict__ img, T *__restrict__ patches, int B, int C,
+                                                             int H, int W, int ph, int pw, int step_h, int step_w, int n_j,
+                                                             int pad_top, int pad_left, int first, long total) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int x = (int)(i % pw);
+        long r = i / pw;
+        const int y = (int)(r % ph); r /= ph;
+        const int c = (int)(r % C); r /= C;
+        const int b = (int)(r % B);
+        const int n = first + (int)(r / B);
+        const int i0 = (n / n_j) * step_h, j0 = (n % n_j) * step_w;
+        const int sy = min(max(i0 + y - pad_top, 0), H - 1), sx = min(max(j0 + x - pad_left, 0), W - 1);
+        patches[i] = img[(((long)b * C + c) * H + sy) * W + sx];
+    }
+}
+
+// out[b, c, Y, X] = clamp( sum_n restored_n * w / (sum_n w + 1e-8), 0, 1 ) over the patches that cover the
+// (padded) pixel, written straight into the cropped H x W result (deblurring.py:332-340): a gather, so
+// no atomics and no window_sum buffer.
+template <typename T>
+__global__ __launch_bounds__(NT) void overlap_add_kernel(const T *__restrict__ patches, T *__restrict__ out, int B, int C, int H,
+                                                         int W, int ph, int pw, int step_h, int step_w, int n_i, int n_j,
+                                                         int pad_top, int pad_left, const float *__restrict__ win_y,
+                                                         const float *__restrict__ win_x, long total) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int X = (int)(i % W);
+        long r = i / W;
+        const int Y = (int)(r % H); r /= H;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const int py = Y + pad_top, px = X + pad_left;            // position in the padded image
+        int ki_lo = (py - ph + step_h) / step_h; if (py - ph + 1 <= 0) ki_lo = 0;
+        int kj_lo = (px - pw + step_w) / step_w; if (px - pw + 1 <= 0) kj_lo = 0;
+        const int ki_hi = min(py / step_h, n_i - 1), kj_hi = min(px / step_w, n_j - 1);
+        float num = 0.f, den = 0.f;
+        for (int ki = ki_lo; ki <= ki_hi; ++ki) {
+            const int y = py - ki * step_h;
+            if (y < 0 || y >= ph) continue;
+            for (int kj = kj_lo; kj <= kj_hi; ++kj) {
+                const int x = px - kj * step_w;
+                if (x < 0 || x >= pw) continue;
+                const float w = win_y[y] * win_x[x];
+                const long n = (long)ki * n_j + kj;
+                num += w * pb_ld(patches + (((n * B + b) * C + c) * ph + y) * pw + x);
+                den += w;
+            }
+        }
+        pb_st(out + i, fminf(fmaxf(num / (den + 1e-8f), 0.f), 1.f));
+    }
+}
+
+}  // namespace
+
+int pb_extract_patches_impl(pb_ctx *ctx, const void *img, void *patches, int dtype, int B, int C, int H, int W, int ph, int pw,
+                            int step_h, int step_w, int n_j, int pad_top, int pad_left, int first, int count) {
+    const long total = (long)count * B * C * ph * pw;
+    ProfScope prof(ctx, PB_PROF_OTHER);
+    if (dtype == PB_F32)
+        hipLaunchKernelGGL(extract_patches_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, ctx->stream,
+                           static_cast<const float *>(img), static_cast<float *>(patches), B, C, H, W, ph, pw, step_h, step_w, n_j,
+                           pad_top, pad_left, first, total);
+    else
+        hipLaunchKernelGGL(extract_patches_kernel<__half>, dim3(grid_for(total)), dim3(NT), 0, ctx->stream,
+                           static_cast<const __half *>(img), static_cast<__half *>(patches), B, C, H, W, ph, pw, step_h, step_w,
+                           n_j, pad_top, pad_left, first, total);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_overlap_add_impl(pb_ctx *ctx, const void *patches, void *out, int dtype, int B, int C, int H, int W, int ph, int pw,
+                        int step_h, int step_w, int n_i, int n_j, int pad_top, int pad_left, const float *win_y,
+                        const float *win_x) {
+    const long total = (long)B * C * H * W;
+    ProfScope prof(ctx, PB_PROF_OTHER);
+    if (dtype == PB_F32)
+        hipLaunchKernelGGL(overlap_add_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, ctx->stream,
+                           static_cast<const float *>(patches), static_cast<float *>(out), B, C, H, W, ph, pw, step_h, step_w, n_i,
+                           n_j, pad_top, pad_left, win_y, win_x, total);
+    else
+        hipLaunchKernelGGL(overlap_add_kernel<__half>, dim3(grid_for(total)), dim3(NT), 0, ctx->stream,
+                           static_cast<const __half *>(patches), static_cast<__half *>(out), B, C, H, W, ph, pw, step_h, step_w,
+                           n_i, n_j, pad_top, pad_left, win_y, win_x, total);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}

@@ -138,6 +138,77 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
     return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
 
 
+def kaiser_window_periodic(n: int, beta: float = 5.0) -> np.ndarray:
+    """torch.kaiser_window(n, periodic=True, beta) (deblurring.py:352): the symmetric window of
+    length n+1 without its last sample."""
+    if n == 1:
+        return np.ones(1, np.float32)
+    k = np.arange(n, dtype=np.float64)
+    r = 2.0 * k / n - 1.0
+    return (np.i0(beta * np.sqrt(np.maximum(0.0, 1.0 - r * r))) / np.i0(beta)).astype(np.float32)
+
+
+def patch_grid(h: int, w: int, patch_size, overlap: float):
+    """The reference's patch lattice (deblurring.py:281-299): steps, padded size, pads, counts."""
+    ph, pw = patch_size
+    step_h, step_w = int(ph * (1 - overlap)), int(pw * (1 - overlap))
+    new_h = int(np.ceil((h - ph) / step_h) * step_h) + ph
+    new_w = int(np.ceil((w - pw) / step_w) * step_w) + pw
+    pad_top, pad_left = int(np.floor((new_h - h) / 2)), int(np.floor((new_w - w) / 2))
+    n_i = len(range(0, new_h - ph + 1, step_h))
+    n_j = len(range(0, new_w - pw + 1, step_w))
+    return dict(ph=ph, pw=pw, step_h=step_h, step_w=step_w, new_h=new_h, new_w=new_w, pad_top=pad_top,
+                pad_left=pad_left, n_i=n_i, n_j=n_j)
+
+
+def _patchwise_deblurring(images, patch_size, overlap, batch_size, kwargs):
+    """PolyblurDeblurring.forward, patch branch (deblurring.py:269-340, fix-forward)."""
+    import ctypes as C
+
+    import torch
+    if not _is_torch_tensor(images) or images.dim() != 4:
+        raise ValueError("patch decomposition expects a (B,C,H,W) tensor")
+    if images.dtype not in (torch.float32, torch.float16):
+        raise TypeError("tensor dtype must be float32 or float16")
+    was_cuda = images.is_cuda
+    dev = (images.device.index if images.device.index is not None else torch.cuda.current_device()) if was_cuda else 0
+    x = images if was_cuda else images.to("cuda:%d" % dev)
+    h, w = x.shape[-2:]
+    if h % 2 == 1:                                      # :273-279 make the size even
+        x = x[..., :-1, :]
+        h -= 1
+    if w % 2 == 1:
+        x = x[..., :, :-1]
+        w -= 1
+    x = x.contiguous()
+    B, Cc = x.shape[:2]
+    g = patch_grid(h, w, patch_size, overlap)
+    if g["new_h"] - h > 2 * (h - 1) + 2 or g["ph"] < 2 or g["pw"] < 2:
+        raise ValueError("patch size incompatible with the image")
+    eng = get_engine(dev)
+    dtype = capi.PB_F32 if x.dtype == torch.float32 else capi.PB_F16
+    n_p = g["n_i"] * g["n_j"]
+    wy = torch.from_numpy(kaiser_window_periodic(g["ph"])).to(x.device)
+    wx = torch.from_numpy(kaiser_window_periodic(g["pw"])).to(x.device)
+    restored = torch.empty((n_p * B, Cc, g["ph"], g["pw"]), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(dev):
+        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        group = max(1, int(batch_size))
+        for first in range(0, n_p, group):                       # :310 groups of `batch_size` patches
+            count = min(group, n_p - first)
+            patches = torch.empty((count * B, Cc, g["ph"], g["pw"]), dtype=x.dtype, device=x.device)
+            eng._check(eng.lib.pb_extract_patches(eng.ctx, x.data_ptr(), patches.data_ptr(), dtype, B, Cc, h, w, g["ph"],
+                                                  g["pw"], g["step_h"], g["step_w"], g["n_i"], g["n_j"], g["pad_top"],
+                                                  g["pad_left"], first, count))
+            restored[first * B:(first + count) * B] = polyblur_deblurring(patches, **kwargs)
+        out = torch.empty_like(x)
+        eng._check(eng.lib.pb_overlap_add(eng.ctx, restored.data_ptr(), out.data_ptr(), dtype, B, Cc, h, w, g["ph"], g["pw"],
+                                          g["step_h"], g["step_w"], g["n_i"], g["n_j"], g["pad_top"], g["pad_left"],
+                                          C.c_void_p(wy.data_ptr()), C.c_void_p(wx.data_ptr())))
+        torch.cuda.current_stream(dev).synchronize()             # wy / wx / restored must outlive the kernels
+    return out if was_cuda else out.cpu()
+
+
 class _ModuleBase:
     pass
 
@@ -153,7 +224,10 @@ class PolyblurDeblurring(_Base):
     """Stateless module wrapper, reference deblurring.py:250-347.
 
     ``patch_decomposition=True`` raises ``NameError`` in the reference (undefined
-    ``handling_saturation``, deblurring.py:289); here it raises ``NotImplementedError``.
+    ``handling_saturation``, deblurring.py:289).  Here it is built "fix-forward" (SURVEY 8f row 1):
+    the saturation branch is dropped and the restored patches of a batch are indexed per image;
+    everything else -- even-size crop, replicate padding to the patch grid, periodic Kaiser(beta=5)
+    window, overlap-add normalised by the summed window + 1e-8, clamp, crop -- follows :269-340.
     Note the defaults of ``forward`` differ from the functional API's (deblurring.py:266-268).
     """
 
@@ -168,8 +242,13 @@ class PolyblurDeblurring(_Base):
                 q=0.0, n_angles=6, n_interpolated_angles=30, remove_halo=False, edgetaping=False, prefiltering=False,
                 discard_saturation=False, multichannel_kernel=False, method='fft', device=None, **extras):
         if self.patch_decomposition:
-            raise NotImplementedError("patch decomposition is broken in the reference (deblurring.py:289) "
-                                      "and not built yet")
+            return _patchwise_deblurring(images, self.patch_size, self.patch_overlap, self.batch_size,
+                                         dict(n_iter=n_iter, c=c, b=b, alpha=alpha, beta=beta, ker_size=ker_size,
+                                              sigma_s=sigma_s, sigma_r=sigma_r, remove_halo=remove_halo,
+                                              edgetaping=edgetaping, prefiltering=prefiltering,
+                                              discard_saturation=discard_saturation,
+                                              multichannel_kernel=multichannel_kernel, method=method, q=q,
+                                              n_angles=n_angles, n_interpolated_angles=n_interpolated_angles, **extras))
         return polyblur_deblurring(images, n_iter=n_iter, c=c, b=b, alpha=alpha, beta=beta, ker_size=ker_size,
                                    sigma_s=sigma_s, sigma_r=sigma_r, remove_halo=remove_halo, edgetaping=edgetaping,
                                    prefiltering=prefiltering, discard_saturation=discard_saturation,

@@ -64,8 +64,8 @@ def test_argument_validation_before_any_device_work():
         polyblur_deblurring(np.zeros((4,), np.float32))
     with pytest.raises(TypeError):
         polyblur_deblurring([[0.0]])
-    with pytest.raises(NotImplementedError):
-        PolyblurDeblurring(patch_decomposition=True)(x)
+    with pytest.raises(ValueError):
+        PolyblurDeblurring(patch_decomposition=True)(x)             # patch branch: (B,C,H,W) tensors only
     # the module's defaults differ from the functional ones (reference deblurring.py:266-268)
     import inspect
     f = inspect.signature(polyblur_deblurring).parameters
@@ -91,3 +91,17 @@ def test_synthetic_generator_is_deterministic():
     assert a.min() >= 0 and a.max() <= 1 and not np.array_equal(a[0], a[1])
     c, pc = synthetic_blurry_batch(1, 3, 40, 56, seed0=5, force_theta_deg=0.0)
     assert pc[0][2] == 0.0
+
+
+def test_patch_lattice_matches_reference_formulas():
+    """deblurring.py:281-299 for the reference's default 400 / 0.25 and a small case"""
+    from polyblur_amd.deblurring import patch_grid, kaiser_window_periodic
+    g = patch_grid(1080, 1920, (400, 400), 0.25)
+    assert (g["step_h"], g["step_w"]) == (300, 300)
+    assert (g["new_h"], g["new_w"]) == (1300, 2200) and (g["n_i"], g["n_j"]) == (4, 7)
+    assert (g["pad_top"], g["pad_left"]) == (110, 140)
+    g = patch_grid(90, 60, (100, 100), 0.25)                # image smaller than one patch
+    assert (g["new_h"], g["new_w"], g["n_i"], g["n_j"]) == (100, 100, 1, 1)
+    import torch
+    for n in (400, 7):
+        assert np.abs(kaiser_window_periodic(n) - torch.kaiser_window(n, periodic=True, beta=5.0).numpy()).max() < 1e-6

@@ -332,8 +332,8 @@ def test_argument_errors():
         polyblur_deblurring(x, method="nope")
     with pytest.raises(ValueError):
         polyblur_deblurring(x, q=0.7)
-    with pytest.raises(NotImplementedError):
-        PolyblurDeblurring(patch_decomposition=True)(x)
+    with pytest.raises(ValueError):
+        PolyblurDeblurring(patch_decomposition=True)(x)               # the patch branch needs a (B,C,H,W) tensor
     with pytest.raises(ValueError):
         polyblur_deblurring(np.zeros((2, 2, 2, 2, 2), np.float32))
 
@@ -439,3 +439,26 @@ def test_non_contiguous_and_stream(eng):
         c = polyblur_deblurring(xt, n_iter=1, **KW)
     st.synchronize()
     assert torch.equal(a, c)
+
+
+# ---------------------------------------------------------------------------------------------
+# patch decomposition + Kaiser overlap-add (fix-forward of deblurring.py:269-340)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,ps,bs", [((2, 3, 150, 210), 64, 4), ((1, 3, 151, 211), 80, 1), ((1, 1, 90, 60), 100, 20)])
+def test_patch_decomposition(shape, ps, bs):
+    """the reference's patch branch raises NameError, so this is checked against the oracle's
+    fix-forward restatement only ("unpinned"): lattice, replicate padding, periodic Kaiser window,
+    normalised overlap-add, odd sizes cropped to even, image smaller than one patch"""
+    import torch
+    from polyblur_amd import PolyblurDeblurring
+    x, _ = synthetic_blurry_batch(shape[0], shape[1], shape[2], shape[3], seed0=23)
+    kw = dict(n_iter=2, c=0.362, b=0.468, alpha=6, beta=1)
+    got = PolyblurDeblurring(patch_decomposition=True, patch_size=ps, patch_overlap=0.25, batch_size=bs)(
+        torch.from_numpy(x).cuda(), **kw)
+    want = ref.PolyblurDeblurring(patch_decomposition=True, patch_size=ps, patch_overlap=0.25)(x, **kw)
+    assert tuple(got.shape) == want.shape == (shape[0], shape[1], shape[2] // 2 * 2, shape[3] // 2 * 2)
+    assert maxabs(got.cpu().numpy(), want) < 3e-5
+    # patches are independent images: grouping them differently must not change a bit
+    got2 = PolyblurDeblurring(patch_decomposition=True, patch_size=ps, patch_overlap=0.25, batch_size=1)(
+        torch.from_numpy(x).cuda(), **kw)
+    assert torch.equal(got, got2)
