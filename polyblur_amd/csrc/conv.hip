@@ -25,17 +25,17 @@
 
 #include "common.h"
 #include "conv_common.h"
+#include "conv_tile_common.h"
 
 int pb_launch_conv_stream(pb_ctx *ctx, const ConvPass &p);
+int pb_launch_conv_sep(pb_ctx *ctx, const ConvPass &p);
 
 namespace {
 
-constexpr int NT = 256;
 
 // =============================================================================================
 // general kernels: workgroup tile body
 // =============================================================================================
-constexpr int GT = 64;   // 64 x 64 outputs per workgroup, 4 x 4 per thread
 
 template <typename T, int LH, int LW, int LP>
 __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
@@ -67,59 +67,70 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
             if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
         }
     } else {
-        for (int e = tid; e < LH * LW; e += NT) {
-            const int r = e / LW, c = e - r * LW;
-            const int iy = map_axis(py0 + r, H, kind, boundary), ix = map_axis(px0 + c, W, kind, boundary);
-            s[r * LP + c] = (iy >= 0 && ix >= 0) ? pb_ld(plane + (long)iy * pitch + ix) : 0.f;
+        // border tile: every sample mapped (wrap / zero / clamp); 8 independent loads in flight per thread
+        for (int base = 0; base < LH * LW; base += 8 * NT) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NT + tid;
+                v[u] = 0.f;
+                if (e < LH * LW) {
+                    const int r = e / LW, c = e - r * LW;
+                    const int iy = map_axis(py0 + r, H, kind, boundary), ix = map_axis(px0 + c, W, kind, boundary);
+                    if (iy >= 0 && ix >= 0) v[u] = pb_ld(plane + (long)iy * pitch + ix);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NT + tid;
+                if (e < LH * LW) { const int r = e / LW, c = e - r * LW; s[r * LP + c] = v[u]; }
+            }
         }
     }
 }
 
-// Per-thread epilogue of a 4 x 4 output block.  `prefetch` is called right after the tile loads have
-// been issued so that the x operand arrives while the stencil is evaluated; blocks that touch the
-// border of the output region (or a clamped / unaligned x operand, or the taper blend) take finish4.
-template <typename TX, typename TOut> struct Block4x4Epilogue {
-    bool fast;
-    float4 xr[4];
-    const TX *xp;
-    TOut *op;
-    __device__ __forceinline__ void prefetch(const ConvPass &a, const TX *xpl, TOut *opl, const OutRegion &rg, int py, int px) {
-        const int xo = a.x_kind == SRC_VIRTUAL ? PB_PAD : 0, oo = a.out_kind == OUT_INTERIOR ? PB_PAD : 0;
-        const int xrows = a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * PB_PAD, xcols = a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * PB_PAD;
-        fast = a.epilogue == EPI_HORNER && py + 3 < rg.y_hi && px + 3 < rg.x_hi && py - xo >= 0 && py - xo + 3 < xrows &&
-               px - xo >= 0 && px - xo + 3 < xcols && ((a.x_pitch | a.out_pitch) & 3) == 0;
-        if (fast) {
-            xp = xpl + (long)(py - xo) * a.x_pitch + (px - xo);
-            op = opl + (long)(py - oo) * a.out_pitch + (px - oo);
+// Wave-private variant for the rank-1 body: wave w stages rows [w*RPW, (w+1)*RPW) of the tile -- exactly
+// the rows it x-filters -- so no workgroup barrier is needed between the load and the x pass and the four
+// waves of a workgroup drift apart (one's loads overlap another's arithmetic).
+template <typename T, int LH, int LW, int LP, int RPW>
+__device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
+                                               int boundary) {
+    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
+    bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
+    int sy0 = py0, sx0 = px0;
+    if (kind == SRC_VIRTUAL) {
+        inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
+        sy0 -= PB_PAD; sx0 -= PB_PAD;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = wave * RPW;
+    const int nrows = min(RPW, LH - r0);
+    constexpr int C4 = LW / 4;
+    if (inside && ((pitch | sx0) & 3) == 0) {
+        const T *base = plane + (long)(sy0 + r0) * pitch + sx0;
+        constexpr int NLD = (RPW * C4 + 63) / 64;
+        float4 buf[NLD];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xr[r] = ld4<TX>(xp + (long)r * a.x_pitch);
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows) buf[k] = ld4<T>(base + (long)r * pitch + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows) *reinterpret_cast<float4 *>(s + (r0 + r) * LP + 4 * c) = buf[k];
+        }
+    } else {
+#pragma unroll 1
+        for (int e = lane; e < nrows * LW; e += 64) {
+            const int r = e / LW, c = e - r * LW;
+            const int iy = map_axis(py0 + r0 + r, H, kind, boundary), ix = map_axis(px0 + c, W, kind, boundary);
+            s[(r0 + r) * LP + c] = (iy >= 0 && ix >= 0) ? pb_ld(plane + (long)iy * pitch + ix) : 0.f;
         }
     }
-    __device__ __forceinline__ void finish(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl,
-                                           const OutRegion &rg, int py, int px, const float4 (&acc)[4]) {
-        if (fast) {
-            const float sc = a.scale, cf = a.coef;
-            const bool cl = a.clamp01 != 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float4 v;
-                v.x = fmaf(sc, acc[r].x, cf * xr[r].x); v.y = fmaf(sc, acc[r].y, cf * xr[r].y);
-                v.z = fmaf(sc, acc[r].z, cf * xr[r].z); v.w = fmaf(sc, acc[r].w, cf * xr[r].w);
-                if (cl) {
-                    v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
-                    v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
-                }
-                st4<TOut>(op + (long)r * a.out_pitch, v);
-            }
-        } else {
-            // (statically indexed: a run-time index would push acc[] -- and a 64-byte store per thread -- to scratch)
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py, px, acc[0]);
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 1, px, acc[1]);
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 2, px, acc[2]);
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 3, px, acc[3]);
-        }
-    }
-};
+}
 
 // One window row of the general stencil: element m of the thread's window (column c0 - R + m) feeds
 // the four outputs c0 .. c0+3 with taps t[m+3], t[m+2], t[m+1], t[m] (t = the kernel row, zero padded by
@@ -202,39 +213,6 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
 // rank-1 kernels in the tile geometry: x pass in place in LDS, y pass into registers.
 // Both passes run on packed FMAs (conv_common.h); rank-1 records carry symmetric marginals.
 // ---------------------------------------------------------------------------------------------
-template <int R, int P> __device__ __forceinline__ void xtap(f2 &acc, const f2 (&TP)[R + 1], f2 dpair, int) {}
-template <int R, int P, int HI> struct XTapApply {
-    static __device__ __forceinline__ void run(f2 &acc, const f2 (&TP)[R + 1], f2 dpair) {
-        if constexpr (P <= R) pk_bcast_data<0, HI>(acc, TP[P], dpair);
-        else pk_bcast_data<1, HI>(acc, TP[2 * R + 1 - P], dpair);
-    }
-};
-// window element J (0 .. 2R+3) feeds (x,y) with the tap pair T[J] and (z,w) with T[J-2]
-template <int R, int J> struct XPassR {
-    static __device__ __forceinline__ void run(f2 &vxy, f2 &vzw, const f2 (&TP)[R + 1], const f2 (&d)[R + 2]) {
-        if constexpr (J <= 2 * R + 1) XTapApply<R, J, J & 1>::run(vxy, TP, d[J >> 1]);
-        if constexpr (J >= 2) XTapApply<R, J - 2, J & 1>::run(vzw, TP, d[J >> 1]);
-        if constexpr (J < 2 * R + 3) XPassR<R, J + 1>::run(vxy, vzw, TP, d);
-    }
-};
-// input row I (0 .. 2R+3) of the thread's window feeds output row r with tap I - r
-template <int R, int I> struct YPassR {
-    static __device__ __forceinline__ void run(f2 (&axy)[4], f2 (&azw)[4], const f2 (&HY)[(R + 2) / 2], const float *col,
-                                               int pitch) {
-        const float4 v4 = *reinterpret_cast<const float4 *>(col + I * pitch);
-        const f2 vxy = (f2){v4.x, v4.y}, vzw = (f2){v4.z, v4.w};
-#define PB_YROW(RR)                                                                   \
-        if constexpr (I - RR >= 0 && I - RR <= 2 * R) {                               \
-            constexpr int t = I - RR, q = t <= R ? t : 2 * R - t;                     \
-            pk_bcast_tap<q & 1>(axy[RR], HY[q >> 1], vxy);                            \
-            pk_bcast_tap<q & 1>(azw[RR], HY[q >> 1], vzw);                            \
-        }
-        PB_YROW(0) PB_YROW(1) PB_YROW(2) PB_YROW(3)
-#undef PB_YROW
-        if constexpr (I < 2 * R + 3) YPassR<R, I + 1>::run(axy, azw, HY, col, pitch);
-    }
-};
-
 template <typename TIn, typename TX, typename TOut, int R>
 __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
                                               TOut *opl, int tile, int tiles_x, float *smem) {
@@ -248,7 +226,8 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     Block4x4Epilogue<TX, TOut> epi;
     const int rgp = threadIdx.x >> 4, gy = ((threadIdx.x & 15) + YROT * (rgp & 1)) & 15;   // y-pass / output mapping
     epi.prefetch(a, xpl, opl, rg, oy0 + rgp * 4, ox0 + 4 * gy);
-    load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
+    constexpr int RPW = (LH + 3) / 4;                  // rows staged and x-filtered by each wave
+    load_rows_wave<TIn, LH, LW, LP, RPW>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
     // taps: TP[p] = (h[p], h[p-1]),  HY[m] = (hy[2m], hy[2m+1]),  h = marginal taps 0..R of the class
     const PB_CONSTANT float *ckx = as_constant(info->kx) + (PB_KRAD - R), *cky = as_constant(info->ky) + (PB_KRAD - R);
     f2 TP[R + 1], HY[(R + 2) / 2];
@@ -256,12 +235,11 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     for (int t = 0; t <= R; ++t) TP[t] = (f2){ckx[t], t ? ckx[t - 1] : 0.f};
 #pragma unroll
     for (int m = 0; m < (R + 2) / 2; ++m) HY[m] = (f2){cky[2 * m], 2 * m + 1 <= R ? cky[2 * m + 1] : 0.f};
-    __syncthreads();
+    wave_lds_fence();                                   // a wave reads back only rows it staged itself
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // ---- x pass, in place: each wave owns LH/4 rows; a wave instruction covers 4 rows x 16 groups ----
     {
-        constexpr int RPW = (LH + 3) / 4;                  // rows per wave
         // consecutive rows are LP/4 sixteen-byte slots apart; the two rows that share a 32-lane half are
         // read conflict-free when the odd one starts XROT groups further along the row
         const int rsub = lane >> 4, g = ((lane & 15) + XROT * (rsub & 1)) & 15;
@@ -350,14 +328,23 @@ int launch_typed(pb_ctx *ctx, const ConvPass &p, int sep_in_tile) {
 // rank-1 and general kernels and the host never has to read the estimates back.
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
     ProfScope prof(ctx, PB_PROF_CONV);
-    static int sep_in_tile = -1;          // PB_SEP_BODY=stream|tile selects the rank-1 body (default: tile)
-    if (sep_in_tile < 0) {
+    // PB_SEP_BODY selects the body for rank-1 images: "tile" (default: inside the one-shot tile kernel,
+    // the fastest today), "dma" (persistent double-buffered LDS-DMA kernel, fp32 input only) or "stream"
+    // (wave-private streaming kernel).  The two alternatives are kept selectable and parity-tested.
+    static int sep_mode = -1;
+    if (sep_mode < 0) {
         const char *e = getenv("PB_SEP_BODY");
-        sep_in_tile = (e && e[0] == 's') ? 0 : 1;
+        sep_mode = (e && e[0] == 's') ? 2 : ((e && e[0] == 'd') ? 0 : 1);
     }
-    if (!sep_in_tile) {
+    int sep_in_tile = 1;
+    if (sep_mode == 2) {
         int rc = pb_launch_conv_stream(ctx, p);
         if (rc) return rc;
+        sep_in_tile = 0;
+    } else if (sep_mode == 0 && p.in_dtype == PB_F32) {
+        int rc = pb_launch_conv_sep(ctx, p);
+        if (rc) return rc;
+        sep_in_tile = 0;
     }
     const int key = p.in_dtype * 4 + p.x_dtype * 2 + p.out_dtype;
     switch (key) {

@@ -1,0 +1,111 @@
+// Pieces shared by the tile-geometry stencil kernels (conv.hip, conv_sep.hip).
+#pragma once
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int GT = 64;   // 64 x 64 outputs per workgroup tile, 4 x 4 per thread
+
+// What a workgroup needs to know about one tile.
+struct TileJob {
+    int plane, ty, tx;
+    const pb_blur_info *info;
+    int cls;                       // 8 * separable + support class index (0: R=4, 1: R=8, 2: R=12)
+};
+__device__ __forceinline__ TileJob decode_tile(const ConvPass &a, int tile_id, int tiles_per_plane, int tiles_x, int) {
+    TileJob j;
+    j.plane = tile_id / tiles_per_plane;
+    const int local = tile_id - j.plane * tiles_per_plane;
+    j.ty = local / tiles_x;
+    j.tx = local - j.ty * tiles_x;
+    j.info = a.info + j.plane / a.C;
+    const PB_CONSTANT pb_blur_info *ci = as_constant(j.info);
+    const int sep = ci->separable != 0;
+    const int R = a.force_full ? PB_KRAD : ci->radius;
+    j.cls = 8 * sep + (R <= 4 ? 0 : (R <= 8 ? 1 : 2));
+    return j;
+}
+
+// Per-thread epilogue of a 4 x 4 output block.  `prefetch` is called right after the tile loads have
+// been issued so that the x operand arrives while the stencil is evaluated; blocks that touch the
+// border of the output region (or a clamped / unaligned x operand, or the taper blend) take finish4.
+template <typename TX, typename TOut> struct Block4x4Epilogue {
+    bool fast;
+    float4 xr[4];
+    const TX *xp;
+    TOut *op;
+    __device__ __forceinline__ void prefetch(const ConvPass &a, const TX *xpl, TOut *opl, const OutRegion &rg, int py, int px) {
+        const int xo = a.x_kind == SRC_VIRTUAL ? PB_PAD : 0, oo = a.out_kind == OUT_INTERIOR ? PB_PAD : 0;
+        const int xrows = a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * PB_PAD, xcols = a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * PB_PAD;
+        fast = a.epilogue == EPI_HORNER && py + 3 < rg.y_hi && px + 3 < rg.x_hi && py - xo >= 0 && py - xo + 3 < xrows &&
+               px - xo >= 0 && px - xo + 3 < xcols && ((a.x_pitch | a.out_pitch) & 3) == 0;
+        if (fast) {
+            xp = xpl + (long)(py - xo) * a.x_pitch + (px - xo);
+            op = opl + (long)(py - oo) * a.out_pitch + (px - oo);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xr[r] = ld4<TX>(xp + (long)r * a.x_pitch);
+        }
+    }
+    __device__ __forceinline__ void finish(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl,
+                                           const OutRegion &rg, int py, int px, const float4 (&acc)[4]) {
+        if (fast) {
+            const float sc = a.scale, cf = a.coef;
+            const bool cl = a.clamp01 != 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 v;
+                v.x = fmaf(sc, acc[r].x, cf * xr[r].x); v.y = fmaf(sc, acc[r].y, cf * xr[r].y);
+                v.z = fmaf(sc, acc[r].z, cf * xr[r].z); v.w = fmaf(sc, acc[r].w, cf * xr[r].w);
+                if (cl) {
+                    v.x = fminf(fmaxf(v.x, 0.f), 1.f); v.y = fminf(fmaxf(v.y, 0.f), 1.f);
+                    v.z = fminf(fmaxf(v.z, 0.f), 1.f); v.w = fminf(fmaxf(v.w, 0.f), 1.f);
+                }
+                st4<TOut>(op + (long)r * a.out_pitch, v);
+            }
+        } else {
+            // (statically indexed: a run-time index would push acc[] -- and a 64-byte store per thread -- to scratch)
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py, px, acc[0]);
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 1, px, acc[1]);
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 2, px, acc[2]);
+            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 3, px, acc[3]);
+        }
+    }
+};
+
+template <int R, int P> __device__ __forceinline__ void xtap(f2 &acc, const f2 (&TP)[R + 1], f2 dpair, int) {}
+template <int R, int P, int HI> struct XTapApply {
+    static __device__ __forceinline__ void run(f2 &acc, const f2 (&TP)[R + 1], f2 dpair) {
+        if constexpr (P <= R) pk_bcast_data<0, HI>(acc, TP[P], dpair);
+        else pk_bcast_data<1, HI>(acc, TP[2 * R + 1 - P], dpair);
+    }
+};
+// window element J (0 .. 2R+3) feeds (x,y) with the tap pair T[J] and (z,w) with T[J-2]
+template <int R, int J> struct XPassR {
+    static __device__ __forceinline__ void run(f2 &vxy, f2 &vzw, const f2 (&TP)[R + 1], const f2 (&d)[R + 2]) {
+        if constexpr (J <= 2 * R + 1) XTapApply<R, J, J & 1>::run(vxy, TP, d[J >> 1]);
+        if constexpr (J >= 2) XTapApply<R, J - 2, J & 1>::run(vzw, TP, d[J >> 1]);
+        if constexpr (J < 2 * R + 3) XPassR<R, J + 1>::run(vxy, vzw, TP, d);
+    }
+};
+// input row I (0 .. 2R+3) of the thread's window feeds output row r with tap I - r
+template <int R, int I> struct YPassR {
+    static __device__ __forceinline__ void run(f2 (&axy)[4], f2 (&azw)[4], const f2 (&HY)[(R + 2) / 2], const float *col,
+                                               int pitch) {
+        const float4 v4 = *reinterpret_cast<const float4 *>(col + I * pitch);
+        const f2 vxy = (f2){v4.x, v4.y}, vzw = (f2){v4.z, v4.w};
+#define PB_YROW(RR)                                                                   \
+        if constexpr (I - RR >= 0 && I - RR <= 2 * R) {                               \
+            constexpr int t = I - RR, q = t <= R ? t : 2 * R - t;                     \
+            pk_bcast_tap<q & 1>(axy[RR], HY[q >> 1], vxy);                            \
+            pk_bcast_tap<q & 1>(azw[RR], HY[q >> 1], vzw);                            \
+        }
+        PB_YROW(0) PB_YROW(1) PB_YROW(2) PB_YROW(3)
+#undef PB_YROW
+        if constexpr (I < 2 * R + 3) YPassR<R, I + 1>::run(axy, azw, HY, col, pitch);
+    }
+};
+
+
+}  // namespace

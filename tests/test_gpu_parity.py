@@ -462,3 +462,30 @@ def test_patch_decomposition(shape, ps, bs):
     got2 = PolyblurDeblurring(patch_decomposition=True, patch_size=ps, patch_overlap=0.25, batch_size=1)(
         torch.from_numpy(x).cuda(), **kw)
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("body", ["dma", "stream"])
+def test_alternative_rank1_bodies(body):
+    """the two alternative rank-1 kernels (PB_SEP_BODY=dma|stream, read once per process) stay parity-green"""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, %r)\n"
+        "from oracle import polyblur_ref as ref\n"
+        "from polyblur_amd import _capi as capi\n"
+        "from polyblur_amd.engine import get_engine\n"
+        "from polyblur_amd.synthetic import synthetic_blurry_batch\n"
+        "eng = get_engine(0)\n"
+        "x, _ = synthetic_blurry_batch(2, 3, 300, 520, seed0=11)\n"
+        "for sg, rh, dg, bnd, m in ((2.5, 1.0, 0.0, capi.PB_WRAP, 'fft'), (1.0, 3.0, 90.0, capi.PB_ZERO, 'direct')):\n"
+        "    th = np.float32(dg) * np.float32(np.pi) / np.float32(180)\n"
+        "    k = ref.gaussian_kernel_2d([th] * 2, [sg] * 2, [rh] * 2)\n"
+        "    buf = eng.make_kernels([sg] * 2, [rh] * 2, [th] * 2)\n"
+        "    out = eng.inverse_filter(x, buf, 6.0, 1.0, bnd)\n"
+        "    want = ref.inverse_filtering_rank3(x, k[:, None], 6.0, 1.0, method=m)\n"
+        "    err = float(np.abs(out - want).max())\n"
+        "    assert err < 1e-5, err\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, PB_SEP_BODY=body)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
