@@ -55,9 +55,11 @@ typedef enum pb_boundary { PB_WRAP = 0, PB_ZERO = 1 } pb_boundary;
 typedef enum pb_prefilter { PB_PREFILTER_NONE = 0, PB_PREFILTER_BILATERAL = 1,
                             PB_PREFILTER_DOMAIN_TRANSFORM = 2 } pb_prefilter;
 
-/* Kernel-support policy: PB_SUPPORT_FULL evaluates all 25 taps per axis like the
- * reference; PB_SUPPORT_ADAPTIVE drops taps whose marginal mass is < 1e-8 (support
- * radius rounded up to 4, 8 or 12) -- results agree to fp32 rounding.                  */
+/* Kernel-support policy: PB_SUPPORT_FULL evaluates every tap of the reference's 25x25 kernel
+ * that is not exactly 0.0f (outer rows / columns whose taps all underflowed to zero are skipped,
+ * which is bit-identical to evaluating them); PB_SUPPORT_ADAPTIVE also drops taps whose marginal
+ * mass is < 1e-8 -- results agree to fp32 rounding.  Either way the evaluated radius is rounded
+ * up to 4, 8 or 12.                                                                      */
 typedef enum pb_support { PB_SUPPORT_FULL = 0, PB_SUPPORT_ADAPTIVE = 1,
                           /* test/bench flag, OR-ed in: never take the rank-1 (separable) path */
                           PB_SUPPORT_FORCE_GENERAL = 16 } pb_support;

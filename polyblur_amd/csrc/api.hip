@@ -470,7 +470,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (!smooth || !ybuf) return PB_ERR_NOMEM;
     }
     const void *cur = in;
-    const int force_full = (opt->support & 15) == PB_SUPPORT_FULL;
+    const int force_full = 0;          // the record's radius already encodes the policy (estimate.hip: finish_record)
     for (int it = 0; it < n_iter; ++it) {
         // the last iteration must land in `out`; alternate between out and tmpimg before that
         void *dst = ((n_iter - 1 - it) % 2 == 0) ? out : tmpimg;

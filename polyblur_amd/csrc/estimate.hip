@@ -689,6 +689,13 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         info->gtaps[idx] = (j >= 0 && j < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j] : 0.f;
         info->gtaps_odd[idx] = (j + 1 >= 0 && j + 1 < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j + 1] : 0.f;
     }
+    __shared__ int nz[PB_KSIZE];
+    if (tid < PB_KSIZE) {
+        int any = 0;
+        for (int i = 0; i < PB_KSIZE; ++i)
+            any |= (info->kernel[i * PB_KSIZE + tid] != 0.f) | (info->kernel[tid * PB_KSIZE + i] != 0.f);
+        nz[tid] = any;
+    }
     // rank-1 residual  sum |k - ky (x) kx|  and the total mass (for arbitrary taps)
     float res = 0.f;
     for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT)
@@ -696,17 +703,17 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     const float resid = block_sum(res, red);
     if (tid == 0) {
         info->separable = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL)) ? 1 : 0;
-        int rad = PB_KRAD;
-        if ((support & 15) == PB_SUPPORT_ADAPTIVE) {
-            // smallest radius outside which both marginals carry < 1e-8 of the mass
-            rad = 0;
-            for (int t = 0; t < PB_KSIZE; ++t) {
-                const int d = t > PB_KRAD ? t - PB_KRAD : PB_KRAD - t;
-                if ((fabsf(info->kx[t]) >= 1e-8f || fabsf(info->ky[t]) >= 1e-8f) && d > rad) rad = d;
-            }
-            rad = rad <= 4 ? 4 : (rad <= 8 ? 8 : PB_KRAD);
+        // FULL: every tap that is not exactly 0.0f is evaluated (rows / columns whose taps all underflowed to
+        // zero -- sigma below ~0.9 -- are skipped: bit-identical to evaluating them).  ADAPTIVE: the smallest
+        // radius outside which both marginals carry < 1e-8 of the mass.
+        const float thr = (support & 15) == PB_SUPPORT_ADAPTIVE ? 1e-8f : 0.f;
+        int rad = 0;
+        for (int t = 0; t < PB_KSIZE; ++t) {
+            const int d = t > PB_KRAD ? t - PB_KRAD : PB_KRAD - t;
+            const bool live = thr > 0.f ? (fabsf(info->kx[t]) >= thr || fabsf(info->ky[t]) >= thr) : (nz[t] != 0);
+            if (live && d > rad) rad = d;
         }
-        info->radius = rad;
+        info->radius = rad <= 4 ? 4 : (rad <= 8 ? 8 : PB_KRAD);
     }
 }
 

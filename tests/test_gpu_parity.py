@@ -91,7 +91,12 @@ def test_make_kernels_grid(eng, golden):
     assert maxabs(info["kernel"], g["kernels"]) < 5e-7
     sep_expected = (np.isin(np.round(np.rad2deg(g["theta"])).astype(int) % 90, [0])) | (g["sigma"] == g["rho"])
     assert np.array_equal(info["separable"].astype(bool), sep_expected)
-    assert np.all(info["radius"] == 12)
+    # full support: the radius class covers every tap that is not exactly 0.0f
+    k = info["kernel"].reshape(-1, 25, 25) != 0
+    d = np.abs(np.arange(25) - 12)
+    ext = np.maximum((k.any(axis=1) * d).max(axis=1), (k.any(axis=2) * d).max(axis=1))
+    assert np.array_equal(info["radius"], np.where(ext <= 4, 4, np.where(ext <= 8, 8, 12)))
+    assert np.all(info["radius"][np.maximum(g["sigma"], g["rho"]) >= 1.0] == 12)
     # adaptive support: radius class follows the wider std
     buf = eng.make_kernels(g["sigma"], g["rho"], g["theta"], support=capi.PB_SUPPORT_ADAPTIVE)
     info = eng.read_info(buf, g["sigma"].size)
