@@ -28,6 +28,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 KW = dict(n_iter=3, c=0.362, b=0.468, alpha=6, beta=1)
+VALU_PEAK_TFLOPS = 157.3      # fp32 packed FMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -144,7 +145,18 @@ def main():
     # ---- context: what the estimator found, and the labelled side numbers ----------------------
     _, infos = polyblur_deblurring(x, return_info=True, **KW)
     est = [dict(theta_deg=round(float(np.rad2deg(i["theta"][0])), 1), sigma=round(float(i["sigma"][0]), 3),
-                rho=round(float(i["rho"][0]), 3), separable=int(i["separable"][0])) for i in infos]
+                rho=round(float(i["rho"][0]), 3), separable=int(i["separable"][0]), radius=int(i["radius"][0]))
+           for i in infos]
+    # The synthetic blur is oblique (2 of the 30 candidate angles give a rank-1 kernel), so the estimated 25x25
+    # kernels are dense and the stencil pass is fp32-VALU-bound, not HBM-bound: say how close to THAT ceiling it
+    # runs (multiply-adds actually issued per launch / launch time; peak = 256 CU x 128 lanes x 2 x 2.4 GHz).
+    macs = [sum((2 * int(r) + 1) * (2 if sp else (2 * int(r) + 1)) for r, sp in zip(i["radius"], i["separable"]))
+            for i in infos]                                       # per sample position of the batch, per pass
+    tflops = 2.0 * 3 * H * W * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12
+    roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(tflops / VALU_PEAK_TFLOPS, 4),
+                            note="dense (non-rank-1) kernels estimated for this input: the pass is VALU-bound; "
+                                 "context.inner_loop_rank1_* is the HBM-bound separable case")
 
     def inner_loop(theta_deg, sigma, rho, support, reps=20):
         buf = eng.make_kernels([sigma] * B, [rho] * B, [np.deg2rad(np.float32(theta_deg))] * B, support=support,

@@ -45,7 +45,11 @@ typedef enum pb_status {
     PB_ERR_NOMEM = -4
 } pb_status;
 
-typedef enum pb_dtype { PB_F32 = 0, PB_F16 = 1 } pb_dtype;
+/* PB_U8: 8-bit images at the file edge of the reference's CLI flow (main.py:80-82,146): loaded as
+ * v * float32(1/255) (skimage 0.19.2 img_as_float32) and stored as clip(rint(v*255), 0, 255)
+ * (img_as_ubyte) inside the first / last kernels that touch them; everything in between is fp32.
+ * Accepted by pb_polyblur_batch, pb_estimate_blur, pb_u8_interleave / pb_u8_deinterleave.     */
+typedef enum pb_dtype { PB_F32 = 0, PB_F16 = 1, PB_U8 = 2 } pb_dtype;
 
 /* Outer boundary of the three reblurring convolutions on the replicate-padded domain:
  * PB_WRAP == reference method='fft'  (circular, deblurring.py:141-169, filters.py:31-35)
@@ -129,6 +133,11 @@ int pb_memcpy_d2h(pb_ctx *ctx, void *dst, const void *src, size_t bytes);   /* s
 int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype,
                       int B, int C, int H, int W, const pb_options *opt,
                       pb_blur_info *host_info);
+
+/* (H,W,C) interleaved bytes <-> (C,H,W) planar bytes for B images, the layouts either side of
+ * utils.to_tensor / utils.to_array (utils.py:8-31) when the pixels stay uint8 on the device.  */
+int pb_u8_deinterleave(pb_ctx *ctx, const unsigned char *hwc, unsigned char *chw, int B, int C, int H, int W);
+int pb_u8_interleave(pb_ctx *ctx, const unsigned char *chw, unsigned char *hwc, int B, int C, int H, int W);
 
 /* ---- stage entry points (each is also what the pipeline calls) ----------------------- */
 

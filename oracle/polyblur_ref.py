@@ -549,6 +549,30 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
     return (out, infos) if return_info else out
 
 
+# --------------------------------------------------------------------------------------------
+# 8-bit file edge of the CLI flow (main.py:80-82,146).  The conversions live in scikit-image
+# (requirements.txt:4 pins 0.19.2), which is absent here and from /root/reference, so they are
+# restated from its published algorithm (skimage/util/dtype.py `_convert`): unsigned -> float32 is
+# `np.multiply(image, 1. / 255, dtype=np.float32)`; float -> uint8 is `np.multiply(image, 255)`,
+# `np.rint`, `np.clip(0, 255)`, cast.  Parity of this edge is UNPINNED against scikit-image itself.
+# --------------------------------------------------------------------------------------------
+def img_as_float32_from_ubyte(img: np.ndarray) -> np.ndarray:
+    assert img.dtype == np.uint8
+    return np.multiply(img, 1.0 / 255, dtype=np.float32)
+
+
+def img_as_ubyte_from_float(img: np.ndarray) -> np.ndarray:
+    out = np.multiply(np.asarray(img, np.float32), 255, dtype=np.float32)
+    np.rint(out, out=out)
+    np.clip(out, 0, 255, out=out)
+    return out.astype(np.uint8)
+
+
+def polyblur_deblurring_uint8(img: np.ndarray, **kwargs) -> np.ndarray:
+    """main.py:80-82,146: uint8 (H,W)/(H,W,C) image -> float32 -> polyblur_deblurring -> uint8."""
+    return img_as_ubyte_from_float(polyblur_deblurring(img_as_float32_from_ubyte(img), **kwargs))
+
+
 def kaiser_window_periodic(n: int, beta: float = 5.0) -> np.ndarray:
     """torch.kaiser_window(n, periodic=True, beta=5) (deblurring.py:352)."""
     if n == 1:

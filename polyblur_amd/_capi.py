@@ -16,7 +16,7 @@ PB_KSIZE = 25
 PB_MAX_ANGLES = 13
 PB_MAX_INTERP = 64
 
-PB_F32, PB_F16 = 0, 1
+PB_F32, PB_F16, PB_U8 = 0, 1, 2
 PB_WRAP, PB_ZERO = 0, 1
 PB_PREFILTER_NONE, PB_PREFILTER_BILATERAL, PB_PREFILTER_DOMAIN_TRANSFORM = 0, 1, 2
 PB_SUPPORT_FULL, PB_SUPPORT_ADAPTIVE = 0, 1
@@ -30,7 +30,7 @@ SYMBOLS = [
     "pb_polyblur_batch", "pb_estimate_blur", "pb_make_kernels", "pb_set_kernels", "pb_fourier_gradients",
     "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
-    "pb_overlap_add",
+    "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other"]
 
@@ -109,6 +109,8 @@ def load_library():
             "pb_memcpy_h2d": (ci, [vp, vp, vp, sz]),
             "pb_memcpy_d2h": (ci, [vp, vp, vp, sz]),
             "pb_polyblur_batch": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), vp]),
+            "pb_u8_deinterleave": (ci, [vp, vp, vp, ci, ci, ci, ci]),
+            "pb_u8_interleave": (ci, [vp, vp, vp, ci, ci, ci, ci]),
             "pb_estimate_blur": (ci, [vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), vp]),
             "pb_make_kernels": (ci, [vp, ci, fp, fp, fp, ci, vp]),
             "pb_set_kernels": (ci, [vp, ci, fp, ci, vp]),

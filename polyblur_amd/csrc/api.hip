@@ -15,6 +15,7 @@ int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int
 int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype, float *out, int B, int C, int H, int W,
                       float sigma_s, float sigma_r, int num_iterations);
 int pb_convert_from_float(pb_ctx *ctx, const float *in, void *out, int dtype, long n);
+int pb_u8_layout(pb_ctx *ctx, const unsigned char *in, unsigned char *out, int B, int C, int H, int W, int to_planar);
 int pb_convert_to_float(pb_ctx *ctx, const void *in, int dtype, float *out, long n);
 int pb_extract_patches_impl(pb_ctx *ctx, const void *img, void *patches, int dtype, int B, int C, int H, int W, int ph, int pw,
                             int step_h, int step_w, int n_j, int pad_top, int pad_left, int first, int count);
@@ -51,7 +52,7 @@ void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes) {
     return b.p;
 }
 
-static size_t dsize(int dtype) { return dtype == PB_F16 ? 2 : 4; }
+static size_t dsize(int dtype) { return dtype == PB_F16 ? 2 : (dtype == PB_U8 ? 1 : 4); }
 static int pitch4(int w) { return (w + 3) & ~3; }
 
 extern "C" {
@@ -277,9 +278,10 @@ int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtyp
     return pb_halo_apply(ctx, src, src_dtype, g.W, g.HW, y, g0x, g0y, ox, nM, dst, dst_dtype, g.P, g.H, g.W, final_clamp);
 }
 
-int check_shape(pb_ctx *ctx, int dtype, int B, int C, int H, int W) {
+int check_shape(pb_ctx *ctx, int dtype, int B, int C, int H, int W, int allow_u8 = 0) {
     if (!ctx) return PB_ERR_BADARG;
-    if (dtype != PB_F32 && dtype != PB_F16) return pb_fail(ctx, PB_ERR_BADARG, "dtype must be PB_F32 or PB_F16");
+    if (dtype != PB_F32 && dtype != PB_F16 && !(allow_u8 && dtype == PB_U8))
+        return pb_fail(ctx, PB_ERR_BADARG, allow_u8 ? "dtype must be PB_F32, PB_F16 or PB_U8" : "dtype must be PB_F32 or PB_F16");
     if (B < 1 || C < 1 || H < 2 || W < 2) return pb_fail(ctx, PB_ERR_BADARG, "bad shape (%d,%d,%d,%d)", B, C, H, W);
     return PB_OK;
 }
@@ -290,7 +292,7 @@ extern "C" {
 
 int pb_estimate_blur(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, const pb_options *opt,
                      pb_blur_info *dev_info) {
-    int rc = check_shape(ctx, dtype, B, C, H, W);
+    int rc = check_shape(ctx, dtype, B, C, H, W, 1);
     if (rc) return rc;
     if (!in || !opt || !dev_info) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
     PB_HIP(hipSetDevice(ctx->device));
@@ -422,7 +424,7 @@ int pb_bilateral5(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int 
 // ---------------------------------------------------------------------------------------------
 int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
                       const pb_options *opt, pb_blur_info *host_info) {
-    int rc = check_shape(ctx, dtype, B, C, H, W);
+    int rc = check_shape(ctx, dtype, B, C, H, W, 1);
     if (rc) return rc;
     if (!in || !out || !opt) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
     if (in == out) return pb_fail(ctx, PB_ERR_BADARG, "out may not alias in");
@@ -436,12 +438,31 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         PB_HIP(hipMemcpyAsync(out, in, dsize(dtype) * n, hipMemcpyDeviceToDevice, ctx->stream));
         return PB_OK;
     }
+    if (dtype == PB_U8 && (opt->remove_halo || opt->prefilter != PB_PREFILTER_NONE)) {
+        // halo masking and the prefilters read the current image from several more kernels: those options run on
+        // an fp32 copy, the conversions at either end being the same img_as_float32 / img_as_ubyte
+        float *in32 = static_cast<float *>(pb_scratch(ctx, "pipe.u8in", sizeof(float) * n));
+        float *out32 = static_cast<float *>(pb_scratch(ctx, "pipe.u8out", sizeof(float) * n));
+        if (!in32 || !out32) return PB_ERR_NOMEM;
+        rc = pb_convert_to_float(ctx, in, PB_U8, in32, n);
+        if (rc) return rc;
+        rc = pb_polyblur_batch(ctx, in32, out32, PB_F32, B, C, H, W, opt, host_info);
+        if (rc) return rc;
+        return pb_convert_from_float(ctx, out32, out, PB_U8, n);
+    }
     pb_blur_info *infos = static_cast<pb_blur_info *>(pb_scratch(ctx, "pipe.info", sizeof(pb_blur_info) * (size_t)n_iter * B));
     if (!infos) return PB_ERR_NOMEM;
-    void *tmpimg = nullptr;
+    // images between iterations: of `dtype` for float I/O (alternating between out and one scratch image), fp32 for
+    // 8-bit I/O (rounding to 8 bits happens once, in the last store -- main.py:146)
+    const int work = dtype == PB_U8 ? PB_F32 : dtype;
+    void *tmpimg = nullptr, *tmpimg2 = nullptr;
     if (n_iter > 1) {
-        tmpimg = pb_scratch(ctx, "pipe.img", dsize(dtype) * n);
+        tmpimg = pb_scratch(ctx, "pipe.img", dsize(work) * n);
         if (!tmpimg) return PB_ERR_NOMEM;
+    }
+    if (n_iter > 2 && dtype == PB_U8) {
+        tmpimg2 = pb_scratch(ctx, "pipe.img2", dsize(work) * n);
+        if (!tmpimg2) return PB_ERR_NOMEM;
     }
     // gradients of the ORIGINAL image, used by halo masking in every iteration (deblurring.py:61,83)
     float *g0x = nullptr, *g0y = nullptr, *nM = nullptr;
@@ -474,11 +495,13 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     for (int it = 0; it < n_iter; ++it) {
         // the last iteration must land in `out`; alternate between out and tmpimg before that
         void *dst = ((n_iter - 1 - it) % 2 == 0) ? out : tmpimg;
+        if (dtype == PB_U8 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
+        const int cur_dtype = it == 0 ? dtype : work, dst_dtype = it == n_iter - 1 ? dtype : work;
         pb_blur_info *info = infos + (size_t)it * B;
-        rc = pb_estimate_impl(ctx, cur, dtype, B, C, H, W, opt, info);
+        rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
         if (rc) return rc;
         if (opt->prefilter == PB_PREFILTER_NONE) {
-            rc = inverse_filter(ctx, g, cur, dtype, dst, dtype, info, opt->alpha, opt->beta, opt->boundary,
+            rc = inverse_filter(ctx, g, cur, cur_dtype, dst, dst_dtype, info, opt->alpha, opt->beta, opt->boundary,
                                 opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1, force_full);
             if (rc) return rc;
         } else {
@@ -500,6 +523,18 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         PB_HIP(hipStreamSynchronize(ctx->stream));
     }
     return PB_OK;
+}
+
+int pb_u8_deinterleave(pb_ctx *ctx, const unsigned char *hwc, unsigned char *chw, int B, int C, int H, int W) {
+    if (!ctx || !hwc || !chw || hwc == chw || B < 1 || C < 1 || H < 1 || W < 1) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_u8_layout(ctx, hwc, chw, B, C, H, W, 1);
+}
+
+int pb_u8_interleave(pb_ctx *ctx, const unsigned char *chw, unsigned char *hwc, int B, int C, int H, int W) {
+    if (!ctx || !hwc || !chw || hwc == chw || B < 1 || C < 1 || H < 1 || W < 1) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_u8_layout(ctx, chw, hwc, B, C, H, W, 0);
 }
 
 int pb_extract_patches(pb_ctx *ctx, const void *img, void *patches, int dtype, int B, int C, int H, int W, int ph, int pw,

@@ -138,7 +138,18 @@ int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support,
 template <typename T> __device__ __forceinline__ float pb_ld(const T *p);
 template <> __device__ __forceinline__ float pb_ld<float>(const float *p) { return *p; }
 template <> __device__ __forceinline__ float pb_ld<__half>(const __half *p) { return __half2float(*p); }
+// (the conversions are never contracted into a neighbouring FMA, so the fused edge computes exactly what the
+// float pipeline computes between host-side conversions)
+// 8-bit pixels: img_as_float32 on load, img_as_ubyte on store (skimage 0.19.2 util/dtype.py _convert)
+__device__ __forceinline__ float pb_from_ubyte(unsigned u) {
+    float r = (float)u * (1.0f / 255.0f);
+    asm volatile("" : "+v"(r));          // keeps the product from being contracted into a neighbouring FMA
+    return r;
+}
+template <> __device__ __forceinline__ float pb_ld<unsigned char>(const unsigned char *p) { return pb_from_ubyte(*p); }
 template <typename T> __device__ __forceinline__ void pb_st(T *p, float v);
+__device__ __forceinline__ unsigned pb_to_ubyte(float v) { return (unsigned)__float2int_rn(fminf(fmaxf(__fmul_rn(v, 255.f), 0.f), 255.f)); }
+template <> __device__ __forceinline__ void pb_st<unsigned char>(unsigned char *p, float v) { *p = (unsigned char)pb_to_ubyte(v); }
 template <> __device__ __forceinline__ void pb_st<float>(float *p, float v) { *p = v; }
 template <> __device__ __forceinline__ void pb_st<__half>(__half *p, float v) { *p = __float2half_rn(v); }
 

@@ -337,7 +337,9 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
         sep_mode = (e && e[0] == 's') ? 2 : ((e && e[0] == 'd') ? 0 : 1);
     }
     int sep_in_tile = 1;
-    if (sep_mode == 2) {
+    const bool bytes = p.in_dtype == PB_U8 || p.x_dtype == PB_U8 || p.out_dtype == PB_U8;   // tile kernel only
+    if (bytes) {
+    } else if (sep_mode == 2) {
         int rc = pb_launch_conv_stream(ctx, p);
         if (rc) return rc;
         sep_in_tile = 0;
@@ -346,14 +348,21 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
         if (rc) return rc;
         sep_in_tile = 0;
     }
-    const int key = p.in_dtype * 4 + p.x_dtype * 2 + p.out_dtype;
+    const int key = p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype;
+    typedef unsigned char u8;
     switch (key) {
         case 0: return launch_typed<float, float, float>(ctx, p, sep_in_tile);
         case 1: return launch_typed<float, float, __half>(ctx, p, sep_in_tile);
-        case 2: return launch_typed<float, __half, float>(ctx, p, sep_in_tile);
-        case 3: return launch_typed<float, __half, __half>(ctx, p, sep_in_tile);
-        case 6: return launch_typed<__half, __half, float>(ctx, p, sep_in_tile);
-        case 7: return launch_typed<__half, __half, __half>(ctx, p, sep_in_tile);
+        case 3: return launch_typed<float, __half, float>(ctx, p, sep_in_tile);
+        case 4: return launch_typed<float, __half, __half>(ctx, p, sep_in_tile);
+        case 12: return launch_typed<__half, __half, float>(ctx, p, sep_in_tile);
+        case 13: return launch_typed<__half, __half, __half>(ctx, p, sep_in_tile);
+        // 8-bit images: first pass of the first iteration, the later passes that still read the 8-bit x, and the
+        // store of the last pass (fp32 in between)
+        case 24: return launch_typed<u8, u8, float>(ctx, p, sep_in_tile);
+        case 6: return launch_typed<float, u8, float>(ctx, p, sep_in_tile);
+        case 8: return launch_typed<float, u8, u8>(ctx, p, sep_in_tile);
+        case 2: return launch_typed<float, float, u8>(ctx, p, sep_in_tile);
         default: return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: unsupported dtype combination %d", key);
     }
 }

@@ -51,7 +51,14 @@ template <> __device__ __forceinline__ float4 ld4<__half>(const __half *p) {
     const float2 fa = __half22float2(a), fb = __half22float2(b);
     return make_float4(fa.x, fa.y, fb.x, fb.y);
 }
+template <> __device__ __forceinline__ float4 ld4<unsigned char>(const unsigned char *p) {
+    const unsigned u = *reinterpret_cast<const unsigned *>(p);
+    return make_float4(pb_from_ubyte(u & 255u), pb_from_ubyte((u >> 8) & 255u), pb_from_ubyte((u >> 16) & 255u), pb_from_ubyte(u >> 24));
+}
 template <typename T> __device__ __forceinline__ void st4(T *p, float4 v);
+template <> __device__ __forceinline__ void st4<unsigned char>(unsigned char *p, float4 v) {
+    *reinterpret_cast<unsigned *>(p) = pb_to_ubyte(v.x) | (pb_to_ubyte(v.y) << 8) | (pb_to_ubyte(v.z) << 16) | (pb_to_ubyte(v.w) << 24);
+}
 template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 template <> __device__ __forceinline__ void st4<__half>(__half *p, float4 v) {
     const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);

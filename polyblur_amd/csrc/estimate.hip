@@ -200,6 +200,10 @@ template <> __device__ __forceinline__ float4 ld4e<__half>(const __half *p) {
     const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&u.x)), b = __half22float2(*reinterpret_cast<const __half2 *>(&u.y));
     return make_float4(a.x, a.y, b.x, b.y);
 }
+template <> __device__ __forceinline__ float4 ld4e<unsigned char>(const unsigned char *p) {
+    const unsigned u = *reinterpret_cast<const unsigned *>(p);
+    return make_float4(pb_from_ubyte(u & 255u), pb_from_ubyte((u >> 8) & 255u), pb_from_ubyte((u >> 16) & 255u), pb_from_ubyte(u >> 24));
+}
 
 // VEC: HW % 4 == 0, so every plane starts 16-byte aligned and the image is walked in float4 units.
 // CC: compile-time channel count (1 or 3; 0 = run-time C) so that all channel loads of a sample
@@ -895,7 +899,8 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                        static_cast<const T *>(in), gray, part, C, HW, bpi)
 #define PB_GRAY_C(T, V) do { if (C == 3) PB_GRAY(T, V, 3); else if (C == 1) PB_GRAY(T, V, 1); else PB_GRAY(T, V, 0); } while (0)
     if (dtype == PB_F32) { if (vec) PB_GRAY_C(float, true); else PB_GRAY_C(float, false); }
-    else { if (vec) PB_GRAY_C(__half, true); else PB_GRAY_C(__half, false); }
+    else if (dtype == PB_F16) { if (vec) PB_GRAY_C(__half, true); else PB_GRAY_C(__half, false); }
+    else { if (vec) PB_GRAY_C(unsigned char, true); else PB_GRAY_C(unsigned char, false); }
 #undef PB_GRAY_C
 #undef PB_GRAY
     hipLaunchKernelGGL(minmax_reduce_kernel, dim3(B), dim3(NT), 0, ctx->stream, part, mm, bpi);

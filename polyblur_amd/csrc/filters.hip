@@ -325,9 +325,35 @@ int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype,
     return PB_OK;
 }
 
+// (H,W,C) interleaved bytes <-> (C,H,W) planar bytes.  One thread per pixel: the interleaved side is touched
+// as C consecutive bytes per lane (a wavefront covers one contiguous 64*C-byte span), the planar side as
+// one byte per lane per plane.
+template <bool TO_PLANAR>
+__global__ void u8_layout_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, int C, long HW, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i - b * HW;
+        const long inter = (b * HW + p) * C, planar = b * C * HW + p;
+        for (int c = 0; c < C; ++c) {
+            if (TO_PLANAR) out[planar + c * HW] = in[inter + c];
+            else out[inter + c] = in[planar + c * HW];
+        }
+    }
+}
+
+int pb_u8_layout(pb_ctx *ctx, const unsigned char *in, unsigned char *out, int B, int C, int H, int W, int to_planar) {
+    const long HW = (long)H * W, total = (long)B * HW;
+    if (to_planar) hipLaunchKernelGGL(u8_layout_kernel<true>, dim3(grid_for(total)), dim3(NT), 0, ctx->stream, in, out, C, HW, total);
+    else hipLaunchKernelGGL(u8_layout_kernel<false>, dim3(grid_for(total)), dim3(NT), 0, ctx->stream, in, out, C, HW, total);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
 int pb_convert_to_float(pb_ctx *ctx, const void *in, int dtype, float *out, long n) {
     if (dtype == PB_F32) PB_HIP(hipMemcpyAsync(out, in, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
-    else {
+    else if (dtype == PB_U8) {
+        hipLaunchKernelGGL(to_float_kernel<unsigned char>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, static_cast<const unsigned char *>(in), out, n);
+        PB_LAUNCH_CHECK();
+    } else {
         hipLaunchKernelGGL(to_float_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, static_cast<const __half *>(in), out, n);
         PB_LAUNCH_CHECK();
     }
@@ -336,7 +362,10 @@ int pb_convert_to_float(pb_ctx *ctx, const void *in, int dtype, float *out, long
 
 int pb_convert_from_float(pb_ctx *ctx, const float *in, void *out, int dtype, long n) {
     if (dtype == PB_F32) PB_HIP(hipMemcpyAsync(out, in, sizeof(float) * n, hipMemcpyDeviceToDevice, ctx->stream));
-    else {
+    else if (dtype == PB_U8) {
+        hipLaunchKernelGGL(from_float_kernel<unsigned char>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, in, static_cast<unsigned char *>(out), n);
+        PB_LAUNCH_CHECK();
+    } else {
         hipLaunchKernelGGL(from_float_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, in, static_cast<__half *>(out), n);
         PB_LAUNCH_CHECK();
     }

@@ -138,6 +138,60 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
     return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
 
 
+def polyblur_deblurring_uint8(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_r=0.8, sigma_s=2.0, ker_size=25,
+                              q=0.0, n_angles=6, n_interpolated_angles=30, remove_halo=False, edgetaping=False,
+                              prefiltering=False, discard_saturation=False, multichannel_kernel=False, method='fft',
+                              verbose=False, *, support='full', prefilter='bilateral', return_info=False, device=None):
+    """8-bit images in, 8-bit images out: the reference CLI's
+    ``img_as_ubyte(polyblur_deblurring(img_as_float32(imread(...)), ...))`` (main.py:80-82,146) with both
+    conversions done inside the first / last device kernels (scikit-image 0.19.2 semantics:
+    ``v * float32(1/255)`` on load, ``clip(rint(v * 255), 0, 255)`` on store; fp32 in between).
+
+    ``numpy.ndarray`` uint8 (H,W) / (H,W,C) -> same shape uint8;  ``torch.Tensor`` uint8 (B,C,H,W) -> same."""
+    start = time()
+    if isinstance(img, np.ndarray):
+        if img.dtype != np.uint8:
+            raise TypeError("expected a uint8 image, got %s" % img.dtype)
+        if img.ndim == 2:
+            x = img[None, :, :, None]
+        elif img.ndim == 3:
+            x = img[None]
+        else:
+            raise ValueError("expected an (H,W) or (H,W,C) array, got shape %r" % (img.shape,))
+        opts = _build_options(x.shape[3], n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles,
+                              n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
+                              multichannel_kernel, method, support, prefilter)
+        eng = get_engine(0 if device is None else int(device))
+        res = eng.polyblur_u8_hwc(x, opts, want_info=return_info)
+        out, info = res if return_info else (res, None)
+        out = out.reshape(img.shape)
+    else:
+        if not _is_torch_tensor(img):
+            raise TypeError("img must be a numpy.ndarray or a torch.Tensor")
+        import torch
+        if img.dim() != 4 or img.dtype != torch.uint8:
+            raise TypeError("expected a (B,C,H,W) uint8 tensor")
+        opts = _build_options(img.shape[1], n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles,
+                              n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
+                              multichannel_kernel, method, support, prefilter)
+        if img.is_cuda:
+            dev = img.device.index if img.device.index is not None else torch.cuda.current_device()
+            eng = get_engine(dev)
+            xin = img.contiguous()
+            out = torch.empty_like(xin)
+            with torch.cuda.device(dev):
+                eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+                info = eng.polyblur_ptr(xin.data_ptr(), out.data_ptr(), capi.PB_U8, xin.shape, opts, want_info=return_info)
+        else:
+            eng = get_engine(0 if device is None else int(device))
+            res = eng.polyblur(img.detach().contiguous().numpy(), opts, want_info=return_info)
+            o, info = res if return_info else (res, None)
+            out = torch.from_numpy(o)
+    if verbose:
+        print('-- polyblur (hip, uint8): %1.5f s' % (time() - start))
+    return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
+
+
 def kaiser_window_periodic(n: int, beta: float = 5.0) -> np.ndarray:
     """torch.kaiser_window(n, periodic=True, beta) (deblurring.py:352): the symmetric window of
     length n+1 without its last sample."""

@@ -13,7 +13,7 @@ import numpy as np
 from . import _capi as capi
 from ._capi import PolyblurHipError
 
-_DT = {np.dtype(np.float32): capi.PB_F32, np.dtype(np.float16): capi.PB_F16}
+_DT = {np.dtype(np.float32): capi.PB_F32, np.dtype(np.float16): capi.PB_F16, np.dtype(np.uint8): capi.PB_U8}
 
 
 class DeviceBuffer:
@@ -132,6 +132,20 @@ class Engine:
         dout = self.buffer("np.out", x.nbytes)
         info = self.polyblur_ptr(din.ptr, dout.ptr, _DT[x.dtype], x.shape, opts, want_info)
         out = dout.download(x.shape, x.dtype)
+        return (out, info) if want_info else out
+
+    def polyblur_u8_hwc(self, imgs: np.ndarray, opts: capi.pb_options, want_info=False):
+        """(B,H,W,C) uint8 host images -> deblurred (B,H,W,C) uint8: the bytes go up as they are, are planarised,
+        deblurred (8-bit load / store fused into the first / last kernels) and re-interleaved on the device."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        B, H, W, Cc = imgs.shape
+        hwc = self.to_device("np.u8.hwc", imgs)
+        chw = self.buffer("np.u8.chw", imgs.nbytes)
+        res = self.buffer("np.u8.out", imgs.nbytes)
+        self._check(self.lib.pb_u8_deinterleave(self.ctx, hwc.ptr, chw.ptr, B, Cc, H, W))
+        info = self.polyblur_ptr(chw.ptr, res.ptr, capi.PB_U8, (B, Cc, H, W), opts, want_info)
+        self._check(self.lib.pb_u8_interleave(self.ctx, res.ptr, hwc.ptr, B, Cc, H, W))
+        out = hwc.download(imgs.shape, np.uint8)
         return (out, info) if want_info else out
 
     def info_buffer(self, name: str, B: int) -> DeviceBuffer:

@@ -469,6 +469,56 @@ def test_patch_decomposition(shape, ps, bs):
     assert torch.equal(got, got2)
 
 
+# ---------------------------------------------------------------------------------------------
+# 8-bit file edge (main.py:80-82,146): uint8 -> img_as_float32 -> polyblur -> img_as_ubyte, fused
+# ---------------------------------------------------------------------------------------------
+def _u8_image(c, h, w, seed):
+    x, _ = synthetic_blurry_batch(1, c, h, w, seed0=seed)
+    img = np.ascontiguousarray(ref.img_as_ubyte_from_float(np.moveaxis(x[0], 0, -1)))
+    return np.ascontiguousarray(img[..., 0]) if c == 1 else img
+
+
+@pytest.mark.parametrize("extra", [dict(n_iter=1), dict(n_iter=2), dict(n_iter=3), dict(n_iter=4, method="direct"),
+                                   dict(n_iter=3, edgetaping=True), dict(n_iter=2, remove_halo=True),
+                                   dict(n_iter=2, prefiltering=True), dict(n_iter=0)])
+@pytest.mark.parametrize("c,h,w", [(3, 120, 164), (1, 97, 131)])
+def test_uint8_edge(extra, c, h, w):
+    from polyblur_amd import polyblur_deblurring, polyblur_deblurring_uint8
+    img = _u8_image(c, h, w, seed=77)
+    got = polyblur_deblurring_uint8(img, **KW, **extra)
+    assert got.dtype == np.uint8 and got.shape == img.shape
+    # (i) the fused byte load / store computes exactly what the float pipeline computes between host conversions
+    via_float = ref.img_as_ubyte_from_float(polyblur_deblurring(ref.img_as_float32_from_ubyte(img), **KW, **extra))
+    assert np.array_equal(got, via_float)
+    # (ii) against the CPU restatement: a float difference of <= 2e-5 flips a rounding only next to a half level
+    want = ref.polyblur_deblurring_uint8(img, **KW, **extra)
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 2e-3, (int(d.max()), float(np.mean(d != 0)))
+
+
+def test_uint8_planar_tensor_and_layout(eng):
+    import torch
+    from polyblur_amd import polyblur_deblurring_uint8
+    imgs = np.stack([_u8_image(3, 90, 132, seed=s) for s in (5, 6)])                 # (B,H,W,C)
+    planar = torch.from_numpy(np.ascontiguousarray(np.moveaxis(imgs, -1, 1))).cuda()    # (B,C,H,W) uint8
+    out = polyblur_deblurring_uint8(planar, n_iter=3, **KW)
+    assert out.dtype == torch.uint8 and out.is_cuda and out.shape == planar.shape
+    for i in range(2):
+        one = polyblur_deblurring_uint8(imgs[i], n_iter=3, **KW)
+        assert np.array_equal(np.moveaxis(out[i].cpu().numpy(), 0, -1), one)
+    # interleave / de-interleave round trip through the C ABI
+    hwc = torch.from_numpy(imgs).cuda()
+    chw, back = torch.empty_like(planar), torch.empty_like(hwc)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng._check(eng.lib.pb_u8_deinterleave(eng.ctx, hwc.data_ptr(), chw.data_ptr(), 2, 3, 90, 132))
+    eng._check(eng.lib.pb_u8_interleave(eng.ctx, chw.data_ptr(), back.data_ptr(), 2, 3, 90, 132))
+    torch.cuda.synchronize()
+    assert torch.equal(chw, planar)
+    assert torch.equal(back, hwc)
+    with pytest.raises(TypeError):
+        polyblur_deblurring_uint8(imgs[0].astype(np.float32))
+
+
 @pytest.mark.parametrize("body", ["dma", "stream"])
 def test_alternative_rank1_bodies(body):
     """the two alternative rank-1 kernels (PB_SEP_BODY=dma|stream, read once per process) stay parity-green"""

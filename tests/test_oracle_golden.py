@@ -156,3 +156,16 @@ def test_pipeline_fp16_rounded_inputs(golden):
     out, infos = ref.polyblur_deblurring(g["x"], n_iter=3, return_info=True, **KW)
     check_iterations(g, "fft", infos, 3)
     assert maxabs(out, g["fft/out"]) < 3e-5
+
+
+def test_uint8_edge_conversions():
+    """skimage 0.19.2 `_convert` restated: multiply by float32(1/255); multiply by 255, rint (half to even), clip"""
+    u = np.arange(256, dtype=np.uint8)
+    f = ref.img_as_float32_from_ubyte(u)
+    assert f.dtype == np.float32 and f[0] == 0 and f[255] == np.float32(255) * np.float32(1.0 / 255)
+    assert np.array_equal(ref.img_as_ubyte_from_float(f), u)                       # round trip of every level
+    assert np.array_equal(ref.img_as_ubyte_from_float(np.array([0.5 / 255, 1.5 / 255, 2.5 / 255, -0.2, 1.7], np.float32)),
+                          np.array([0, 2, 2, 0, 255], np.uint8))
+    img = (np.random.default_rng(3).random((24, 31, 3)) * 255).astype(np.uint8)
+    out = ref.polyblur_deblurring_uint8(img, n_iter=1)
+    assert out.dtype == np.uint8 and out.shape == img.shape
