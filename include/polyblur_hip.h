@@ -57,7 +57,8 @@ typedef enum pb_dtype { PB_F32 = 0, PB_F16 = 1, PB_U8 = 2 } pb_dtype;
 typedef enum pb_boundary { PB_WRAP = 0, PB_ZERO = 1 } pb_boundary;
 
 typedef enum pb_prefilter { PB_PREFILTER_NONE = 0, PB_PREFILTER_BILATERAL = 1,
-                            PB_PREFILTER_DOMAIN_TRANSFORM = 2 } pb_prefilter;
+                            PB_PREFILTER_DOMAIN_TRANSFORM = 2,      /* recursive filter, N = 1  */
+                            PB_PREFILTER_NORMALIZED_CONVOLUTION = 3 /* NC variant,       N = 1  */ } pb_prefilter;
 
 /* Kernel-support policy: PB_SUPPORT_FULL evaluates every tap of the reference's 25x25 kernel
  * that is not exactly 0.0f (outer rows / columns whose taps all underflowed to zero are skipped,
@@ -184,6 +185,11 @@ int pb_halo_mask(pb_ctx *ctx, const float *x, const float *y, const float *grad0
  * joint may be NULL (filter guided by itself).                                           */
 int pb_dt_recursive_filter(pb_ctx *ctx, const void *in, const void *joint, void *out, int dtype,
                            int B, int C, int H, int W, float sigma_s, float sigma_r, int num_iterations);
+
+/* normalized_convolution (NC.cpp:143-204), the domain-transform variant built on box filters in the
+ * transformed domain; single-image semantics of the reference applied per image, any C.  H, W <= 8190. */
+int pb_dt_normalized_convolution(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
+                                 float sigma_s, float sigma_r, int num_iterations);
 
 /* filters.bilateral_filter (filters.py:107-148), 5x5, sigma_spatial=5, sigma_color=0.1. */
 int pb_bilateral5(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W);

@@ -481,6 +481,62 @@ def recursive_filter(I: np.ndarray, sigma_s: float = 60, sigma_r: float = 0.4,
     return out
 
 
+def _first_greater(pos_ext: np.ndarray, thr: np.ndarray) -> np.ndarray:
+    """First index j with pos_ext[j] > thr[k], per k (pos_ext ascending, last entry is the sentinel)."""
+    return np.searchsorted(pos_ext, thr, side="right")
+
+
+def _nc_box_rows(F: np.ndarray, ct: np.ndarray, box_radius) -> np.ndarray:
+    """One horizontal normalized-convolution box pass.  NC.cpp:50-139 with its per-image (B=1)
+    semantics applied to every image of the batch (the reference's `find` NC.cpp:10-47 returns the
+    wrong index for batch > 1); any channel count (the reference hard-codes 3, NC.cpp:128-130).
+    F: (B,C,H,W) float32, ct: (B,H,W) float32 transformed-domain positions."""
+    B, C, H, W = F.shape
+    r = F32(box_radius)
+    l_pos = (ct - r).astype(F32)                                           # :65-66
+    u_pos = (ct + r).astype(F32)
+    # torch.cumsum on CPU accumulates float32 inputs in double and rounds each prefix to float32
+    sat = np.zeros((B, C, H, W + 1), F32)                                  # :113-114
+    sat[..., 1:] = np.cumsum(F, axis=-1, dtype=np.float64).astype(F32)
+    out = np.empty_like(F)
+    for b in range(B):
+        for y in range(H):
+            pos_ext = np.concatenate([ct[b, y], np.asarray([65535.0], F32)])        # :83-84, 2^16 - 1 = "infinity"
+            li = _first_greater(pos_ext, l_pos[b, y])                                # :95-108
+            ui = _first_greater(pos_ext, u_pos[b, y])
+            den = ((ui - li).astype(np.int64).astype(F32) + F32(0.0001)).astype(F32)   # :134 (int64 + double scalar -> float32)
+            out[b, :, y] = (sat[b, :, y][:, ui] - sat[b, :, y][:, li]) / den            # :128-134
+    return out
+
+
+def normalized_convolution(I: np.ndarray, sigma_s: float = 60, sigma_r: float = 0.4,
+                           num_iterations: int = 3) -> np.ndarray:
+    """Domain-transform normalized convolution (Gastal & Oliveira NC), the variant the reference's author
+    recommends over RF for parallel hardware (RF.cpp:7-11).  NC.cpp:143-204."""
+    I = np.asarray(I, dtype=F32)
+    dx = np.abs(np.diff(I, axis=-1)).sum(axis=1, dtype=F32)               # :157-169
+    dy = np.abs(np.diff(I, axis=-2)).sum(axis=1, dtype=F32)
+    dx = np.pad(dx, [(0, 0), (0, 0), (1, 0)])
+    dy = np.pad(dy, [(0, 0), (1, 0), (0, 0)])
+    ratio = F32(F32(sigma_s) / F32(sigma_r))                               # float / float in C++  :173
+    dHdx = (F32(1) + ratio * dx).astype(F32)
+    dVdy = (F32(1) + ratio * dy).astype(F32)
+    ct_H = np.cumsum(dHdx, axis=2, dtype=np.float64).astype(F32)          # :177-178
+    ct_V = np.cumsum(dVdy, axis=1, dtype=np.float64).astype(F32)
+    ct_Vt = np.ascontiguousarray(ct_V.transpose(0, 2, 1))                  # :181
+    N = num_iterations
+    F = I.copy()
+    for i in range(N):
+        # C++ float arithmetic: sqrt/pow return double, the product is rounded to float on assignment  :194-197
+        sigma_i = F32(float(F32(sigma_s)) * math.sqrt(3) * math.pow(2, N - (i + 1)) / math.sqrt(math.pow(4, N) - 1))
+        radius = F32(math.sqrt(3) * float(sigma_i))
+        F = _nc_box_rows(F, ct_H, radius)                                  # :199
+        Ft = np.ascontiguousarray(F.transpose(0, 1, 3, 2))                 # :200
+        Ft = _nc_box_rows(Ft, ct_Vt, radius)                               # :202
+        F = np.ascontiguousarray(Ft.transpose(0, 1, 3, 2))                 # :203
+    return F
+
+
 def edge_aware_filtering(x: np.ndarray, sigma_s: float, sigma_r: float, prefilter: str = "bilateral"):
     """deblurring.py:99-110.  The reference's live path is the bilateral filter (:108);
     the domain-transform call is the commented-out line :107 and is what BASELINE's
@@ -489,6 +545,8 @@ def edge_aware_filtering(x: np.ndarray, sigma_s: float, sigma_r: float, prefilte
         smooth = bilateral_filter(x)
     elif prefilter == "domain_transform":
         smooth = recursive_filter(x, sigma_s=sigma_s, sigma_r=sigma_r, num_iterations=1)
+    elif prefilter == "normalized_convolution":
+        smooth = normalized_convolution(x, sigma_s=sigma_s, sigma_r=sigma_r, num_iterations=1)
     else:
         raise ValueError("unknown prefilter %r" % prefilter)
     return smooth, (x - smooth).astype(F32)

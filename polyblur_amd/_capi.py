@@ -18,7 +18,7 @@ PB_MAX_INTERP = 64
 
 PB_F32, PB_F16, PB_U8 = 0, 1, 2
 PB_WRAP, PB_ZERO = 0, 1
-PB_PREFILTER_NONE, PB_PREFILTER_BILATERAL, PB_PREFILTER_DOMAIN_TRANSFORM = 0, 1, 2
+PB_PREFILTER_NONE, PB_PREFILTER_BILATERAL, PB_PREFILTER_DOMAIN_TRANSFORM, PB_PREFILTER_NORMALIZED_CONVOLUTION = 0, 1, 2, 3
 PB_SUPPORT_FULL, PB_SUPPORT_ADAPTIVE = 0, 1
 
 STATUS = {0: "PB_OK", -1: "PB_ERR_BADARG", -2: "PB_ERR_UNSUPPORTED", -3: "PB_ERR_HIP", -4: "PB_ERR_NOMEM"}
@@ -30,7 +30,7 @@ SYMBOLS = [
     "pb_polyblur_batch", "pb_estimate_blur", "pb_make_kernels", "pb_set_kernels", "pb_fourier_gradients",
     "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
-    "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave",
+    "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other"]
 
@@ -120,6 +120,7 @@ def load_library():
             "pb_edgetaper": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, ci]),
             "pb_halo_mask": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci]),
             "pb_dt_recursive_filter": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, ci]),
+            "pb_dt_normalized_convolution": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, ci]),
             "pb_bilateral5": (ci, [vp, vp, vp, ci, ci, ci, ci, ci]),
             "pb_time_inner_loop": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, cf, cf, ci, ci, fp]),
             "pb_extract_patches": (ci, [vp, vp, vp] + [ci] * 15),

@@ -14,6 +14,8 @@ int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, const float *smoo
 int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int out_dtype, int P, int H, int W);
 int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype, float *out, int B, int C, int H, int W,
                       float sigma_s, float sigma_r, int num_iterations);
+int pb_nc_filter_impl(pb_ctx *ctx, const void *in, int dtype, float *out, int B, int C, int H, int W, float sigma_s,
+                      float sigma_r, int num_iterations);
 int pb_convert_from_float(pb_ctx *ctx, const float *in, void *out, int dtype, long n);
 int pb_u8_layout(pb_ctx *ctx, const unsigned char *in, unsigned char *out, int B, int C, int H, int W, int to_planar);
 int pb_convert_to_float(pb_ctx *ctx, const void *in, int dtype, float *out, long n);
@@ -411,6 +413,21 @@ int pb_dt_recursive_filter(pb_ctx *ctx, const void *in, const void *joint, void 
     return pb_convert_from_float(ctx, tmp, out, dtype, n);
 }
 
+int pb_dt_normalized_convolution(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
+                                 float sigma_s, float sigma_r, int num_iterations) {
+    int rc = check_shape(ctx, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!in || !out || num_iterations < 1 || !(sigma_r > 0.f)) return pb_fail(ctx, PB_ERR_BADARG, "bad argument");
+    PB_HIP(hipSetDevice(ctx->device));
+    const long n = (long)B * C * H * W;
+    if (dtype == PB_F32) return pb_nc_filter_impl(ctx, in, dtype, static_cast<float *>(out), B, C, H, W, sigma_s, sigma_r, num_iterations);
+    float *tmp = static_cast<float *>(pb_scratch(ctx, "dt.out", sizeof(float) * n));
+    if (!tmp) return PB_ERR_NOMEM;
+    rc = pb_nc_filter_impl(ctx, in, dtype, tmp, B, C, H, W, sigma_s, sigma_r, num_iterations);
+    if (rc) return rc;
+    return pb_convert_from_float(ctx, tmp, out, dtype, n);
+}
+
 int pb_bilateral5(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W) {
     int rc = check_shape(ctx, dtype, B, C, H, W);
     if (rc) return rc;
@@ -507,6 +524,8 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         } else {
             if (opt->prefilter == PB_PREFILTER_BILATERAL)
                 rc = pb_bilateral5_impl(ctx, cur, dtype, smooth, PB_F32, g.P, H, W);
+            else if (opt->prefilter == PB_PREFILTER_NORMALIZED_CONVOLUTION)
+                rc = pb_nc_filter_impl(ctx, cur, dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
             else
                 rc = pb_dt_filter_impl(ctx, cur, nullptr, dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
             if (rc) return rc;

@@ -33,7 +33,8 @@ from .engine import get_engine
 
 _METHODS = {"fft": capi.PB_WRAP, "direct": capi.PB_ZERO, "direct_separable": capi.PB_ZERO}
 _SUPPORT = {"full": capi.PB_SUPPORT_FULL, "adaptive": capi.PB_SUPPORT_ADAPTIVE}
-_PREFILTER = {"bilateral": capi.PB_PREFILTER_BILATERAL, "domain_transform": capi.PB_PREFILTER_DOMAIN_TRANSFORM}
+_PREFILTER = {"bilateral": capi.PB_PREFILTER_BILATERAL, "domain_transform": capi.PB_PREFILTER_DOMAIN_TRANSFORM,
+              "normalized_convolution": capi.PB_PREFILTER_NORMALIZED_CONVOLUTION}
 
 
 def _is_torch_tensor(x) -> bool:
@@ -48,7 +49,7 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
     if support not in _SUPPORT:
         raise ValueError("support must be 'full' or 'adaptive'")
     if prefilter not in _PREFILTER:
-        raise ValueError("prefilter must be 'bilateral' or 'domain_transform'")
+        raise ValueError("prefilter must be 'bilateral', 'domain_transform' or 'normalized_convolution'")
     if ker_size != capi.PB_KSIZE:
         raise NotImplementedError("only ker_size=25 (the reference default) is built")
     if not (0 <= q < 0.5):

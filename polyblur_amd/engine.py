@@ -249,6 +249,16 @@ class Engine:
         self.synchronize()
         return dout.download(x.shape, x.dtype)
 
+    def dt_normalized_convolution(self, x: np.ndarray, sigma_s=60.0, sigma_r=0.4, num_iterations=3) -> np.ndarray:
+        x = np.ascontiguousarray(x)
+        B, Cc, H, W = x.shape
+        din = self.to_device("np.in", x)
+        dout = self.buffer("np.out", x.nbytes)
+        self._check(self.lib.pb_dt_normalized_convolution(self.ctx, din.ptr, dout.ptr, _DT[x.dtype], B, Cc, H, W,
+                                                          float(sigma_s), float(sigma_r), int(num_iterations)))
+        self.synchronize()
+        return dout.download(x.shape, x.dtype)
+
     def bilateral5(self, x: np.ndarray) -> np.ndarray:
         x = np.ascontiguousarray(x)
         B, Cc, H, W = x.shape

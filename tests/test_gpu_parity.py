@@ -174,6 +174,47 @@ def test_edge_aware_filters(eng, golden, name):
     assert maxabs(eng.dt_recursive_filter(g["x"], 60.0, 0.4, 3), g["rf_n3"]) < 1e-5
 
 
+@pytest.mark.parametrize("case", list("abcde"))
+def test_normalized_convolution_goldens(eng, golden, case):
+    """NC.cpp compiled from the reference's source (tests/golden/make_golden_native.py) vs the HIP kernels"""
+    g = golden("native_dt.npz")
+    ss, sr, n = g["p_" + case]
+    got = eng.dt_normalized_convolution(g["x_" + case], ss, sr, int(n))
+    assert maxabs(got, g["nc_" + case]) < 1e-6, maxabs(got, g["nc_" + case])
+
+
+@pytest.mark.parametrize("shape,ss,sr,n", [((2, 3, 130, 250), 2.0, 0.8, 1), ((1, 1, 77, 301), 20.0, 0.3, 3),
+                                           ((1, 4, 64, 1000), 5.0, 0.2, 2), ((1, 3, 1080, 1920), 2.0, 0.8, 1)])
+def test_normalized_convolution_sizes(eng, shape, ss, sr, n):
+    """batches (per-image semantics), C != 3, long rows; fp16 I/O"""
+    x, _ = synthetic_blurry_batch(shape[0], shape[1], shape[2], shape[3], seed0=31)
+    want = ref.normalized_convolution(x, ss, sr, n)
+    got = eng.dt_normalized_convolution(x, ss, sr, n)
+    # box limits are exact float comparisons: a last-bit difference in a prefix sum can move one limit by a sample
+    d = np.abs(got - want)
+    assert np.mean(d > 1e-5) < 1e-4 and d.max() < 5e-2, (float(d.max()), float(np.mean(d > 1e-5)))
+    if shape[2] <= 130:
+        xh = x.astype(np.float16)
+        goth = eng.dt_normalized_convolution(xh, ss, sr, n)
+        wanth = ref.normalized_convolution(xh.astype(np.float32), ss, sr, n)
+        assert goth.dtype == np.float16 and np.mean(np.abs(goth.astype(np.float32) - wanth) > 2e-3) < 1e-3
+
+
+def test_pipeline_with_normalized_convolution_prefilter():
+    from polyblur_amd import polyblur_deblurring
+    x, _ = synthetic_blurry_batch(2, 3, 96, 140, seed0=41)
+    kw = dict(n_iter=2, prefiltering=True, sigma_s=2.0, sigma_r=0.8, **KW)
+    import torch
+    got = polyblur_deblurring(torch.from_numpy(x), prefilter="normalized_convolution", **kw).numpy()
+    want = ref.polyblur_deblurring(x, prefilter="normalized_convolution", **kw)
+    # the NC filter is discontinuous in its input (box limits are comparisons): from the second iteration on,
+    # rounding-level differences of the first move a limit by one sample here and there
+    assert np.mean(np.abs(got - want) > 2e-5) < 2e-2 and maxabs(got, want) < 5e-2
+    one = polyblur_deblurring(torch.from_numpy(x), prefilter="normalized_convolution", **dict(kw, n_iter=1)).numpy()
+    want1 = ref.polyblur_deblurring(x, prefilter="normalized_convolution", **dict(kw, n_iter=1))
+    assert np.mean(np.abs(one - want1) > 2e-5) < 1e-4
+
+
 def test_dt_filter_joint_and_wide(eng):
     rng = np.random.default_rng(5)
     x = rng.random((2, 3, 37, 203), dtype=np.float32)          # W spans several 64-wide scan chunks, ragged tail

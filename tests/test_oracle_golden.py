@@ -169,3 +169,13 @@ def test_uint8_edge_conversions():
     img = (np.random.default_rng(3).random((24, 31, 3)) * 255).astype(np.uint8)
     out = ref.polyblur_deblurring_uint8(img, n_iter=1)
     assert out.dtype == np.uint8 and out.shape == img.shape
+
+
+@pytest.mark.parametrize("case", list("abcde"))
+def test_native_domain_transform_goldens(golden, case):
+    """NC.cpp / RF.cpp (the reference's native sources, compiled by oracle/build_ref_native.py) vs the restatements"""
+    g = golden("native_dt.npz")
+    ss, sr, n = g["p_" + case]
+    x = g["x_" + case]
+    assert np.array_equal(ref.normalized_convolution(x, ss, sr, int(n)), g["nc_" + case])
+    assert np.max(np.abs(ref.recursive_filter(x, ss, sr, int(n)) - g["rf_" + case])) < 2e-6
