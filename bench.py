@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-context", action="store_true",
+                    help="skip the labelled side measurements, so that a profiler sees only the headline workload's kernels")
     ap.add_argument("--cpu-sample", default="2160x3840", help="HxW crop the CPU baseline is timed on")
     return ap.parse_args()
 
@@ -169,30 +171,31 @@ def main():
         return dict(ms=round(ms, 4), achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 4),
                     mp_per_s=round(B * H * W / 1e6 / (ms * 1e-3), 1))
 
-    side = {
+    side = {} if args.no_context else {
         # the north-star figure: n_iter's separable-conv inner loop, rank-1 kernels (theta forced to 0)
         "inner_loop_rank1_full_support": inner_loop(0.0, 2.0, 1.0, capi.PB_SUPPORT_FULL),
         "inner_loop_rank1_adaptive_sigma1": inner_loop(0.0, 1.0, 0.6, capi.PB_SUPPORT_ADAPTIVE),
         "inner_loop_general_full_support": inner_loop(30.0, 2.0, 1.0, capi.PB_SUPPORT_FULL),
         "inner_loop_general_adaptive_sigma1": inner_loop(30.0, 1.0, 0.6, capi.PB_SUPPORT_ADAPTIVE),
     }
-    # adaptive-support end-to-end (same results to fp32 rounding), labelled
-    for _ in range(2):
-        step("adaptive")
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step("adaptive")
-    torch.cuda.synchronize(dev)
-    ms_ad = 1e3 * (time.perf_counter() - t0) / args.steps
-    side["end_to_end_adaptive_support"] = dict(ms_per_step=round(ms_ad, 4), mp_per_s=round(B * H * W / 1e6 / (ms_ad * 1e-3), 1))
-    # host buffers in and out (PCIe-inclusive; never the headline value)
-    xn = x_np.astype(np.float32 if s == 4 else np.float16)
-    polyblur_deblurring(torch.from_numpy(xn), **KW)
-    t0 = time.perf_counter()
-    polyblur_deblurring(torch.from_numpy(xn), **KW)
-    ms_pcie = 1e3 * (time.perf_counter() - t0)
-    side["end_to_end_host_buffers_pcie"] = dict(ms_per_step=round(ms_pcie, 3), mp_per_s=round(B * H * W / 1e6 / (ms_pcie * 1e-3), 1))
+    if not args.no_context:
+        # adaptive-support end-to-end (same results to fp32 rounding), labelled
+        for _ in range(2):
+            step("adaptive")
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step("adaptive")
+        torch.cuda.synchronize(dev)
+        ms_ad = 1e3 * (time.perf_counter() - t0) / args.steps
+        side["end_to_end_adaptive_support"] = dict(ms_per_step=round(ms_ad, 4), mp_per_s=round(B * H * W / 1e6 / (ms_ad * 1e-3), 1))
+        # host buffers in and out (PCIe-inclusive; never the headline value)
+        xn = x_np.astype(np.float32 if s == 4 else np.float16)
+        polyblur_deblurring(torch.from_numpy(xn), **KW)
+        t0 = time.perf_counter()
+        polyblur_deblurring(torch.from_numpy(xn), **KW)
+        ms_pcie = 1e3 * (time.perf_counter() - t0)
+        side["end_to_end_host_buffers_pcie"] = dict(ms_per_step=round(ms_pcie, 3), mp_per_s=round(B * H * W / 1e6 / (ms_pcie * 1e-3), 1))
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample ---------
     cpu = None
