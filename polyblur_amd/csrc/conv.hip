@@ -37,6 +37,26 @@ namespace {
 // general kernels: workgroup tile body
 // =============================================================================================
 
+// Four consecutive padded columns px..px+3 of source row iy (iy < 0: the row reads as zero): one 16-byte load
+// where the columns map to themselves and are aligned, four mapped loads in the pad / wrap region.
+template <typename T>
+__device__ __forceinline__ float4 load_chunk_mapped(const T *plane, int pitch, int iy, int px, int W, int kind, int boundary,
+                                                    bool aligned) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy < 0) return v;
+    const T *row = plane + (long)iy * pitch;
+    const int shift = (kind == SRC_VIRTUAL) ? PB_PAD : 0;
+    const int lo = shift, hi = (kind == SRC_VIRTUAL) ? PB_PAD + W : W + 2 * PB_PAD;
+    if (aligned && px >= lo && px + 3 < hi) return ld4<T>(row + (px - shift));
+    const int i0 = map_axis(px, W, kind, boundary), i1 = map_axis(px + 1, W, kind, boundary);
+    const int i2 = map_axis(px + 2, W, kind, boundary), i3 = map_axis(px + 3, W, kind, boundary);
+    if (i0 >= 0) v.x = pb_ld(row + i0);
+    if (i1 >= 0) v.y = pb_ld(row + i1);
+    if (i2 >= 0) v.z = pb_ld(row + i2);
+    if (i3 >= 0) v.w = pb_ld(row + i3);
+    return v;
+}
+
 template <typename T, int LH, int LW, int LP>
 __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
                                           int boundary) {
@@ -67,24 +87,23 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
             if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
         }
     } else {
-        // border tile: every sample mapped (wrap / zero / clamp); 8 independent loads in flight per thread
-        for (int base = 0; base < LH * LW; base += 8 * NT) {
-            float v[8];
+        // border tile: rows mapped (wrap / zero / clamp) once per chunk, columns per chunk or per sample
+        const bool aligned = ((pitch | sx0) & 3) == 0;
+        constexpr int C4 = LW / 4;
+        constexpr int NLD = (LH * C4 + NT - 1) / NT;
+        float4 buf[NLD];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + u * NT + tid;
-                v[u] = 0.f;
-                if (e < LH * LW) {
-                    const int r = e / LW, c = e - r * LW;
-                    const int iy = map_axis(py0 + r, H, kind, boundary), ix = map_axis(px0 + c, W, kind, boundary);
-                    if (iy >= 0 && ix >= 0) v[u] = pb_ld(plane + (long)iy * pitch + ix);
-                }
-            }
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int r = e / C4, c = e - r * C4;
+            if (e < LH * C4)
+                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r, H, kind, boundary), px0 + 4 * c, W, kind, boundary, aligned);
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + u * NT + tid;
-                if (e < LH * LW) { const int r = e / LW, c = e - r * LW; s[r * LP + c] = v[u]; }
-            }
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int r = e / C4, c = e - r * C4;
+            if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
         }
     }
 }
@@ -123,11 +142,22 @@ __device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kin
             if (r < nrows) *reinterpret_cast<float4 *>(s + (r0 + r) * LP + 4 * c) = buf[k];
         }
     } else {
-#pragma unroll 1
-        for (int e = lane; e < nrows * LW; e += 64) {
-            const int r = e / LW, c = e - r * LW;
-            const int iy = map_axis(py0 + r0 + r, H, kind, boundary), ix = map_axis(px0 + c, W, kind, boundary);
-            s[(r0 + r) * LP + c] = (iy >= 0 && ix >= 0) ? pb_ld(plane + (long)iy * pitch + ix) : 0.f;
+        const bool aligned = ((pitch | sx0) & 3) == 0;
+        constexpr int NLD = (RPW * C4 + 63) / 64;
+        float4 buf[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows)
+                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r0 + r, H, kind, boundary), px0 + 4 * c, W, kind,
+                                              boundary, aligned);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows) *reinterpret_cast<float4 *>(s + (r0 + r) * LP + 4 * c) = buf[k];
         }
     }
 }

@@ -75,28 +75,33 @@ __device__ __forceinline__ OutRegion out_region(const ConvPass &a) {
     return OutRegion{0, a.H + 2 * PB_PAD, 0, a.W + 2 * PB_PAD};
 }
 
-// Epilogue + store of 4 horizontally adjacent outputs at padded (py, px..px+3).
-template <typename TX, typename TOut>
-__device__ __forceinline__ void finish4(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl,
-                                        const OutRegion &rg, int py, int px, float4 acc) {
-    if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi) return;
+// The x operand of 4 horizontally adjacent outputs at padded (py, px..px+3): rows and columns of a virtual
+// (un-padded) source clamp (replicate pad); a 16-byte load when the four columns are contiguous in the source.
+template <typename TX>
+__device__ __forceinline__ float4 load_x4(const ConvPass &a, const TX *xpl, int py, int px) {
     const int H = a.H, W = a.W;
-    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
-    float av[4] = {acc.x, acc.y, acc.z, acc.w};
-    float xv[4];
-    const bool full = px >= rg.x_lo && px + 3 < rg.x_hi;
-    // x operand: rows clamp uniformly; a 16-byte load when the four columns are contiguous in the source
     const int xr = (a.x_kind == SRC_VIRTUAL) ? min(max(py - PB_PAD, 0), H - 1) : py;
     const int xc0 = (a.x_kind == SRC_VIRTUAL) ? px - PB_PAD : px;
-    const int xcmax = (a.x_kind == SRC_VIRTUAL) ? W : Wp;
+    const int xcmax = (a.x_kind == SRC_VIRTUAL) ? W : W + 2 * PB_PAD;
     const TX *xrow = xpl + (long)xr * a.x_pitch;
-    if (full && xc0 >= 0 && xc0 + 3 < xcmax && ((a.x_pitch | xc0) & 3) == 0) {
-        const float4 t = ld4<TX>(xrow + xc0);
-        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = pb_ld(xrow + min(max(xc0 + i, 0), xcmax - 1));
-    }
+    if (xc0 >= 0 && xc0 + 3 < xcmax && ((a.x_pitch | xc0) & 3) == 0) return ld4<TX>(xrow + xc0);
+    float4 t;
+    t.x = pb_ld(xrow + min(max(xc0, 0), xcmax - 1));
+    t.y = pb_ld(xrow + min(max(xc0 + 1, 0), xcmax - 1));
+    t.z = pb_ld(xrow + min(max(xc0 + 2, 0), xcmax - 1));
+    t.w = pb_ld(xrow + min(max(xc0 + 3, 0), xcmax - 1));
+    return t;
+}
+
+// Epilogue + store of 4 horizontally adjacent outputs at padded (py, px..px+3); xq = their x operand.
+template <typename TOut>
+__device__ __forceinline__ void finish4(const ConvPass &a, const pb_blur_info *info, TOut *opl, const OutRegion &rg, int py,
+                                        int px, float4 acc, float4 xq) {
+    if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi) return;
+    const int Hp = a.H + 2 * PB_PAD, Wp = a.W + 2 * PB_PAD;
+    float av[4] = {acc.x, acc.y, acc.z, acc.w};
+    const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+    const bool full = px >= rg.x_lo && px + 3 < rg.x_hi;
     float ty = 1.f;
     if (a.epilogue == EPI_TAPER) ty = taper_weight(info->acorr_y, py, Hp);
 #pragma unroll

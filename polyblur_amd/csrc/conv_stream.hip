@@ -16,6 +16,13 @@
 
 namespace {
 
+template <typename TX>
+__device__ __forceinline__ float4 stream_x4(const ConvPass &a, const TX *xpl, const OutRegion &rg, int py, int px) {
+    if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return load_x4<TX>(a, xpl, py, px);
+}
+
+
 constexpr int SR = PB_KRAD;                   // always evaluates all 25 taps per axis
 constexpr int SNT = 2 * SR + 1;
 constexpr int SOUT = 256 - 2 * SR;            // 232 outputs per strip: 58 lanes x 4 ...
@@ -219,8 +226,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             PB_STAGE(cur)                                                                                     \
             PB_SCATTER(S)                                                                                     \
             if (i - 1 >= 2 * SR)                                                                              \
-                finish4<TX, TOut>(b, info, xpl, opl, rg, y0 + i - 1 - 2 * SR, pxo,                            \
-                                  make_float4(axy[S].x, axy[S].y, azw[S].x, azw[S].y));                       \
+                finish4<TOut>(b, info, opl, rg, y0 + i - 1 - 2 * SR, pxo,                                     \
+                              make_float4(axy[S].x, axy[S].y, azw[S].x, azw[S].y),                            \
+                              stream_x4<TX>(b, xpl, rg, y0 + i - 1 - 2 * SR, pxo));                           \
             PB_XPASS()                                                                                        \
         }                                                                                                     \
     }

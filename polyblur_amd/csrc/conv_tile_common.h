@@ -46,6 +46,13 @@ template <typename TX, typename TOut> struct Block4x4Epilogue {
             op = opl + (long)(py - oo) * a.out_pitch + (px - oo);
 #pragma unroll
             for (int r = 0; r < 4; ++r) xr[r] = ld4<TX>(xp + (long)r * a.x_pitch);
+        } else {
+            // border blocks: the (clamped) x operand is fetched up front all the same, one row at a time
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xr[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (py + r >= rg.y_lo && py + r < rg.y_hi && px < rg.x_hi) xr[r] = load_x4<TX>(a, xpl, py + r, px);
+            }
         }
     }
     __device__ __forceinline__ void finish(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl,
@@ -66,10 +73,10 @@ template <typename TX, typename TOut> struct Block4x4Epilogue {
             }
         } else {
             // (statically indexed: a run-time index would push acc[] -- and a 64-byte store per thread -- to scratch)
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py, px, acc[0]);
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 1, px, acc[1]);
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 2, px, acc[2]);
-            finish4<TX, TOut>(a, info, xpl, opl, rg, py + 3, px, acc[3]);
+            finish4<TOut>(a, info, opl, rg, py, px, acc[0], xr[0]);
+            finish4<TOut>(a, info, opl, rg, py + 1, px, acc[1], xr[1]);
+            finish4<TOut>(a, info, opl, rg, py + 2, px, acc[2], xr[2]);
+            finish4<TOut>(a, info, opl, rg, py + 3, px, acc[3], xr[3]);
         }
     }
 };
