@@ -29,6 +29,7 @@
 
 int pb_launch_conv_stream(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_sep(pb_ctx *ctx, const ConvPass &p);
+int pb_launch_conv_persist(pb_ctx *ctx, const ConvPass &p);
 
 namespace {
 
@@ -36,131 +37,6 @@ namespace {
 // =============================================================================================
 // general kernels: workgroup tile body
 // =============================================================================================
-
-// Four consecutive padded columns px..px+3 of source row iy (iy < 0: the row reads as zero): one 16-byte load
-// where the columns map to themselves and are aligned, four mapped loads in the pad / wrap region.
-template <typename T>
-__device__ __forceinline__ float4 load_chunk_mapped(const T *plane, int pitch, int iy, int px, int W, int kind, int boundary,
-                                                    bool aligned) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy < 0) return v;
-    const T *row = plane + (long)iy * pitch;
-    const int shift = (kind == SRC_VIRTUAL) ? PB_PAD : 0;
-    const int lo = shift, hi = (kind == SRC_VIRTUAL) ? PB_PAD + W : W + 2 * PB_PAD;
-    if (aligned && px >= lo && px + 3 < hi) return ld4<T>(row + (px - shift));
-    const int i0 = map_axis(px, W, kind, boundary), i1 = map_axis(px + 1, W, kind, boundary);
-    const int i2 = map_axis(px + 2, W, kind, boundary), i3 = map_axis(px + 3, W, kind, boundary);
-    if (i0 >= 0) v.x = pb_ld(row + i0);
-    if (i1 >= 0) v.y = pb_ld(row + i1);
-    if (i2 >= 0) v.z = pb_ld(row + i2);
-    if (i3 >= 0) v.w = pb_ld(row + i3);
-    return v;
-}
-
-template <typename T, int LH, int LW, int LP>
-__device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
-                                          int boundary) {
-    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
-    bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
-    int sy0 = py0, sx0 = px0;
-    if (kind == SRC_VIRTUAL) {
-        inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
-        sy0 -= PB_PAD; sx0 -= PB_PAD;
-    }
-    const int tid = threadIdx.x;
-    if (inside && ((pitch | sx0) & 3) == 0) {
-        // interior tile: every 16-byte load of the tile is issued before the first one is consumed
-        const T *base = plane + (long)sy0 * pitch + sx0;
-        constexpr int C4 = LW / 4;
-        constexpr int NLD = (LH * C4 + NT - 1) / NT;
-        float4 buf[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * NT;
-            const int r = e / C4, c = e - r * C4;
-            if (e < LH * C4) buf[k] = ld4<T>(base + (long)r * pitch + 4 * c);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * NT;
-            const int r = e / C4, c = e - r * C4;
-            if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
-        }
-    } else {
-        // border tile: rows mapped (wrap / zero / clamp) once per chunk, columns per chunk or per sample
-        const bool aligned = ((pitch | sx0) & 3) == 0;
-        constexpr int C4 = LW / 4;
-        constexpr int NLD = (LH * C4 + NT - 1) / NT;
-        float4 buf[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * NT;
-            const int r = e / C4, c = e - r * C4;
-            if (e < LH * C4)
-                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r, H, kind, boundary), px0 + 4 * c, W, kind, boundary, aligned);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + k * NT;
-            const int r = e / C4, c = e - r * C4;
-            if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
-        }
-    }
-}
-
-// Wave-private variant for the rank-1 body: wave w stages rows [w*RPW, (w+1)*RPW) of the tile -- exactly
-// the rows it x-filters -- so no workgroup barrier is needed between the load and the x pass and the four
-// waves of a workgroup drift apart (one's loads overlap another's arithmetic).
-template <typename T, int LH, int LW, int LP, int RPW>
-__device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
-                                               int boundary) {
-    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
-    bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
-    int sy0 = py0, sx0 = px0;
-    if (kind == SRC_VIRTUAL) {
-        inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
-        sy0 -= PB_PAD; sx0 -= PB_PAD;
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r0 = wave * RPW;
-    const int nrows = min(RPW, LH - r0);
-    constexpr int C4 = LW / 4;
-    if (inside && ((pitch | sx0) & 3) == 0) {
-        const T *base = plane + (long)(sy0 + r0) * pitch + sx0;
-        constexpr int NLD = (RPW * C4 + 63) / 64;
-        float4 buf[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = lane + k * 64;
-            const int r = e / C4, c = e - r * C4;
-            if (r < nrows) buf[k] = ld4<T>(base + (long)r * pitch + 4 * c);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = lane + k * 64;
-            const int r = e / C4, c = e - r * C4;
-            if (r < nrows) *reinterpret_cast<float4 *>(s + (r0 + r) * LP + 4 * c) = buf[k];
-        }
-    } else {
-        const bool aligned = ((pitch | sx0) & 3) == 0;
-        constexpr int NLD = (RPW * C4 + 63) / 64;
-        float4 buf[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = lane + k * 64;
-            const int r = e / C4, c = e - r * C4;
-            if (r < nrows)
-                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r0 + r, H, kind, boundary), px0 + 4 * c, W, kind,
-                                              boundary, aligned);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = lane + k * 64;
-            const int r = e / C4, c = e - r * C4;
-            if (r < nrows) *reinterpret_cast<float4 *>(s + (r0 + r) * LP + 4 * c) = buf[k];
-        }
-    }
-}
 
 // One window row of the general stencil: element m of the thread's window (column c0 - R + m) feeds
 // the four outputs c0 .. c0+3 with taps t[m+3], t[m+2], t[m+1], t[m] (t = the kernel row, zero padded by
@@ -325,6 +201,10 @@ __global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int 
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
     const int R = a.force_full ? PB_KRAD : cinfo->radius;
+    if (sep && sep_in_tile == 2) {                                 // the persistent kernel takes the simple tiles
+        const int ty = local / tiles_x, tx = local - ty * tiles_x;
+        if (pb_tile_is_simple(a, R <= 4 ? 4 : (R <= 8 ? 8 : PB_KRAD), ty, tx)) return;
+    }
     if (sep) {
         if (R <= 4) body_tile_sep<TIn, TX, TOut, 4>(a, info, ipl, xpl, opl, local, tiles_x, smem);
         else if (R <= 8) body_tile_sep<TIn, TX, TOut, 8>(a, info, ipl, xpl, opl, local, tiles_x, smem);
@@ -364,11 +244,18 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
     static int sep_mode = -1;
     if (sep_mode < 0) {
         const char *e = getenv("PB_SEP_BODY");
-        sep_mode = (e && e[0] == 's') ? 2 : ((e && e[0] == 'd') ? 0 : 1);
+        sep_mode = (e && e[0] == 's') ? 2 : ((e && e[0] == 'd') ? 0 : ((e && e[0] == 'p') ? 3 : 1));
     }
     int sep_in_tile = 1;
     const bool bytes = p.in_dtype == PB_U8 || p.x_dtype == PB_U8 || p.out_dtype == PB_U8;   // tile kernel only
     if (bytes) {
+    } else if (sep_mode == 3) {
+        const int key = p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype;
+        if (p.epilogue == EPI_HORNER && (key == 0 || key == 1 || key == 3 || key == 4 || key == 12 || key == 13)) {
+            int rc = pb_launch_conv_persist(ctx, p);
+            if (rc) return rc;
+            sep_in_tile = 2;
+        }
     } else if (sep_mode == 2) {
         int rc = pb_launch_conv_stream(ctx, p);
         if (rc) return rc;

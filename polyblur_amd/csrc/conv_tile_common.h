@@ -28,6 +28,150 @@ __device__ __forceinline__ TileJob decode_tile(const ConvPass &a, int tile_id, i
     return j;
 }
 
+// A tile is "simple" when nothing about it needs border handling: Horner epilogue, 16-byte-aligned pitches,
+// the whole (64+2R)^2 input window inside the source, all 64x64 outputs inside the output region and their
+// x operands inside the x source.  The persistent rank-1 kernel (conv_persist.hip) takes exactly these tiles;
+// conv_tile_kernel takes the others of the same pass.
+__device__ __forceinline__ bool pb_tile_is_simple(const ConvPass &a, int R, int ty, int tx) {
+    if (a.epilogue != EPI_HORNER || ((a.in_pitch | a.x_pitch | a.out_pitch) & 3) != 0) return false;
+    const OutRegion rg = out_region(a);
+    const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
+    if (oy0 + GT > rg.y_hi || ox0 + GT > rg.x_hi) return false;
+    const int H = a.H, W = a.W;
+    const int in_off = a.in_kind == SRC_VIRTUAL ? PB_PAD : 0, x_off = a.x_kind == SRC_VIRTUAL ? PB_PAD : 0;
+    const int in_rows = a.in_kind == SRC_VIRTUAL ? H : H + 2 * PB_PAD, in_cols = a.in_kind == SRC_VIRTUAL ? W : W + 2 * PB_PAD;
+    const int x_rows = a.x_kind == SRC_VIRTUAL ? H : H + 2 * PB_PAD, x_cols = a.x_kind == SRC_VIRTUAL ? W : W + 2 * PB_PAD;
+    if (oy0 - R - in_off < 0 || oy0 + GT + R - in_off > in_rows || ox0 - R - in_off < 0 || ox0 + GT + R - in_off > in_cols) return false;
+    if (oy0 - x_off < 0 || oy0 + GT - x_off > x_rows || ox0 - x_off < 0 || ox0 + GT - x_off > x_cols) return false;
+    return ((ox0 - R - in_off) & 3) == 0 && ((ox0 - x_off) & 3) == 0 &&
+           ((ox0 - (a.out_kind == OUT_INTERIOR ? PB_PAD : 0)) & 3) == 0;
+}
+
+// Four consecutive padded columns px..px+3 of source row iy (iy < 0: the row reads as zero): one 16-byte load
+// where the columns map to themselves and are aligned, four mapped loads in the pad / wrap region.
+template <typename T>
+__device__ __forceinline__ float4 load_chunk_mapped(const T *plane, int pitch, int iy, int px, int W, int kind, int boundary,
+                                                    bool aligned) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy < 0) return v;
+    const T *row = plane + (long)iy * pitch;
+    const int shift = (kind == SRC_VIRTUAL) ? PB_PAD : 0;
+    const int lo = shift, hi = (kind == SRC_VIRTUAL) ? PB_PAD + W : W + 2 * PB_PAD;
+    if (aligned && px >= lo && px + 3 < hi) return ld4<T>(row + (px - shift));
+    const int i0 = map_axis(px, W, kind, boundary), i1 = map_axis(px + 1, W, kind, boundary);
+    const int i2 = map_axis(px + 2, W, kind, boundary), i3 = map_axis(px + 3, W, kind, boundary);
+    if (i0 >= 0) v.x = pb_ld(row + i0);
+    if (i1 >= 0) v.y = pb_ld(row + i1);
+    if (i2 >= 0) v.z = pb_ld(row + i2);
+    if (i3 >= 0) v.w = pb_ld(row + i3);
+    return v;
+}
+
+template <typename T, int LH, int LW, int LP>
+__device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
+                                          int boundary) {
+    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
+    bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
+    int sy0 = py0, sx0 = px0;
+    if (kind == SRC_VIRTUAL) {
+        inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
+        sy0 -= PB_PAD; sx0 -= PB_PAD;
+    }
+    const int tid = threadIdx.x;
+    if (inside && ((pitch | sx0) & 3) == 0) {
+        // interior tile: every 16-byte load of the tile is issued before the first one is consumed
+        const T *base = plane + (long)sy0 * pitch + sx0;
+        constexpr int C4 = LW / 4;
+        constexpr int NLD = (LH * C4 + NT - 1) / NT;
+        float4 buf[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int r = e / C4, c = e - r * C4;
+            if (e < LH * C4) buf[k] = ld4<T>(base + (long)r * pitch + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int r = e / C4, c = e - r * C4;
+            if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
+        }
+    } else {
+        // border tile: rows mapped (wrap / zero / clamp) once per chunk, columns per chunk or per sample
+        const bool aligned = ((pitch | sx0) & 3) == 0;
+        constexpr int C4 = LW / 4;
+        constexpr int NLD = (LH * C4 + NT - 1) / NT;
+        float4 buf[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int r = e / C4, c = e - r * C4;
+            if (e < LH * C4)
+                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r, H, kind, boundary), px0 + 4 * c, W, kind, boundary, aligned);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + k * NT;
+            const int r = e / C4, c = e - r * C4;
+            if (e < LH * C4) *reinterpret_cast<float4 *>(s + r * LP + 4 * c) = buf[k];
+        }
+    }
+}
+
+// Wave-private variant for the rank-1 body: wave w stages rows [w*RPW, (w+1)*RPW) of the tile -- exactly
+// the rows it x-filters -- so no workgroup barrier is needed between the load and the x pass and the four
+// waves of a workgroup drift apart (one's loads overlap another's arithmetic).
+template <typename T, int LH, int LW, int LP, int RPW>
+__device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
+                                               int boundary) {
+    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
+    bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
+    int sy0 = py0, sx0 = px0;
+    if (kind == SRC_VIRTUAL) {
+        inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
+        sy0 -= PB_PAD; sx0 -= PB_PAD;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = wave * RPW;
+    const int nrows = min(RPW, LH - r0);
+    constexpr int C4 = LW / 4;
+    if (inside && ((pitch | sx0) & 3) == 0) {
+        const T *base = plane + (long)(sy0 + r0) * pitch + sx0;
+        constexpr int NLD = (RPW * C4 + 63) / 64;
+        float4 buf[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows) buf[k] = ld4<T>(base + (long)r * pitch + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows) *reinterpret_cast<float4 *>(s + (r0 + r) * LP + 4 * c) = buf[k];
+        }
+    } else {
+        const bool aligned = ((pitch | sx0) & 3) == 0;
+        constexpr int NLD = (RPW * C4 + 63) / 64;
+        float4 buf[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows)
+                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r0 + r, H, kind, boundary), px0 + 4 * c, W, kind,
+                                              boundary, aligned);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = lane + k * 64;
+            const int r = e / C4, c = e - r * C4;
+            if (r < nrows) *reinterpret_cast<float4 *>(s + (r0 + r) * LP + 4 * c) = buf[k];
+        }
+    }
+}
+
 // Per-thread epilogue of a 4 x 4 output block.  `prefetch` is called right after the tile loads have
 // been issued so that the x operand arrives while the stencil is evaluated; blocks that touch the
 // border of the output region (or a clamped / unaligned x operand, or the taper blend) take finish4.
@@ -96,11 +240,15 @@ template <int R, int J> struct XPassR {
         if constexpr (J < 2 * R + 3) XPassR<R, J + 1>::run(vxy, vzw, TP, d);
     }
 };
-// input row I (0 .. 2R+3) of the thread's window feeds output row r with tap I - r
+// input row I (0 .. 2R+3) of the thread's window feeds output row r with tap I - r.  The rows travel through a
+// ring of four registers quads, read three steps ahead of their use (the scheduler barrier keeps each ds_read in
+// front of the step's arithmetic instead of sinking it to its first use and exposing the LDS latency every step).
 template <int R, int I> struct YPassR {
-    static __device__ __forceinline__ void run(f2 (&axy)[4], f2 (&azw)[4], const f2 (&HY)[(R + 2) / 2], const float *col,
-                                               int pitch) {
-        const float4 v4 = *reinterpret_cast<const float4 *>(col + I * pitch);
+    static __device__ __forceinline__ void step(f2 (&axy)[4], f2 (&azw)[4], const f2 (&HY)[(R + 2) / 2], const float *col,
+                                                int pitch, float4 (&ring)[4]) {
+        if constexpr (I + 3 <= 2 * R + 3) ring[(I + 3) & 3] = *reinterpret_cast<const float4 *>(col + (I + 3) * pitch);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 v4 = ring[I & 3];
         const f2 vxy = (f2){v4.x, v4.y}, vzw = (f2){v4.z, v4.w};
 #define PB_YROW(RR)                                                                   \
         if constexpr (I - RR >= 0 && I - RR <= 2 * R) {                               \
@@ -110,7 +258,16 @@ template <int R, int I> struct YPassR {
         }
         PB_YROW(0) PB_YROW(1) PB_YROW(2) PB_YROW(3)
 #undef PB_YROW
-        if constexpr (I < 2 * R + 3) YPassR<R, I + 1>::run(axy, azw, HY, col, pitch);
+        if constexpr (I < 2 * R + 3) YPassR<R, I + 1>::step(axy, azw, HY, col, pitch, ring);
+    }
+    static __device__ __forceinline__ void run(f2 (&axy)[4], f2 (&azw)[4], const f2 (&HY)[(R + 2) / 2], const float *col,
+                                               int pitch) {
+        static_assert(I == 0, "start at row 0");
+        float4 ring[4];
+        ring[0] = *reinterpret_cast<const float4 *>(col);
+        ring[1] = *reinterpret_cast<const float4 *>(col + pitch);
+        ring[2] = *reinterpret_cast<const float4 *>(col + 2 * pitch);
+        step(axy, azw, HY, col, pitch, ring);
     }
 };
 

@@ -560,9 +560,9 @@ def test_uint8_planar_tensor_and_layout(eng):
         polyblur_deblurring_uint8(imgs[0].astype(np.float32))
 
 
-@pytest.mark.parametrize("body", ["dma", "stream"])
+@pytest.mark.parametrize("body", ["dma", "stream", "persist"])
 def test_alternative_rank1_bodies(body):
-    """the two alternative rank-1 kernels (PB_SEP_BODY=dma|stream, read once per process) stay parity-green"""
+    """the alternative rank-1 kernels (PB_SEP_BODY=dma|stream|persist, read once per process) stay parity-green"""
     import subprocess
     import sys
     code = (
