@@ -130,7 +130,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_traffic.json")))
         if cands and B == 1 and (H, W) == (2160, 3840) and s == 4:
             tj = json.load(open(cands[-1]))
             for k, v in tj.get("traffic", {}).items():
