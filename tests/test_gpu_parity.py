@@ -426,6 +426,49 @@ def test_4k_properties(eng):
     assert all(0.3 <= float(i["sigma"][0]) <= 4.0 for i in infos)
 
 
+def test_large_batch_is_per_image(eng):
+    """BASELINE configs 3/4 in miniature: a 1080p batch (fp16 I/O, halo masking, domain-transform prefilter; and
+    plain fp32) gives every image exactly what it gets alone -- every reduction of the pipeline is per image"""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    small, _ = synthetic_blurry_batch(6, 3, 135, 240, seed0=90)
+    x = torch.nn.functional.interpolate(torch.from_numpy(small).cuda(), size=(1080, 1920), mode="bicubic",
+                                        align_corners=False).clamp(0, 1).contiguous()
+    for xx, kw in ((x.half(), dict(remove_halo=True, prefiltering=True, prefilter="domain_transform")), (x, dict())):
+        full, infos = polyblur_deblurring(xx, n_iter=3, return_info=True, **KW, **kw)
+        for i in (0, 3, 5):
+            one = polyblur_deblurring(xx[i:i + 1].contiguous(), n_iter=3, **KW, **kw)
+            assert torch.equal(full[i:i + 1], one), i
+        assert len({float(i_["theta"][k]) for i_ in infos for k in range(6)}) > 1      # the images do differ
+
+
+def test_8k_fp16_properties(eng):
+    """BASELINE config 5's per-GPU share: one 7680x4320 fp16 image, n_iter=5 (longest FFT lines, largest grid)"""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    H, W = 4320, 7680
+    small, _ = synthetic_blurry_batch(1, 3, 270, 480, seed0=34)
+    x = torch.nn.functional.interpolate(torch.from_numpy(small).cuda(), size=(H, W), mode="bicubic",
+                                        align_corners=False).clamp(0, 1).half().contiguous()
+    a, infos = polyblur_deblurring(x, n_iter=5, return_info=True, **KW)
+    b = polyblur_deblurring(x, n_iter=5, **KW)
+    assert torch.equal(a, b) and a.dtype == torch.float16
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and bool(torch.isfinite(a).all())
+    assert all(0.3 <= float(i["sigma"][0]) <= 4.0 and 0.3 <= float(i["rho"][0]) <= 4.0 for i in infos)
+    # the spectral gradient at these lengths (7680 = 2^9*15, 4320 = 2^5*135) against the FFT definition on one plane
+    g = x[0, 0].float()
+    gx, gy = eng.fourier_gradients(g[None, None].cpu().numpy())
+    G = torch.fft.fft2(g.double())
+    fx = torch.fft.fftfreq(W, dtype=torch.float64, device="cuda") * W
+    fy = torch.fft.fftfreq(H, dtype=torch.float64, device="cuda") * H
+    fx[W // 2] = 0
+    fy[H // 2] = 0
+    rx = torch.fft.ifft2(G * (2j * np.pi * fx / W)[None, :]).real.cpu().numpy()
+    ry = torch.fft.ifft2(G * (2j * np.pi * fy / H)[:, None]).real.cpu().numpy()
+    scale = max(1.0, float(np.abs(rx).max()), float(np.abs(ry).max()))
+    assert maxabs(gx[0, 0], rx) < 1e-5 * scale and maxabs(gy[0, 0], ry) < 1e-5 * scale
+
+
 # ---------------------------------------------------------------------------------------------
 # edge cases: ragged / tiny sizes, mixed batches, degenerate inputs
 # ---------------------------------------------------------------------------------------------
