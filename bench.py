@@ -114,8 +114,11 @@ def main():
 
     if rank != 0:
         if use_dist:
+            dist.barrier()                       # leave together with rank 0 (it prints the line first)
             dist.destroy_process_group()
         return
+    if world > 1:
+        args.no_context = True                   # the labelled side measurements belong to the 1-GPU run
 
     s = 4 if args.dtype == "f32" else 2
     samples = B * 3 * H * W
@@ -221,8 +224,9 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "stages_ms_per_step": stages_ms, "estimated_blur": est,
         "context": side, "workspace_bytes": eng.workspace_bytes(),
     }
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -193,7 +193,10 @@ __global__ __launch_bounds__(NT) void dt_rows_kernel(float *__restrict__ F, cons
     }
 }
 
-// One vertical pass (top->bottom then bottom->top) in place on F; thread = (plane, column).
+// One vertical pass (top->bottom then bottom->top) in place on F; thread = (plane, column).  The recurrence is
+// sequential down a column, but its operands are not: the samples and domain weights of the next DT_U rows are
+// fetched together before the U dependent steps run, so a column waits for memory once per U rows, not every row.
+constexpr int DT_U = 16;
 __global__ __launch_bounds__(NT) void dt_cols_kernel(float *__restrict__ F, const float *__restrict__ domy, int C, int H,
                                                      int W, float log_a, long cols_total) {
     const long id = (long)blockIdx.x * NT + threadIdx.x;   // over B*C*W
@@ -204,17 +207,39 @@ __global__ __launch_bounds__(NT) void dt_cols_kernel(float *__restrict__ F, cons
     float *f = F + plane * (long)H * W + c;
     const float *d = domy + b * (long)H * W + c;
     float prev = f[0];
-    for (int r = 1; r < H; ++r) {
-        const float v = expf(d[(long)r * W] * log_a);
-        const float x = f[(long)r * W];
-        prev = x + v * (prev - x);
-        f[(long)r * W] = prev;
+    for (int r0 = 1; r0 < H; r0 += DT_U) {
+        float xs[DT_U], vs[DT_U];
+#pragma unroll
+        for (int u = 0; u < DT_U; ++u) {
+            const int r = min(r0 + u, H - 1);
+            xs[u] = f[(long)r * W];
+            vs[u] = d[(long)r * W];
+        }
+#pragma unroll
+        for (int u = 0; u < DT_U; ++u) {
+            if (r0 + u < H) {
+                const float v = expf(vs[u] * log_a);
+                prev = xs[u] + v * (prev - xs[u]);
+                f[(long)(r0 + u) * W] = prev;
+            }
+        }
     }
-    for (int r = H - 2; r >= 0; --r) {
-        const float v = expf(d[(long)(r + 1) * W] * log_a);
-        const float x = f[(long)r * W];
-        prev = x + v * (prev - x);
-        f[(long)r * W] = prev;
+    for (int r0 = H - 2; r0 >= 0; r0 -= DT_U) {
+        float xs[DT_U], vs[DT_U];
+#pragma unroll
+        for (int u = 0; u < DT_U; ++u) {
+            const int r = max(r0 - u, 0);
+            xs[u] = f[(long)r * W];
+            vs[u] = d[(long)(r + 1) * W];
+        }
+#pragma unroll
+        for (int u = 0; u < DT_U; ++u) {
+            if (r0 - u >= 0) {
+                const float v = expf(vs[u] * log_a);
+                prev = xs[u] + v * (prev - xs[u]);
+                f[(long)(r0 - u) * W] = prev;
+            }
+        }
     }
 }
 
