@@ -6,21 +6,19 @@
 // utils.pad_with_kernel / crop_with_kernel (utils.py:48-61, folded into index arithmetic)
 // and the intent of separable_gaussian2d.cpp:47-88 (x-then-y 1-D Gaussian passes).
 //
-// Two bodies live in the one kernel; every image picks its own at run time from its
-// pb_blur_info record (so a batch may mix them and the host never synchronises):
+// Two bodies live in the one kernel; every image picks its own at run time from its pb_blur_info record (so a
+// batch may mix them and the host never synchronises).  A 256-thread workgroup owns a 64x64 output tile of one
+// plane and stages the (64+2R)^2 samples it needs in LDS once (R = 4, 8 or 12: the image's support class):
 //
-// * rank-1 kernels (theta % 90 == 0 or sigma == rho) -- "streaming" body.  Each WAVE owns a
-//   232-column strip segment and walks down it one row at a time: the row is loaded with
-//   16-byte coalesced reads (prefetched one row ahead), staged through a 1.1 KB wave-private
-//   LDS line, filtered along x (ds_read_b128 + 100 FMA per lane), and scattered along y into
-//   25 rotating accumulator rows held in registers; each step emits one finished output row.
-//   No workgroup barrier, no second LDS buffer, no vertical re-filtering: per sample the pass
-//   moves its 3 algorithmic words of HBM traffic and ~7 words of LDS traffic.
-// * general (rotated anisotropic) kernels -- "tile" body: a 256-thread workgroup stages a
-//   (64+2R)^2 tile in LDS once and evaluates the exact 2-D stencil from it, 4x4 outputs per
-//   thread, the 25-tap rows of the kernel streamed through SGPRs.  fp32 VALU-bound by design.
+// * rank-1 kernels (theta % 90 == 0 or sigma == rho): every wave stages the rows it x-filters itself, filters them
+//   in place along x (ds_read_b128 x7 -> 52 packed FMAs -> ds_write_b128 per 4 outputs), one barrier, then the
+//   y pass accumulates a 4x4 output block per thread (28 ds_read_b128, 200 packed FMAs).  Per sample the pass moves
+//   its 3 algorithmic words of HBM traffic (measured 1.05x) -- both 1-D passes in one launch.
+// * general (rotated anisotropic) kernels: the exact 2-D stencil from the same LDS tile, 4x4 outputs per thread, the
+//   25-tap rows of the kernel streamed through SGPRs (208 packed FMAs per kernel row).  fp32 VALU-bound by design.
 //
-// No MFMA anywhere: the pass is bound by HBM (rank-1) or by the fp32 vector rate (general).
+// No MFMA anywhere: the pass is bound by HBM / latency (rank-1) or by the fp32 vector rate (general).  Alternative
+// rank-1 bodies (conv_stream.hip, conv_sep.hip, conv_persist.hip) are selectable with PB_SEP_BODY for experiments.
 #include <cstdlib>
 #include <cstring>
 

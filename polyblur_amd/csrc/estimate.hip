@@ -10,6 +10,7 @@
 //                                                                blur_estimation.py:138-232
 // Everything stays on the stream: no host synchronisation between stages.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "fft.h"
@@ -805,7 +806,9 @@ template <typename K> int allow_lds(pb_ctx *ctx, K kernel, size_t bytes) {
 
 // choose how many complex lines a column workgroup transforms together
 int pick_lognb(const FftPlan *pl, int W) {
-    int lognb = 3;
+    static int forced = -2;
+    if (forced == -2) { const char *e = getenv("PB_FFT_LOGNB"); forced = e ? atoi(e) : -1; }
+    int lognb = forced >= 0 ? forced : 3;
     while (lognb > 0 && fft_lds_bytes(pl, 1 << lognb) > 80 * 1024) --lognb;
     while (lognb > 0 && (2 << (lognb - 1)) >= W * 2) --lognb;
     return lognb;

@@ -160,14 +160,19 @@ __device__ __forceinline__ void stage(float2 *s, int N, int lognb, int L, const 
         float2 v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = base[q * stride];
+        // M == 1 (the innermost stage): np == 0, every twiddle is 1 -- nothing to fetch or multiply
         if (DIT) {
+            if (M > 1) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[np * q * tw_step]);
+                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[np * q * tw_step]);
+            }
             dft_small<R>(v);
         } else {
             dft_small<R>(v);
+            if (M > 1) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[np * q * tw_step]);
+                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[np * q * tw_step]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) base[q * stride] = v[q];
