@@ -68,7 +68,7 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     constexpr int NP = 2 * WCH + 2;            // tap pairs per copy (taps n = 0 .. 4 WCH + 3)
     constexpr int PR = 4;
     const OutRegion rg = out_region(a);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
     const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
     const int tid = threadIdx.x;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     constexpr int LP = LW;                        // unpadded LDS rows: 30 976 B at R = 12 -> 5 workgroups per CU
     constexpr int XROT = (16 - ((LP / 4) % 16)) % 16, YROT = (16 - (LP % 16)) % 16;   // lane -> column-group rotations
     const OutRegion rg = out_region(a);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
     const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
     Block4x4Epilogue<TX, TOut> epi;
@@ -190,9 +190,11 @@ __global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int 
     const int chunk = gridDim.x >> 3;
     const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (tile_id >= total_tiles) return;
-    const int plane = tile_id / tiles_per_plane;
+    // (integer division runs on the vector ALU even for uniform operands: pin the results back into SGPRs so that the
+    // record pointer -- and with it every tap address in the stencil loops -- stays scalar)
+    const int plane = __builtin_amdgcn_readfirstlane(tile_id / tiles_per_plane);
     const int local = tile_id - plane * tiles_per_plane;
-    const pb_blur_info *info = a.info + plane / a.C;
+    const pb_blur_info *info = a.info + __builtin_amdgcn_readfirstlane(plane / a.C);
     const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
     const bool sep = cinfo->separable != 0;
     if (sep && !sep_in_tile) return;                               // rank-1 images take the streaming kernel
