@@ -328,6 +328,33 @@ def test_pipeline_misc(golden):
     assert maxabs(m(xt.cuda(), n_iter=2, alpha=6, beta=1).cpu().numpy(), g["module_n2"]) < 2e-5
 
 
+EXTRA = {"a6_i45": dict(n_iter=2, n_interpolated_angles=45), "a6_i12": dict(n_iter=2, n_interpolated_angles=12),
+         "a6_i60": dict(n_iter=1, n_interpolated_angles=60), "a6_i7": dict(n_iter=2, n_interpolated_angles=7)}
+
+
+@pytest.mark.parametrize("name", sorted(EXTRA))
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_pipeline_extra_interpolation_grids(golden, name, method):
+    """other interpolation grids than 30 (tests/golden/make_golden_extra.py ran the reference on them)"""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    g = golden("pipeline_extra.npz")
+    out = polyblur_deblurring(torch.from_numpy(g["x"]).cuda(), method=method, **KW, **EXTRA[name]).cpu().numpy()
+    assert maxabs(out, g["%s_%s" % (name, method)]) < 2e-5
+
+
+def test_pipeline_extra_defaults_and_odd_batch(golden):
+    import torch
+    from polyblur_amd import polyblur_deblurring, PolyblurDeblurring
+    g = golden("pipeline_extra.npz")
+    out = polyblur_deblurring(torch.from_numpy(g["y"]).cuda(), n_iter=3, method="fft", **KW).cpu().numpy()
+    assert maxabs(out, g["odd_batch_fft"]) < 2e-5
+    out = PolyblurDeblurring()(torch.from_numpy(g["x"]).cuda(), n_iter=3).cpu().numpy()
+    assert maxabs(out, g["module_defaults_n3"]) < 2e-5
+    out = polyblur_deblurring(torch.from_numpy(g["x"]).cuda(), n_iter=2).cpu().numpy()
+    assert maxabs(out, g["functional_defaults_n2"]) < 2e-5
+
+
 @pytest.mark.parametrize("method", ["fft", "direct"])
 def test_pipeline_strongblur(golden, method):
     """sigma ~ 3.5 blur: fft and direct differ by 3.6e-2 at the border -- each must match its own golden"""

@@ -179,3 +179,25 @@ def test_native_domain_transform_goldens(golden, case):
     x = g["x_" + case]
     assert np.array_equal(ref.normalized_convolution(x, ss, sr, int(n)), g["nc_" + case])
     assert np.max(np.abs(ref.recursive_filter(x, ss, sr, int(n)) - g["rf_" + case])) < 2e-6
+
+
+EXTRA = {"a6_i45": dict(n_iter=2, n_interpolated_angles=45), "a6_i12": dict(n_iter=2, n_interpolated_angles=12),
+         "a6_i60": dict(n_iter=1, n_interpolated_angles=60), "a6_i7": dict(n_iter=2, n_interpolated_angles=7)}
+
+
+@pytest.mark.parametrize("name", sorted(EXTRA))
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_pipeline_extra_interpolation_grids(golden, name, method):
+    g = golden("pipeline_extra.npz")
+    out = ref.polyblur_deblurring(g["x"], method=method, c=0.362, b=0.468, alpha=6, beta=1, **EXTRA[name])
+    assert np.max(np.abs(out - g["%s_%s" % (name, method)])) < 3e-5
+
+
+def test_pipeline_extra_defaults_and_odd_batch(golden):
+    g = golden("pipeline_extra.npz")
+    out = ref.polyblur_deblurring(g["y"], n_iter=3, method="fft", c=0.362, b=0.468, alpha=6, beta=1)
+    assert np.max(np.abs(out - g["odd_batch_fft"])) < 3e-5
+    out = ref.PolyblurDeblurring()(g["x"], n_iter=3)
+    assert np.max(np.abs(out - g["module_defaults_n3"])) < 3e-5
+    out = ref.polyblur_deblurring(g["x"], n_iter=2)
+    assert np.max(np.abs(out - g["functional_defaults_n2"])) < 3e-5
