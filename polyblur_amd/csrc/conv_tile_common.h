@@ -123,7 +123,7 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
 // waves of a workgroup drift apart (one's loads overlap another's arithmetic).
 template <typename T, int LH, int LW, int LP, int RPW>
 __device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
-                                               int boundary) {
+                                               int boundary, int tid = threadIdx.x) {
     const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
     bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
     int sy0 = py0, sx0 = px0;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kin
         inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
         sy0 -= PB_PAD; sx0 -= PB_PAD;
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     const int r0 = wave * RPW;
     const int nrows = min(RPW, LH - r0);
     constexpr int C4 = LW / 4;
