@@ -29,7 +29,6 @@
 int pb_launch_conv_stream(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_sep(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_persist(pb_ctx *ctx, const ConvPass &p);
-int pb_launch_conv_slide(pb_ctx *ctx, const ConvPass &p);
 
 namespace {
 
@@ -250,16 +249,11 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
         if (e && !strcmp(e, "stream")) sep_mode = 2;
         else if (e && !strcmp(e, "dma")) sep_mode = 0;
         else if (e && !strcmp(e, "persist")) sep_mode = 3;
-        else if (e && !strcmp(e, "slide")) sep_mode = 4;
 
     }
     int sep_in_tile = 1;
     const bool bytes = p.in_dtype == PB_U8 || p.x_dtype == PB_U8 || p.out_dtype == PB_U8;   // tile kernel only
-    if (sep_mode == 4) {
-        int rc = pb_launch_conv_slide(ctx, p);
-        if (rc) return rc;
-        sep_in_tile = 0;
-    } else if (bytes) {
+    if (bytes) {
     } else if (sep_mode == 3) {
         const int key = p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype;
         if (p.epilogue == EPI_HORNER && (key == 0 || key == 1 || key == 3 || key == 4 || key == 12 || key == 13)) {
