@@ -514,6 +514,27 @@ def test_small_and_ragged_sizes(shape, method):
     assert maxabs(out.cpu().numpy(), want) < 3e-5
 
 
+def test_many_small_images_and_many_iterations():
+    """grid sizing with B far above the CU count, and a long iteration chain"""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    x, _ = synthetic_blurry_batch(4, 3, 40, 52, seed0=123)
+    big = np.concatenate([x] * 75)                                    # B = 300
+    out = polyblur_deblurring(torch.from_numpy(big).cuda(), n_iter=2, **KW).cpu().numpy()
+    want = ref.polyblur_deblurring(x, n_iter=2, **KW)
+    for i in (0, 1, 150, 299):
+        assert maxabs(out[i], want[i % 4]) < 2e-5
+    assert np.array_equal(out[:4], out[296:])
+    # each iteration is polyblur applied to the previous result: 6 at once == 4 followed by 2, bit for bit
+    xs = torch.from_numpy(x[:1]).cuda()
+    six = polyblur_deblurring(xs, n_iter=6, **KW)
+    assert torch.equal(six, polyblur_deblurring(polyblur_deblurring(xs, n_iter=4, **KW), n_iter=2, **KW))
+    want6 = ref.polyblur_deblurring(x[:1], n_iter=6, **KW)
+    got6 = six.cpu().numpy()
+    # after six sharpening passes rounding differences have been amplified; the bulk still agrees closely
+    assert np.mean(np.abs(got6 - want6) > 1e-4) < 1e-2
+
+
 def test_mixed_batch_rank1_and_general(eng):
     """one launch, images with different bodies and support classes (device-side dispatch per image)"""
     x, _ = synthetic_blurry_batch(5, 3, 140, 200, seed0=17)
