@@ -135,11 +135,6 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype,
                       int B, int C, int H, int W, const pb_options *opt,
                       pb_blur_info *host_info);
 
-/* mode 1: a repeated identical pb_polyblur_batch call (same buffers, shape, dtype, options; host_info == NULL)
- * is captured into a hipGraph on its second occurrence and replayed afterwards -- for small images the ~24
- * launches of a call are launch-bound.  Default 0 (or the PB_GRAPH=1 environment variable at pb_create).   */
-int pb_set_graph_mode(pb_ctx *ctx, int mode);
-
 /* (H,W,C) interleaved bytes <-> (C,H,W) planar bytes for B images, the layouts either side of
  * utils.to_tensor / utils.to_array (utils.py:8-31) when the pixels stay uint8 on the device.  */
 int pb_u8_deinterleave(pb_ctx *ctx, const unsigned char *hwc, unsigned char *chw, int B, int C, int H, int W);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "pb_polyblur_batch", "pb_estimate_blur", "pb_make_kernels", "pb_set_kernels", "pb_fourier_gradients",
     "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
-    "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution", "pb_set_graph_mode",
+    "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other"]
 
@@ -109,7 +109,6 @@ def load_library():
             "pb_memcpy_h2d": (ci, [vp, vp, vp, sz]),
             "pb_memcpy_d2h": (ci, [vp, vp, vp, sz]),
             "pb_polyblur_batch": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), vp]),
-            "pb_set_graph_mode": (ci, [vp, ci]),
             "pb_u8_deinterleave": (ci, [vp, vp, vp, ci, ci, ci, ci]),
             "pb_u8_interleave": (ci, [vp, vp, vp, ci, ci, ci, ci]),
             "pb_estimate_blur": (ci, [vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), vp]),

@@ -39,13 +39,11 @@ void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes) {
     ScratchBuf &b = ctx->scratch[name];
     if (b.bytes >= bytes && b.p) return b.p;
     if (b.p) {
-        if (!ctx->capturing) (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(b.p);
         b.p = nullptr;
         b.bytes = 0;
     }
-    ++ctx->scratch_gen;                       // every captured graph holds the old pointers: they are stale now
-    if (ctx->capturing) ctx->capture_poisoned = true;
     const size_t want = (bytes + 255) & ~(size_t)255;
     if (hipMalloc(&b.p, want) != hipSuccess) {
         b.p = nullptr;
@@ -82,8 +80,6 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(stream);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
-    const char *g = getenv("PB_GRAPH");
-    ctx->graph_mode = (g && g[0] == '1') ? 1 : 0;
     *out = ctx;
     return PB_OK;
 }
@@ -106,8 +102,6 @@ int pb_destroy(pb_ctx *ctx) {
     for (auto e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    for (auto &e : ctx->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
-    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     delete ctx;
     return PB_OK;
 }
@@ -445,80 +439,8 @@ int pb_bilateral5(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int 
 // ---------------------------------------------------------------------------------------------
 // polyblur_deblurring (deblurring.py:23-96)
 // ---------------------------------------------------------------------------------------------
-static int polyblur_pipeline(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
-                             const pb_options *opt, pb_blur_info *host_info);
-
-int pb_set_graph_mode(pb_ctx *ctx, int mode) {
-    if (!ctx || (mode != 0 && mode != 1)) return PB_ERR_BADARG;
-    ctx->graph_mode = mode;
-    return PB_OK;
-}
-
-// Repeated identical calls (same buffers, shape, dtype and options) are launch-bound for small images: ~24 kernels of
-// a few microseconds each.  With graph mode on, the second such call is captured into a hipGraph (on a private stream:
-// the caller's may be the legacy default stream, which cannot be captured) and replayed from the third call on.  A
-// graph bakes in the context's scratch pointers, so any scratch (re)allocation invalidates every graph.
 int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
                       const pb_options *opt, pb_blur_info *host_info) {
-    if (!ctx || !ctx->graph_mode || ctx->prof_on || host_info || !in || !out || !opt || opt->n_iter <= 0)
-        return polyblur_pipeline(ctx, in, out, dtype, B, C, H, W, opt, host_info);
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (ctx->stream && hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
-        return polyblur_pipeline(ctx, in, out, dtype, B, C, H, W, opt, host_info);     // the caller is capturing: join it
-    std::string key(reinterpret_cast<const char *>(opt), sizeof(*opt));
-    const long long head[8] = {(long long)(size_t)in, (long long)(size_t)out, dtype, B, C, H, W, ctx->device};
-    key.append(reinterpret_cast<const char *>(head), sizeof(head));
-    pb_ctx::GraphEntry *e = nullptr;
-    for (auto &g : ctx->graphs) if (g.key == key) { e = &g; break; }
-    if (e && e->exec && e->gen == ctx->scratch_gen) {
-        PB_HIP(hipSetDevice(ctx->device));
-        PB_HIP(hipGraphLaunch(e->exec, ctx->stream));
-        return PB_OK;
-    }
-    if (!e) {                                     // first sighting: run eagerly (this is also what sizes the scratch)
-        if (ctx->graphs.size() >= 16) {
-            if (ctx->graphs.front().exec) (void)hipGraphExecDestroy(ctx->graphs.front().exec);
-            ctx->graphs.erase(ctx->graphs.begin());
-        }
-        ctx->graphs.emplace_back();
-        ctx->graphs.back().key = key;
-        ctx->graphs.back().seen = 1;
-        return polyblur_pipeline(ctx, in, out, dtype, B, C, H, W, opt, host_info);
-    }
-    if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }      // stale: scratch moved since
-    PB_HIP(hipSetDevice(ctx->device));
-    if (!ctx->cap_stream) PB_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
-    hipStream_t user = ctx->stream;
-    if (hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        (void)hipGetLastError();
-        return polyblur_pipeline(ctx, in, out, dtype, B, C, H, W, opt, host_info);
-    }
-    ctx->stream = ctx->cap_stream; ctx->capturing = true; ctx->capture_poisoned = false;
-    const int rc = polyblur_pipeline(ctx, in, out, dtype, B, C, H, W, opt, nullptr);
-    ctx->stream = user; ctx->capturing = false;
-    hipGraph_t graph = nullptr;
-    const hipError_t ce = hipStreamEndCapture(ctx->cap_stream, &graph);
-    if (rc != PB_OK || ce != hipSuccess || !graph || ctx->capture_poisoned) {
-        // nothing ran during the capture: run eagerly (which also reports a genuine error properly)
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        return polyblur_pipeline(ctx, in, out, dtype, B, C, H, W, opt, host_info);
-    }
-    hipGraphExec_t exec = nullptr;
-    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess || !exec) {
-        (void)hipGetLastError();
-        return polyblur_pipeline(ctx, in, out, dtype, B, C, H, W, opt, host_info);
-    }
-    e->exec = exec;
-    e->gen = ctx->scratch_gen;
-    PB_HIP(hipGraphLaunch(exec, ctx->stream));
-    return PB_OK;
-}
-
-static int polyblur_pipeline(pb_ctx *ctx, const void *in, void *out, int dtype, int B, int C, int H, int W,
-                             const pb_options *opt, pb_blur_info *host_info) {
     int rc = check_shape(ctx, dtype, B, C, H, W, 1);
     if (rc) return rc;
     if (!in || !out || !opt) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
@@ -541,7 +463,7 @@ static int polyblur_pipeline(pb_ctx *ctx, const void *in, void *out, int dtype, 
         if (!in32 || !out32) return PB_ERR_NOMEM;
         rc = pb_convert_to_float(ctx, in, PB_U8, in32, n);
         if (rc) return rc;
-        rc = polyblur_pipeline(ctx, in32, out32, PB_F32, B, C, H, W, opt, host_info);
+        rc = pb_polyblur_batch(ctx, in32, out32, PB_F32, B, C, H, W, opt, host_info);
         if (rc) return rc;
         return pb_convert_from_float(ctx, out32, out, PB_U8, n);
     }

@@ -52,13 +52,6 @@ struct pb_ctx {
     int interp_na = 0, interp_ni = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t est_done_bytes = 0;     // size of the zero-initialised arrival counters
-    // hipGraph replay of repeated identical pb_polyblur_batch calls (api.hip)
-    int graph_mode = 0;            // 0 = off, 1 = capture the second identical call and replay it from then on
-    unsigned long long scratch_gen = 0;   // bumped by every scratch (re)allocation: graphs bake scratch pointers
-    bool capturing = false, capture_poisoned = false;
-    hipStream_t cap_stream = nullptr;
-    struct GraphEntry { std::string key; hipGraphExec_t exec = nullptr; unsigned long long gen = 0; int seen = 0; };
-    std::vector<GraphEntry> graphs;
 };
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);

@@ -79,10 +79,6 @@ class Engine:
     def set_stream(self, stream: int):
         self._check(self.lib.pb_set_stream(self.ctx, C.c_void_p(stream or 0)))
 
-    def set_graph_mode(self, on: bool):
-        """Replay repeated identical polyblur calls from a captured hipGraph (see pb_set_graph_mode)."""
-        self._check(self.lib.pb_set_graph_mode(self.ctx, 1 if on else 0))
-
     def synchronize(self):
         self._check(self.lib.pb_synchronize(self.ctx))
 

@@ -514,59 +514,6 @@ def test_small_and_ragged_sizes(shape, method):
     assert maxabs(out.cpu().numpy(), want) < 3e-5
 
 
-def test_graph_replay(eng):
-    """pb_set_graph_mode: eager first call, captured second call, replayed later calls -- all bit-identical to eager;
-    a scratch re-allocation (larger image) invalidates the graphs; other options make another graph"""
-    import torch
-    from polyblur_amd import polyblur_deblurring
-    from polyblur_amd.engine import Engine
-    xs, _ = synthetic_blurry_batch(2, 3, 120, 168, seed0=70)
-    x = torch.from_numpy(xs).cuda()
-    want = polyblur_deblurring(x, n_iter=3, **KW)
-    want_halo = polyblur_deblurring(x, n_iter=2, remove_halo=True, **KW)
-    o3 = Engine.make_options(n_iter=3, **KW)
-    o2 = Engine.make_options(n_iter=2, remove_halo=True, **KW)
-    out = torch.empty_like(x)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_graph_mode(True)
-    try:
-        for rep in range(5):
-            out.zero_()
-            eng.polyblur_ptr(x.data_ptr(), out.data_ptr(), capi.PB_F32, x.shape, o3)
-            assert torch.equal(out, want), rep
-        for rep in range(4):
-            out.zero_()
-            eng.polyblur_ptr(x.data_ptr(), out.data_ptr(), capi.PB_F32, x.shape, o2)
-            assert torch.equal(out, want_halo), rep
-        # a larger image grows the scratch: every graph captured so far is stale and must not be replayed
-        bigs, _ = synthetic_blurry_batch(1, 3, 300, 420, seed0=71)
-        big = torch.from_numpy(bigs).cuda()
-        eng.set_graph_mode(False)
-        want_big = polyblur_deblurring(big, n_iter=3, **KW)
-        eng.set_graph_mode(True)
-        for rep in range(3):
-            out.zero_()
-            eng.polyblur_ptr(x.data_ptr(), out.data_ptr(), capi.PB_F32, x.shape, o3)
-            assert torch.equal(out, want), rep
-        ob = torch.empty_like(big)
-        for rep in range(4):
-            ob.zero_()
-            eng.polyblur_ptr(big.data_ptr(), ob.data_ptr(), capi.PB_F32, big.shape, o3)
-            assert torch.equal(ob, want_big), rep
-        # on a side stream too
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            eng.set_stream(s.cuda_stream)
-            for rep in range(3):
-                out.zero_()
-                eng.polyblur_ptr(x.data_ptr(), out.data_ptr(), capi.PB_F32, x.shape, o3)
-            s.synchronize()
-            assert torch.equal(out, want)
-    finally:
-        eng.set_graph_mode(False)
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
-
-
 def test_many_small_images_and_many_iterations():
     """grid sizing with B far above the CU count, and a long iteration chain"""
     import torch
