@@ -10,7 +10,8 @@ int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int
 int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
                   const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
                   int clamp01);
-int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, const float *smooth, void *out, int dtype, long n);
+int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, int cur_dtype, const float *smooth, void *out, int out_dtype,
+                 long n);
 int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int out_dtype, int P, int H, int W);
 int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype, float *out, int B, int C, int H, int W,
                       float sigma_s, float sigma_r, int num_iterations);
@@ -469,15 +470,15 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     }
     pb_blur_info *infos = static_cast<pb_blur_info *>(pb_scratch(ctx, "pipe.info", sizeof(pb_blur_info) * (size_t)n_iter * B));
     if (!infos) return PB_ERR_NOMEM;
-    // images between iterations: of `dtype` for float I/O (alternating between out and one scratch image), fp32 for
-    // 8-bit I/O (rounding to 8 bits happens once, in the last store -- main.py:146)
-    const int work = dtype == PB_U8 ? PB_F32 : dtype;
+    // images between iterations are fp32 whatever the I/O type: fp16 / 8-bit I/O rounds once, in the last store
+    // (fp32 I/O alternates between `out` and one scratch image; narrower I/O needs two fp32 scratch images)
+    const int work = PB_F32;
     void *tmpimg = nullptr, *tmpimg2 = nullptr;
     if (n_iter > 1) {
         tmpimg = pb_scratch(ctx, "pipe.img", dsize(work) * n);
         if (!tmpimg) return PB_ERR_NOMEM;
     }
-    if (n_iter > 2 && dtype == PB_U8) {
+    if (n_iter > 2 && dtype != PB_F32) {
         tmpimg2 = pb_scratch(ctx, "pipe.img2", dsize(work) * n);
         if (!tmpimg2) return PB_ERR_NOMEM;
     }
@@ -512,7 +513,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     for (int it = 0; it < n_iter; ++it) {
         // the last iteration must land in `out`; alternate between out and tmpimg before that
         void *dst = ((n_iter - 1 - it) % 2 == 0) ? out : tmpimg;
-        if (dtype == PB_U8 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
+        if (dtype != PB_F32 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
         const int cur_dtype = it == 0 ? dtype : work, dst_dtype = it == n_iter - 1 ? dtype : work;
         pb_blur_info *info = infos + (size_t)it * B;
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
@@ -523,16 +524,16 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
             if (rc) return rc;
         } else {
             if (opt->prefilter == PB_PREFILTER_BILATERAL)
-                rc = pb_bilateral5_impl(ctx, cur, dtype, smooth, PB_F32, g.P, H, W);
+                rc = pb_bilateral5_impl(ctx, cur, cur_dtype, smooth, PB_F32, g.P, H, W);
             else if (opt->prefilter == PB_PREFILTER_NORMALIZED_CONVOLUTION)
-                rc = pb_nc_filter_impl(ctx, cur, dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
+                rc = pb_nc_filter_impl(ctx, cur, cur_dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
             else
-                rc = pb_dt_filter_impl(ctx, cur, nullptr, dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
+                rc = pb_dt_filter_impl(ctx, cur, nullptr, cur_dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
             if (rc) return rc;
             rc = inverse_filter(ctx, g, smooth, PB_F32, ybuf, PB_F32, info, opt->alpha, opt->beta, opt->boundary,
                                 opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1, force_full);
             if (rc) return rc;
-            rc = pb_recombine(ctx, ybuf, cur, smooth, dst, dtype, n);
+            rc = pb_recombine(ctx, ybuf, cur, cur_dtype, smooth, dst, dst_dtype, n);
             if (rc) return rc;
         }
         cur = dst;

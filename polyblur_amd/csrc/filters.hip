@@ -60,9 +60,9 @@ __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int 
 }
 
 // out = clip(clip(y,0,1) + (cur - smooth), 0, 1)          (deblurring.py:84,88,239)
-template <typename T>
-__global__ __launch_bounds__(NT) void recombine_kernel(const float *__restrict__ y, const T *__restrict__ cur,
-                                                       const float *__restrict__ smooth, T *__restrict__ out, long n) {
+template <typename TC, typename TO>
+__global__ __launch_bounds__(NT) void recombine_kernel(const float *__restrict__ y, const TC *__restrict__ cur,
+                                                       const float *__restrict__ smooth, TO *__restrict__ out, long n) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
         const float d = pb_ld(cur + i) - smooth[i];
         const float v = fminf(fmaxf(y[i], 0.f), 1.f) + d;
@@ -288,14 +288,17 @@ int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_p
     return PB_OK;
 }
 
-int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, const float *smooth, void *out, int dtype, long n) {
+int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, int cur_dtype, const float *smooth, void *out, int out_dtype,
+                 long n) {
     ProfScope prof(ctx, PB_PROF_PREFILTER);
-    if (dtype == PB_F32)
-        hipLaunchKernelGGL(recombine_kernel<float>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, y,
-                           static_cast<const float *>(cur), smooth, static_cast<float *>(out), n);
-    else
-        hipLaunchKernelGGL(recombine_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, y,
-                           static_cast<const __half *>(cur), smooth, static_cast<__half *>(out), n);
+#define PB_REC(TC, TO)                                                                                           \
+    hipLaunchKernelGGL((recombine_kernel<TC, TO>), dim3(grid_for(n)), dim3(NT), 0, ctx->stream, y,                \
+                       static_cast<const TC *>(cur), smooth, static_cast<TO *>(out), n)
+    if (cur_dtype == PB_F32 && out_dtype == PB_F32) PB_REC(float, float);
+    else if (cur_dtype == PB_F32) PB_REC(float, __half);
+    else if (out_dtype == PB_F32) PB_REC(__half, float);
+    else PB_REC(__half, __half);
+#undef PB_REC
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

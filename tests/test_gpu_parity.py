@@ -385,7 +385,8 @@ def test_pipeline_batch(golden):
 
 def test_pipeline_fp16(golden):
     """fp16 I/O (configs 3 and 5): inputs rounded to fp16, fp32 oracle on those inputs.
-    Estimation and all temporaries stay fp32; only the final store rounds: tolerance = 1 fp16 ulp at 1.0."""
+    Estimation, all temporaries and the images between iterations stay fp32; only the final store rounds:
+    tolerance = 1 fp16 ulp at 1.0 (SURVEY 8c asks for <= 2e-3)."""
     from polyblur_amd import polyblur_deblurring
     import torch
     g = golden("pipeline_fp16in.npz")
@@ -395,7 +396,7 @@ def test_pipeline_fp16(golden):
     check_iterations(g, "fft", infos, 1)
     out3, infos3 = polyblur_deblurring(x, n_iter=3, return_info=True, **KW)
     assert [float(i["theta"][0]) for i in infos3] == [float(g["fft/it%d/theta" % k][0]) for k in range(3)]
-    assert maxabs(out3.float().cpu().numpy(), g["fft/out"]) < 4e-3
+    assert maxabs(out3.float().cpu().numpy(), g["fft/out"]) < 1e-3
 
 
 def test_argument_errors():
