@@ -145,6 +145,10 @@ def main():
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=traffic, traffic_source=traffic_src, launches=conv_n, avg_launch_ms=round(conv_avg_ms, 5),
                     algorithmic_bytes_per_launch=int(alg_bytes_per_launch))
+    # whole-step figure of SURVEY 8d: 9 words per sample per iteration (8 for the polynomial + 1 read for the estimate)
+    e2e_gbs = 9.0 * s * samples * KW["n_iter"] * world / (ms_per_step * 1e-3) / 1e9
+    roofline["end_to_end"] = dict(algorithmic_bytes_per_step=int(9.0 * s * samples * KW["n_iter"]), achieved=round(e2e_gbs, 1),
+                                  unit="GB/s", frac=round(e2e_gbs / (HBM_PEAK_GBS * world), 4))
     stages_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]}
 
     # ---- context: what the estimator found, and the labelled side numbers ----------------------
