@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/s of the Polyblur hot path on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--mode resident|from_root]
 
-One "step" = one full polyblur_deblurring() call (n_iter=3, alpha=6, beta=1, c=0.362, b=0.468,
-q=0, method='fft', full 25-tap support) on one resident batch: BASELINE config 2, a single
-4K (3840x2160x3) fp32 image per GPU.  With N > 1 every rank owns an independent image
-(images shard with no data-path collective; "scaling": "weak"); the timed region is bracketed by
-a barrier + device synchronise on both sides and the maximum over ranks is reported.
+One "step" = one full polyblur_deblurring() call (n_iter=3, alpha=6, beta=1, c=0.362, b=0.468, q=0,
+method='fft', full 25-tap support) on one resident batch.  Default workload: BASELINE config 2, a single
+4K (3840x2160x3) fp32 image per GPU.  The other configs of BASELINE.json are selectable (per-GPU shares):
+cfg3 = 64 x 1080p fp16 + halo removal + domain-transform prefilter, cfg4 = 32 x 1080p fp32 per GPU,
+cfg5 = 1 x 8K fp16 per GPU with n_iter=5.
+
+N > 1: one process per GPU over RCCL.  The driver launches the ranks with torch.distributed.run; when
+bench.py is started directly with --gpus N > 1 (no RANK in the environment) it re-launches itself the same
+way.  --mode resident (default, "scaling": "weak"): every rank owns its shard already (images shard with no
+data-path collective); --mode from_root: the whole batch lives on rank 0 and every step is scatter + compute
++ gather (polyblur_amd.distributed.deblur_from_root, grouped RCCL point-to-point over xGMI).  At N > 1 the
+resident run also carries a short from_root measurement in `context` (report both).  Either way
+the timed region is bracketed by a barrier + device synchronise on both sides and the maximum over ranks is
+reported.
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
-  roofline      -- the dominant kernel (the stencil pass) over the timed region: algorithmic
-                   bytes per launch / average launch duration (hipEvents on the engine's stream)
-  cpu_baseline  -- the NumPy oracle (a port of the reference's CPU path) timed on this box's host
-                   cores on a bounded sample (rank 0, N == 1 only)
-  stages_ms, inner_loop_rank1, adaptive -- context numbers (labelled), never the headline value.
+  roofline      -- the dominant kernel (the stencil pass): algorithmic bytes per launch / average launch
+                   duration, from hipEvents on the engine's stream around every launch of a second, identical
+                   run of the K steps (the headline `value` is timed without the per-launch events)
+  parity        -- the step's output against the oracle on the same image (N == 1): max-abs difference and
+                   whether the per-iteration theta sequences are identical; the run FAILS above tolerance
+  cpu_baseline  -- the NumPy oracle (a port of the reference's CPU path) timed on this box's host cores on
+                   bounded samples (rank 0, N == 1 only): 1 thread and all cores, 700x500 / 1080p / 4K
+  stages_ms_per_step, context -- labelled side numbers, never the headline value.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -27,9 +40,17 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-KW = dict(n_iter=3, c=0.362, b=0.468, alpha=6, beta=1)
+KW = dict(c=0.362, b=0.468, alpha=6, beta=1)
 VALU_PEAK_TFLOPS = 157.3      # fp32 packed FMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    "cfg2": dict(batch=1, height=2160, width=3840, dtype="f32", n_iter=3, opts={}),
+    "cfg3": dict(batch=64, height=1080, width=1920, dtype="f16", n_iter=3,
+                 opts=dict(remove_halo=True, prefiltering=True, prefilter="domain_transform")),
+    "cfg4": dict(batch=32, height=1080, width=1920, dtype="f32", n_iter=3, opts={}),
+    "cfg5": dict(batch=1, height=4320, width=7680, dtype="f16", n_iter=5, opts={}),
+}
 
 
 def parse():
@@ -37,15 +58,34 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="resident", choices=["resident", "from_root"])
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU")
+    ap.add_argument("--dtype", default=None, choices=["f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-context", action="store_true",
                     help="skip the labelled side measurements, so that a profiler sees only the headline workload's kernels")
-    ap.add_argument("--cpu-sample", default="2160x3840", help="HxW crop the CPU baseline is timed on")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU check of the N-rank launch path: rendezvous over gloo, all-reduce, print the line, no compute")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` started by hand: become N ranks, one per GPU, the way the driver starts them."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def make_batch(b, h, w, seed0):
@@ -59,113 +99,208 @@ def make_batch(b, h, w, seed0):
     return x, params
 
 
+def cpu_baseline_samples(x_np, kw, want_4k_result):
+    """The oracle on this box's host cores: 700x500 (config 1's size), 1080p and the 4K headline image, 1 thread
+    and all cores (scipy.fft workers; NumPy's elementwise passes stay single-threaded).  Returns (samples, the
+    4K single-thread result and records or None)."""
+    from oracle import polyblur_ref as ref          # checker / baseline only
+    from polyblur_amd.synthetic import synthetic_blurry_batch
+    cores = os.cpu_count() or 1
+    H, W = x_np.shape[-2:]
+    cases = [("700x500", synthetic_blurry_batch(1, 3, 500, 700, seed0=31)[0]),
+             ("1920x1080", synthetic_blurry_batch(1, 3, 1080, 1920, seed0=32)[0]),
+             ("%dx%d" % (W, H), np.ascontiguousarray(x_np[:1]).astype(np.float32))]
+    samples, res4k = [], None
+    for name, img in cases:
+        for threads in (1, cores):
+            ref.set_fft_workers(None if threads == 1 else threads)
+            t0 = time.perf_counter()
+            r = ref.polyblur_deblurring(img, method="fft", return_info=True, **kw)
+            dt = time.perf_counter() - t0
+            ref.set_fft_workers(None)
+            samples.append(dict(image=name, threads=threads, seconds=round(dt, 3),
+                                mp_per_s=round(img.shape[-1] * img.shape[-2] / 1e6 / dt, 3)))
+            if img is cases[-1][1] and threads == 1 and want_4k_result:
+                res4k = r
+    return samples, res4k
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
+    cfg = dict(CONFIGS[args.config])
+    for k in ("batch", "height", "width", "dtype"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    if args.selftest_launcher:
+        if use_dist:
+            dist.init_process_group("gloo")
+        ones = torch.ones(1)
+        if use_dist:
+            dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({"selftest_launcher": True, "n_gpus": world, "gpus_requested": args.gpus,
+                              "rccl_ranks": int(ones.item()), "backend": "gloo"}), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
     from polyblur_amd import polyblur_deblurring
     from polyblur_amd import _capi as capi
+    from polyblur_amd.distributed import deblur_from_root
     from polyblur_amd.engine import get_engine
     from polyblur_amd.synthetic import DEFAULT_SEED
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but %d rank(s) were launched" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    rccl_ranks = 1
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                            # RCCL is really up, on every rank
+        rccl_ranks = int(ones.item())
 
-    B, H, W = args.batch, args.height, args.width
-    tdt = torch.float32 if args.dtype == "f32" else torch.float16
-    x_np, true_params = make_batch(B, H, W, DEFAULT_SEED + 1000 * rank)
-    x = torch.from_numpy(x_np).to(dev).to(tdt).contiguous()
+    B, H, W = cfg["batch"], cfg["height"], cfg["width"]
+    kw = dict(KW, n_iter=cfg["n_iter"], **cfg["opts"])
+    tdt = torch.float32 if cfg["dtype"] == "f32" else torch.float16
+    s = 4 if cfg["dtype"] == "f32" else 2
     eng = get_engine(local_rank)
+    from_root = args.mode == "from_root"
+    if from_root:
+        # the whole job's batch on rank 0; every step scatters, deblurs and gathers it
+        x_np = make_batch(B * world, H, W, DEFAULT_SEED)[0] if rank == 0 else None
+        x = torch.from_numpy(x_np).to(dev).to(tdt).contiguous() if rank == 0 else None
+        full_shape = (B * world, 3, H, W)
 
-    def step(support="full"):
-        return polyblur_deblurring(x, support=support, **KW)
+        def step(support="full"):
+            return deblur_from_root(x, full_shape, tdt, device=dev, support=support, **kw)
+    else:
+        x_np = make_batch(B, H, W, DEFAULT_SEED + 1000 * rank)[0]
+        x = torch.from_numpy(x_np).to(dev).to(tdt).contiguous()
+
+        def step(support="full"):
+            return polyblur_deblurring(x, support=support, **kw)
 
     def sync_all():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(nsteps, fn):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            o = fn()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # the slowest rank sets the time
+            dt = float(t.item())
+        return dt, o
+
     for _ in range(args.warmup):
         out = step()
-    sync_all()
-    eng.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_end()
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                           # the slowest rank sets the time
-        dt = float(t.item())
+    dt, out = timed(args.steps, step)                                      # the headline: no per-launch events
     ms_per_step = 1e3 * dt / args.steps
     mp_per_step = B * H * W * world / 1e6
     value = mp_per_step / (ms_per_step / 1e3)
+    # the same K steps once more with an event pair around every launch: per-kernel-class device times
+    eng.profile_begin()
+    dt_prof, _ = timed(args.steps, step)
+    prof = eng.profile_end()
+    ms_per_step_prof = 1e3 * dt_prof / args.steps
+
+    side = {}
+    if world > 1 and not from_root and not args.no_context:
+        # SURVEY 8e (ii): the same total batch starting and ending on rank 0 (scatter + compute + gather)
+        xr = torch.cat([x] * world) if rank == 0 else None
+        fr_shape = (B * world, 3, H, W)
+        fr = lambda: deblur_from_root(xr, fr_shape, tdt, device=dev, **kw)
+        fr()
+        n_fr = max(2, min(args.steps, 5))
+        dt_fr, _ = timed(n_fr, fr)
+        ms_fr = 1e3 * dt_fr / n_fr
+        side["from_root_scatter_compute_gather"] = dict(ms_per_step=round(ms_fr, 4), mp_per_s=round(mp_per_step / (ms_fr * 1e-3), 1),
+                                                        note="whole batch on rank 0 before and after; grouped RCCL send/recv per image")
+        del xr
 
     if rank != 0:
         if use_dist:
             dist.barrier()                       # leave together with rank 0 (it prints the line first)
             dist.destroy_process_group()
-        return
+        return 0
     if world > 1:
-        args.no_context = True                   # the labelled side measurements belong to the 1-GPU run
+        args.no_context = True                   # the labelled side measurements below belong to the 1-GPU run
 
-    s = 4 if args.dtype == "f32" else 2
     samples = B * 3 * H * W
-    # ---- roofline of the dominant kernel over the timed region ---------------------------------
+    # ---- roofline of the dominant kernel (second, event-bracketed run of the same steps) ---------------
     conv_ms, conv_n = prof["conv"]
-    # one polynomial application = 3 launches = (2s + 3s + 3s) bytes per sample
-    alg_bytes_per_launch = 8.0 * s * samples / 3.0
+    # SURVEY 8d: one polynomial application = (2s + 3s + 3s) bytes per sample, spread over its launches
+    calls_per_step = B if from_root else 1                       # from_root deblurs image by image as they arrive
+    launches_per_poly = max(conv_n / (args.steps * cfg["n_iter"] * calls_per_step), 1e-9)
+    alg_bytes_per_launch = 8.0 * s * (samples / calls_per_step) / launches_per_poly
     conv_avg_ms = conv_ms / max(conv_n, 1)
-    achieved = alg_bytes_per_launch / (conv_avg_ms * 1e-3) / 1e9
+    achieved = alg_bytes_per_launch / (conv_avg_ms * 1e-3) / 1e9 if conv_n else 0.0
     # HBM-side bytes per launch of the same kernel from the rocprofv3 PMC passes of this same command
     # (tools/profile_bench.sh -> profiles/*_traffic.json; separate runs, FETCH_SIZE x2 on gfx950)
     traffic, traffic_src = None, None
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_traffic.json")))
-        if cands and B == 1 and (H, W) == (2160, 3840) and s == 4:
+        if cands and args.config == "cfg2" and B == 1 and (H, W) == (2160, 3840) and s == 4:
             tj = json.load(open(cands[-1]))
             for k, v in tj.get("traffic", {}).items():
                 if k.startswith("conv_tile_kernel<float, float, float>"):
-                    traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.basename(cands[-1])
+                    traffic = v["hbm_bytes_per_launch"]
+                    traffic_src = "%s (rocprofv3 --pmc passes of this command at git %s)" % (os.path.basename(cands[-1]), tj.get("git", "?"))
     except Exception:
         pass
     roofline = dict(bound="hbm", kernel="conv_tile_kernel (stencil pass; taps as estimated, full 25x25 support)",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=traffic, traffic_source=traffic_src, launches=conv_n, avg_launch_ms=round(conv_avg_ms, 5),
-                    algorithmic_bytes_per_launch=int(alg_bytes_per_launch))
+                    launches_per_polynomial=round(launches_per_poly, 3),
+                    algorithmic_bytes_per_launch=int(alg_bytes_per_launch),
+                    ms_per_step_with_launch_events=round(ms_per_step_prof, 4))
     # whole-step figure of SURVEY 8d: 9 words per sample per iteration (8 for the polynomial + 1 read for the estimate)
-    e2e_gbs = 9.0 * s * samples * KW["n_iter"] * world / (ms_per_step * 1e-3) / 1e9
-    roofline["end_to_end"] = dict(algorithmic_bytes_per_step=int(9.0 * s * samples * KW["n_iter"]), achieved=round(e2e_gbs, 1),
-                                  unit="GB/s", frac=round(e2e_gbs / (HBM_PEAK_GBS * world), 4))
+    e2e_gbs = 9.0 * s * samples * cfg["n_iter"] * world / (ms_per_step * 1e-3) / 1e9
+    roofline["end_to_end"] = dict(algorithmic_bytes_per_step=int(9.0 * s * samples * cfg["n_iter"]), achieved=round(e2e_gbs, 1),
+                                  unit="GB/s", frac=round(e2e_gbs / (HBM_PEAK_GBS * world), 4),
+                                  note="options of cfg3 (halo, prefilter) add bytes that this figure does not count")
     stages_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]}
 
-    # ---- context: what the estimator found, and the labelled side numbers ----------------------
-    _, infos = polyblur_deblurring(x, return_info=True, **KW)
-    est = [dict(theta_deg=round(float(np.rad2deg(i["theta"][0])), 1), sigma=round(float(i["sigma"][0]), 3),
-                rho=round(float(i["rho"][0]), 3), separable=int(i["separable"][0]), radius=int(i["radius"][0]))
-           for i in infos]
-    # The synthetic blur is oblique (2 of the 30 candidate angles give a rank-1 kernel), so the estimated 25x25
-    # kernels are dense and the stencil pass is fp32-VALU-bound, not HBM-bound: say how close to THAT ceiling it
-    # runs (multiply-adds actually issued per launch / launch time; peak = 256 CU x 128 lanes x 2 x 2.4 GHz).
-    macs = [sum((2 * int(r) + 1) * (2 if sp else (2 * int(r) + 1)) for r, sp in zip(i["radius"], i["separable"]))
-            for i in infos]                                       # per sample position of the batch, per pass
-    tflops = 2.0 * 3 * H * W * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12
-    roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(tflops / VALU_PEAK_TFLOPS, 4),
-                            note="dense (non-rank-1) kernels estimated for this input: the pass is VALU-bound; "
-                                 "context.inner_loop_rank1_* is the HBM-bound separable case")
+    est, infos = None, None
+    if not from_root:
+        # ---- context: what the estimator found ---------------------------------------------------------
+        out_info, infos = polyblur_deblurring(x, return_info=True, **kw)
+        est = [dict(theta_deg=round(float(np.rad2deg(i["theta"][0])), 1), sigma=round(float(i["sigma"][0]), 3),
+                    rho=round(float(i["rho"][0]), 3), separable=int(i["separable"][0]), radius=int(i["radius"][0]))
+               for i in infos]
+        # The synthetic blur is oblique (2 of the 30 candidate angles give a rank-1 kernel), so the estimated 25x25
+        # kernels are dense and the stencil pass is fp32-VALU-bound, not HBM-bound: say how close to THAT ceiling it
+        # runs (multiply-adds actually issued per launch / launch time; peak = 256 CU x 128 lanes x 2 x 2.4 GHz).
+        macs = [sum((2 * int(r) + 1) * (2 if sp else (2 * int(r) + 1)) for r, sp in zip(i["radius"], i["separable"])) / B
+                for i in infos]                                   # per sample, per pass
+        tflops = 2.0 * samples * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12 if conv_n else 0.0
+        roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                                frac=round(tflops / VALU_PEAK_TFLOPS, 4),
+                                note="dense (non-rank-1) kernels estimated for this input: the pass is VALU-bound; "
+                                     "context.inner_loop_rank1_* is the HBM-bound separable case")
 
     def inner_loop(theta_deg, sigma, rho, support, reps=20):
         buf = eng.make_kernels([sigma] * B, [rho] * B, [np.deg2rad(np.float32(theta_deg))] * B, support=support,
@@ -178,61 +313,78 @@ def main():
         return dict(ms=round(ms, 4), achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 4),
                     mp_per_s=round(B * H * W / 1e6 / (ms * 1e-3), 1))
 
-    side = {} if args.no_context else {
-        # the north-star figure: n_iter's separable-conv inner loop, rank-1 kernels (theta forced to 0)
-        "inner_loop_rank1_full_support": inner_loop(0.0, 2.0, 1.0, capi.PB_SUPPORT_FULL),
-        "inner_loop_rank1_adaptive_sigma1": inner_loop(0.0, 1.0, 0.6, capi.PB_SUPPORT_ADAPTIVE),
-        "inner_loop_general_full_support": inner_loop(30.0, 2.0, 1.0, capi.PB_SUPPORT_FULL),
-        "inner_loop_general_adaptive_sigma1": inner_loop(30.0, 1.0, 0.6, capi.PB_SUPPORT_ADAPTIVE),
-    }
-    if not args.no_context:
+    if not args.no_context and not from_root:
+        side.update({
+            # the north-star figure: n_iter's separable-conv inner loop, rank-1 kernels (theta forced to 0)
+            "inner_loop_rank1_full_support": inner_loop(0.0, 2.0, 1.0, capi.PB_SUPPORT_FULL),
+            "inner_loop_rank1_adaptive_sigma1": inner_loop(0.0, 1.0, 0.6, capi.PB_SUPPORT_ADAPTIVE),
+            "inner_loop_general_full_support": inner_loop(30.0, 2.0, 1.0, capi.PB_SUPPORT_FULL),
+            "inner_loop_general_adaptive_sigma1": inner_loop(30.0, 1.0, 0.6, capi.PB_SUPPORT_ADAPTIVE),
+        })
         # adaptive-support end-to-end (same results to fp32 rounding), labelled
         for _ in range(2):
             step("adaptive")
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step("adaptive")
-        torch.cuda.synchronize(dev)
-        ms_ad = 1e3 * (time.perf_counter() - t0) / args.steps
+        dt_ad, _ = timed(args.steps, lambda: step("adaptive"))
+        ms_ad = 1e3 * dt_ad / args.steps
         side["end_to_end_adaptive_support"] = dict(ms_per_step=round(ms_ad, 4), mp_per_s=round(B * H * W / 1e6 / (ms_ad * 1e-3), 1))
         # host buffers in and out (PCIe-inclusive; never the headline value)
         xn = x_np.astype(np.float32 if s == 4 else np.float16)
-        polyblur_deblurring(torch.from_numpy(xn), **KW)
+        polyblur_deblurring(torch.from_numpy(xn), **kw)
         t0 = time.perf_counter()
-        polyblur_deblurring(torch.from_numpy(xn), **KW)
+        polyblur_deblurring(torch.from_numpy(xn), **kw)
         ms_pcie = 1e3 * (time.perf_counter() - t0)
         side["end_to_end_host_buffers_pcie"] = dict(ms_per_step=round(ms_pcie, 3), mp_per_s=round(B * H * W / 1e6 / (ms_pcie * 1e-3), 1))
 
-    # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample ---------
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import polyblur_ref as ref          # checker / baseline only
-        ch, cw = (int(v) for v in args.cpu_sample.split("x"))
-        ch, cw = min(ch, H), min(cw, W)
-        crop = np.ascontiguousarray(x_np[:1, :, :ch, :cw]).astype(np.float32)
-        t0 = time.perf_counter()
-        ref.polyblur_deblurring(crop, method="fft", **KW)
-        cdt = time.perf_counter() - t0
-        cpu = dict(value=round(ch * cw / 1e6 / cdt, 4), unit="MP/s", cores=1, kind="port",
-                   sample="one %dx%dx3 fp32 crop of the same synthetic image, n_iter=3, method='fft', NumPy oracle, "
-                          "single thread (host has %d cores), %.1f s" % (cw, ch, os.cpu_count() or 0, cdt))
+    # ---- CPU baseline + full-size parity: the oracle (port of the reference's CPU path) -----------------
+    cpu, parity, failed = None, None, False
+    want_parity = world == 1 and not args.no_parity and not from_root
+    ref_res = None
+    if world == 1 and not args.no_cpu_baseline and not from_root:
+        cpu_samples, ref_res = cpu_baseline_samples(x_np if s == 4 else x_np.astype(np.float16).astype(np.float32),
+                                                    dict(KW, n_iter=cfg["n_iter"]), want_parity and not cfg["opts"])
+        head = [c for c in cpu_samples if c["threads"] == 1][-1]
+        cpu = dict(value=head["mp_per_s"], unit="MP/s", cores=1, kind="port",
+                   sample="one %s x3 fp32 image (the headline's), n_iter=%d, method='fft', NumPy oracle, single thread, %.1f s"
+                          % (head["image"], cfg["n_iter"], head["seconds"]),
+                   host_cores=os.cpu_count(), omp_num_threads=os.environ.get("OMP_NUM_THREADS"), samples=cpu_samples)
+    if want_parity:
+        from oracle import polyblur_ref as ref          # checker only
+        xin = np.ascontiguousarray(x_np[:1]).astype(np.float32 if s == 4 else np.float16).astype(np.float32)
+        if ref_res is None:
+            ref_res = ref.polyblur_deblurring(xin, method="fft", return_info=True, **kw)
+        want, winfos = ref_res
+        got = out_info[:1].float().cpu().numpy()
+        err = float(np.abs(got - want).max())
+        th_hip = [float(i["theta"][0]) for i in infos]
+        th_ref = [float(i["theta"][0]) for i in winfos]
+        tol = 2e-5 if s == 4 else 1e-3
+        parity = dict(max_abs=err, tolerance=tol, theta_sequence_equal=th_hip == th_ref, image="%dx%d, image 0 of the batch" % (W, H),
+                      oracle="oracle/polyblur_ref.py (NumPy fp32, pinned to the reference by tests/golden)")
+        failed = not (err <= tol and th_hip == th_ref)
 
+    desc = "batch=%d %dx%dx3 %s per GPU, n_iter=%d, method=fft (circular), full 25-tap support" % (
+        B, W, H, "fp32" if s == 4 else "fp16", cfg["n_iter"])
+    if cfg["opts"]:
+        desc += ", " + ", ".join("%s=%s" % kv for kv in sorted(cfg["opts"].items()))
     line = {
         "metric": "megapixels/sec (n_iter=3, alpha=6, beta=1)", "value": round(value, 1), "unit": "MP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "batch=%d %dx%dx3 %s per GPU, n_iter=3, method=fft (circular), full 25-tap support"
-                               % (B, W, H, "fp32" if s == 4 else "fp16"),
-                   "images_per_gpu": B, "height": H, "width": W, "parallelism": "images sharded, no collective"},
-        "roofline": roofline, "cpu_baseline": cpu, "stages_ms_per_step": stages_ms, "estimated_blur": est,
-        "context": side, "workspace_bytes": eng.workspace_bytes(),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "config": {"workload": desc, "name": args.config, "mode": args.mode, "images_per_gpu": B, "height": H, "width": W,
+                   "parallelism": "images sharded, no data-path collective" if not from_root else
+                                  "batch on rank 0: RCCL scatter + compute + gather per step"},
+        "rccl_ranks": rccl_ranks, "roofline": roofline, "parity": parity, "cpu_baseline": cpu,
+        "stages_ms_per_step": stages_ms, "estimated_blur": est, "context": side, "workspace_bytes": eng.workspace_bytes(),
     }
     print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        print("PARITY FAILURE: %r" % (parity,), file=sys.stderr)
+        return 1
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

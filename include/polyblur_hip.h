@@ -14,8 +14,9 @@
  *     arguments are HOST pointers and make the call synchronise the stream;
  *   - all other calls are asynchronous on the context's stream;
  *   - the caller owns every buffer; inputs are never written; scratch memory lives in
- *     the context; a context is single-stream and not thread-safe (one per host
- *     thread / GPU);
+ *     the context; a context runs on one stream at a time and is not thread-safe (one
+ *     per host thread / GPU); pb_set_stream orders the new stream behind the work already
+ *     queued on the old one, because the scratch buffers are shared;
  *   - return value: PB_OK (0) or a negative pb_status; pb_last_error_string() gives
  *     the text for the most recent failure on that context.
  */
@@ -75,7 +76,8 @@ typedef struct pb_options {
     float c, b;                 /* affine blur model (blur_estimation.py:171-185) */
     float alpha, beta;          /* polynomial parameters (deblurring.py:133-135) */
     float sigma_s, sigma_r;     /* domain-transform prefilter (deblurring.py:107) */
-    float q;                    /* normalisation quantile; only q == 0 is implemented */
+    float q;                    /* normalisation quantile in [0, 0.5) (blur_estimation.py:102-105); q > 0 is an exact
+                                   torch.quantile by radix select on the device */
     int32_t n_angles;           /* 6 */
     int32_t n_interpolated_angles; /* 30 */
     int32_t remove_halo;
@@ -156,7 +158,11 @@ int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *ho
 int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_blur_info *dev_info);
 
 /* filters.fourier_gradients (filters.py:159-186) on P = B*C planes of H x W float32.
- * gx or gy may be NULL.                                                                  */
+ * gx or gy may be NULL.  The transform keeps whole image lines in LDS: each of H and W must
+ * satisfy pb_fft_length_supported() -- up to 20480 when every prime factor is <= 7, up to
+ * 8192 otherwise (the reference's torch.fft takes any size).  The same limit applies to every
+ * entry point that estimates blur or removes halos; they return PB_ERR_UNSUPPORTED beyond it. */
+int pb_fft_length_supported(int n);                 /* 1 or 0; needs no context */
 int pb_fourier_gradients(pb_ctx *ctx, const float *planes, int P, int H, int W,
                          float *gx, float *gy);
 

@@ -33,6 +33,28 @@ import numpy as np
 
 F32 = np.float32
 
+
+class _Fft:
+    """The transforms the oracle uses.  Default: numpy.fft (what the goldens were pinned with).
+    ``set_fft_workers(n)`` switches to scipy.fft's multi-threaded pocketfft -- same transforms, rounding-level
+    differences -- for the all-cores leg of bench.py's cpu_baseline; ``set_fft_workers(None)`` switches back."""
+    workers = None
+
+    def __getattr__(self, name):
+        if self.workers is None or name in ("fftshift", "ifftshift"):
+            return getattr(np.fft, name)
+        import functools
+        import scipy.fft
+        return functools.partial(getattr(scipy.fft, name), workers=self.workers)
+
+
+_fft = _Fft()
+
+
+def set_fft_workers(n):
+    _Fft.workers = None if n is None else int(n)
+
+
 __all__ = [
     "polyblur_deblurring", "PolyblurDeblurring", "spectral_gradients",
     "spectral_gradients_1d", "estimate_gaussian_blur", "gaussian_kernel_2d",
@@ -95,13 +117,13 @@ def spectral_gradients(x: np.ndarray):
     """
     x = np.asarray(x, dtype=F32)
     h, w = x.shape[-2:]
-    U = np.fft.fftshift(np.fft.fft2(x), axes=(-2, -1))
+    U = _fft.fftshift(_fft.fft2(x), axes=(-2, -1))
     iU = (-U.imag + 1j * U.real).astype(np.complex64)          # = i * U
     fw = _centered_freqs(w).reshape((1,) * (x.ndim - 1) + (w,))
     fh = _centered_freqs(h).reshape((1,) * (x.ndim - 2) + (h, 1))
     two_pi = F32(2.0 * np.pi)
-    gx = np.fft.ifft2(np.fft.ifftshift((two_pi * fw) * iU, axes=(-2, -1))).real
-    gy = np.fft.ifft2(np.fft.ifftshift((two_pi * fh) * iU, axes=(-2, -1))).real
+    gx = _fft.ifft2(_fft.ifftshift((two_pi * fw) * iU, axes=(-2, -1))).real
+    gy = _fft.ifft2(_fft.ifftshift((two_pi * fh) * iU, axes=(-2, -1))).real
     return gx.astype(F32), gy.astype(F32)
 
 
@@ -124,8 +146,8 @@ def spectral_gradients_1d(x: np.ndarray):
     h, w = x.shape[-2:]
     dw = spectral_derivative_multiplier(w)
     dh = spectral_derivative_multiplier(h)
-    gx = np.fft.ifft(np.fft.fft(x, axis=-1) * dw, axis=-1).real
-    gy = np.fft.ifft(np.fft.fft(x, axis=-2) * dh[:, None], axis=-2).real
+    gx = _fft.ifft(_fft.fft(x, axis=-1) * dw, axis=-1).real
+    gy = _fft.ifft(_fft.fft(x, axis=-2) * dh[:, None], axis=-2).real
     return gx.astype(F32), gy.astype(F32)
 
 
@@ -316,7 +338,7 @@ def psf_to_otf(kernel: np.ndarray, shape) -> np.ndarray:
     big = np.zeros(k.shape[:-2] + tuple(shape), dtype=F32)
     big[..., :kh, :kw] = k
     big = np.roll(big, (-(kh // 2), -(kw // 2)), axis=(-2, -1))
-    return np.fft.fft2(big).astype(np.complex64)
+    return _fft.fft2(big).astype(np.complex64)
 
 
 def circular_convolve(x: np.ndarray, kernel: np.ndarray) -> np.ndarray:
@@ -327,9 +349,9 @@ def circular_convolve(x: np.ndarray, kernel: np.ndarray) -> np.ndarray:
     k = _per_image_kernel(kernel, x.shape[0])
     r = k.shape[-1] // 2
     xp = np.pad(x, [(0, 0), (0, 0), (r, r), (r, r)], mode="wrap")
-    X = np.fft.fft2(xp).astype(np.complex64)
+    X = _fft.fft2(xp).astype(np.complex64)
     K = psf_to_otf(k, xp.shape[-2:])
-    return crop(np.fft.ifft2(K * X).real.astype(F32), r)
+    return crop(_fft.ifft2(K * X).real.astype(F32), r)
 
 
 def convolve2d(x, kernel, method="direct"):
@@ -358,13 +380,13 @@ def polynomial_deconvolution(x: np.ndarray, kernel: np.ndarray, alpha: float, be
     x = np.asarray(x, dtype=F32)
     a3, a2, a1, b0 = polynomial_coefficients(alpha, beta)
     if method == "fft":
-        Y = np.fft.fft2(x).astype(np.complex64)
+        Y = _fft.fft2(x).astype(np.complex64)
         K = psf_to_otf(_per_image_kernel(kernel, x.shape[0]), x.shape[-2:])
         X = F32(a3) * Y
         X = K * X + F32(a2) * Y
         X = K * X + F32(a1) * Y
         X = K * X + F32(b0) * Y
-        return np.fft.ifft2(X).real.astype(F32)
+        return _fft.ifft2(X).real.astype(F32)
     if method in ("direct", "direct_separable"):
         t = F32(a3) * x
         t = correlate_same_zero(t, kernel) + F32(a2) * x
@@ -379,8 +401,8 @@ def polynomial_deconvolution(x: np.ndarray, kernel: np.ndarray, alpha: float, be
 
 def _autocorr_weight(proj: np.ndarray, n: int) -> np.ndarray:
     # edgetaper.py:11-15: z = ifft(|fft(p, n-1)|^2), append z[0], 1 - z/max(z)
-    z = np.fft.fft(proj.astype(F32), n - 1, axis=-1)
-    z = np.fft.ifft(np.abs(z) ** 2, axis=-1).real.astype(F32)
+    z = _fft.fft(proj.astype(F32), n - 1, axis=-1)
+    z = _fft.ifft(np.abs(z) ** 2, axis=-1).real.astype(F32)
     z = np.concatenate([z, z[..., :1]], axis=-1)
     return (F32(1) - z / z.max(axis=-1, keepdims=True)).astype(F32)   # per-image max
 

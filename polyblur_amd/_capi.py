@@ -31,6 +31,7 @@ SYMBOLS = [
     "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
     "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
+    "pb_fft_length_supported",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other"]
 
@@ -125,6 +126,7 @@ def load_library():
             "pb_time_inner_loop": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, cf, cf, ci, ci, fp]),
             "pb_extract_patches": (ci, [vp, vp, vp] + [ci] * 15),
             "pb_overlap_add": (ci, [vp, vp, vp] + [ci] * 13 + [vp, vp]),
+            "pb_fft_length_supported": (ci, [ci]),
             "pb_profile_begin": (ci, [vp]),
             "pb_profile_end": (ci, [vp, fp, C.POINTER(ci)]),
         }

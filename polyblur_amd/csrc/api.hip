@@ -80,7 +80,8 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     pb_ctx *ctx = new pb_ctx();
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(stream);
-    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     *out = ctx;
     return PB_OK;
 }
@@ -103,13 +104,22 @@ int pb_destroy(pb_ctx *ctx) {
     for (auto e : ctx->evpool) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
     delete ctx;
     return PB_OK;
 }
 
 int pb_set_stream(pb_ctx *ctx, void *stream) {
     if (!ctx) return PB_ERR_BADARG;
-    ctx->stream = static_cast<hipStream_t>(stream);
+    hipStream_t next = static_cast<hipStream_t>(stream);
+    if (next != ctx->stream) {
+        // the context's scratch buffers may still be in use by work queued on the old stream: order the new
+        // stream behind it (device-side dependency, no host wait)
+        PB_HIP(hipSetDevice(ctx->device));
+        PB_HIP(hipEventRecord(ctx->ev_switch, ctx->stream));
+        PB_HIP(hipStreamWaitEvent(next, ctx->ev_switch, 0));
+        ctx->stream = next;
+    }
     return PB_OK;
 }
 

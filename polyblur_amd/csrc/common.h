@@ -50,7 +50,7 @@ struct pb_ctx {
     std::map<int, FftPlan> plans;
     float *interp_w = nullptr;     // (n_interp x (n_angles+1)) Keys weights
     int interp_na = 0, interp_ni = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_switch = nullptr;
     size_t est_done_bytes = 0;     // size of the zero-initialised arrival counters
 };
 

@@ -17,18 +17,11 @@
 // * general (rotated anisotropic) kernels: the exact 2-D stencil from the same LDS tile, 4x4 outputs per thread, the
 //   25-tap rows of the kernel streamed through SGPRs (208 packed FMAs per kernel row).  fp32 VALU-bound by design.
 //
-// No MFMA anywhere: the pass is bound by HBM / latency (rank-1) or by the fp32 vector rate (general).  Alternative
-// rank-1 bodies (conv_stream.hip, conv_sep.hip, conv_persist.hip) are selectable with PB_SEP_BODY for experiments.
-#include <cstdlib>
-#include <cstring>
+// No MFMA anywhere: the pass is bound by HBM / latency (rank-1) or by the fp32 vector rate (general).
 
 #include "common.h"
 #include "conv_common.h"
 #include "conv_tile_common.h"
-
-int pb_launch_conv_stream(pb_ctx *ctx, const ConvPass &p);
-int pb_launch_conv_sep(pb_ctx *ctx, const ConvPass &p);
-int pb_launch_conv_persist(pb_ctx *ctx, const ConvPass &p);
 
 namespace {
 
@@ -182,7 +175,7 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
 constexpr size_t kTileLds = sizeof(float) * (GT + 2 * PB_KRAD) * (GT + 2 * PB_KRAD);   // 88 x 88 floats
 
 template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int sep_in_tile, int total_tiles) {
+__global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), so
     // give every XCD one contiguous run of tiles -- row-neighbours then share their halos in that
@@ -197,15 +190,10 @@ __global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int 
     const pb_blur_info *info = a.info + __builtin_amdgcn_readfirstlane(plane / a.C);
     const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
     const bool sep = cinfo->separable != 0;
-    if (sep && !sep_in_tile) return;                               // rank-1 images take the streaming kernel
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
     const int R = a.force_full ? PB_KRAD : cinfo->radius;
-    if (sep && sep_in_tile == 2) {                                 // the persistent kernel takes the simple tiles
-        const int ty = local / tiles_x, tx = local - ty * tiles_x;
-        if (pb_tile_is_simple(a, R <= 4 ? 4 : (R <= 8 ? 8 : PB_KRAD), ty, tx)) return;
-    }
     if (sep) {
         if (R <= 4) body_tile_sep<TIn, TX, TOut, 4>(a, info, ipl, xpl, opl, local, tiles_x, smem);
         else if (R <= 8) body_tile_sep<TIn, TX, TOut, 8>(a, info, ipl, xpl, opl, local, tiles_x, smem);
@@ -218,7 +206,7 @@ __global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int 
 }
 
 template <typename TIn, typename TX, typename TOut>
-int launch_typed(pb_ctx *ctx, const ConvPass &p, int sep_in_tile) {
+int launch_typed(pb_ctx *ctx, const ConvPass &p) {
     const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * PB_PAD;
     const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * PB_PAD;
     const int tiles_x = (ow + GT - 1) / GT, tiles_y = (oh + GT - 1) / GT;
@@ -227,64 +215,32 @@ int launch_typed(pb_ctx *ctx, const ConvPass &p, int sep_in_tile) {
     if (blocks <= 0 || blocks > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "conv pass: bad grid");
     const long grid = (blocks + 7) / 8 * 8;
     hipLaunchKernelGGL((conv_tile_kernel<TIn, TX, TOut>), dim3((unsigned)grid), dim3(NT), kTileLds, ctx->stream, p,
-                       (int)tpp, tiles_x, sep_in_tile, (int)blocks);
+                       (int)tpp, tiles_x, (int)blocks);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
 
 }  // namespace
 
-// Both kernels are launched for every pass: each image's record decides on the device which of the
-// two does the work (the other's workgroups for that image exit at once), so a batch may mix
-// rank-1 and general kernels and the host never has to read the estimates back.
+// One launch per pass: each image's record decides on the device which body evaluates its tiles, so a batch
+// may mix rank-1 and general kernels and the host never has to read the estimates back.
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
     ProfScope prof(ctx, PB_PROF_CONV);
-    // PB_SEP_BODY selects the body for rank-1 images: "tile" (default: inside the one-shot tile kernel,
-    // the fastest today), "dma" (persistent double-buffered LDS-DMA kernel, fp32 input only) or "stream"
-    // (wave-private streaming kernel).  The two alternatives are kept selectable and parity-tested.
-    static int sep_mode = -1;
-    if (sep_mode < 0) {
-        const char *e = getenv("PB_SEP_BODY");
-        sep_mode = 1;
-        if (e && !strcmp(e, "stream")) sep_mode = 2;
-        else if (e && !strcmp(e, "dma")) sep_mode = 0;
-        else if (e && !strcmp(e, "persist")) sep_mode = 3;
-
-    }
-    int sep_in_tile = 1;
-    const bool bytes = p.in_dtype == PB_U8 || p.x_dtype == PB_U8 || p.out_dtype == PB_U8;   // tile kernel only
-    if (bytes) {
-    } else if (sep_mode == 3) {
-        const int key = p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype;
-        if (p.epilogue == EPI_HORNER && (key == 0 || key == 1 || key == 3 || key == 4 || key == 12 || key == 13)) {
-            int rc = pb_launch_conv_persist(ctx, p);
-            if (rc) return rc;
-            sep_in_tile = 2;
-        }
-    } else if (sep_mode == 2) {
-        int rc = pb_launch_conv_stream(ctx, p);
-        if (rc) return rc;
-        sep_in_tile = 0;
-    } else if (sep_mode == 0 && p.in_dtype == PB_F32) {
-        int rc = pb_launch_conv_sep(ctx, p);
-        if (rc) return rc;
-        sep_in_tile = 0;
-    }
     const int key = p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype;
     typedef unsigned char u8;
     switch (key) {
-        case 0: return launch_typed<float, float, float>(ctx, p, sep_in_tile);
-        case 1: return launch_typed<float, float, __half>(ctx, p, sep_in_tile);
-        case 3: return launch_typed<float, __half, float>(ctx, p, sep_in_tile);
-        case 4: return launch_typed<float, __half, __half>(ctx, p, sep_in_tile);
-        case 12: return launch_typed<__half, __half, float>(ctx, p, sep_in_tile);
-        case 13: return launch_typed<__half, __half, __half>(ctx, p, sep_in_tile);
+        case 0: return launch_typed<float, float, float>(ctx, p);
+        case 1: return launch_typed<float, float, __half>(ctx, p);
+        case 3: return launch_typed<float, __half, float>(ctx, p);
+        case 4: return launch_typed<float, __half, __half>(ctx, p);
+        case 12: return launch_typed<__half, __half, float>(ctx, p);
+        case 13: return launch_typed<__half, __half, __half>(ctx, p);
         // 8-bit images: first pass of the first iteration, the later passes that still read the 8-bit x, and the
         // store of the last pass (fp32 in between)
-        case 24: return launch_typed<u8, u8, float>(ctx, p, sep_in_tile);
-        case 6: return launch_typed<float, u8, float>(ctx, p, sep_in_tile);
-        case 8: return launch_typed<float, u8, u8>(ctx, p, sep_in_tile);
-        case 2: return launch_typed<float, float, u8>(ctx, p, sep_in_tile);
+        case 24: return launch_typed<u8, u8, float>(ctx, p);
+        case 6: return launch_typed<float, u8, float>(ctx, p);
+        case 8: return launch_typed<float, u8, u8>(ctx, p);
+        case 2: return launch_typed<float, float, u8>(ctx, p);
         default: return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: unsupported dtype combination %d", key);
     }
 }

@@ -1,4 +1,4 @@
-// Device helpers shared by the two bodies of the stencil pass (conv.hip, conv_stream.hip).
+// Device helpers shared by the two bodies of the stencil pass (conv.hip).
 #pragma once
 #include "common.h"
 
@@ -36,10 +36,11 @@ __device__ __forceinline__ int map_axis(int p, int n_unpadded, int kind, int bou
 }
 
 __device__ __forceinline__ float taper_weight(const float *ac, int p, int n) {
-    // v[p] = 1 - z[p]/z[0], z = circular autocorrelation with period n-1, z[n-1] := z[0]
-    // (edgetaper.py:11-15): non-zero only within 24 samples of either end.
-    const int m = min(p, n - 1 - p);
-    const float z = (m < PB_KSIZE) ? ac[m] : 0.f;
+    // v[p] = 1 - z[p]/z[0], z = circular autocorrelation with period n-1, z[n-1] := z[0] (edgetaper.py:11-15):
+    // z[p] = ac[p] + ac[n-1-p] with ac = 0 beyond lag 24 -- non-zero only within 24 samples of either end, and
+    // both terms count at once only when the padded axis is shorter than 49 samples (n-1 >= 25 always: z[0] = ac[0]).
+    const int q = n - 1 - p;
+    const float z = ((p < PB_KSIZE) ? ac[p] : 0.f) + ((q < PB_KSIZE) ? ac[q] : 0.f);
     return 1.f - z * __frcp_rn(ac[0]);
 }
 

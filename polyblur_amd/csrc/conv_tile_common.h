@@ -1,4 +1,4 @@
-// Pieces shared by the tile-geometry stencil kernels (conv.hip, conv_sep.hip).
+// Tile-geometry pieces of the stencil kernels (conv.hip).
 #pragma once
 #include "common.h"
 #include "conv_common.h"
@@ -26,25 +26,6 @@ __device__ __forceinline__ TileJob decode_tile(const ConvPass &a, int tile_id, i
     const int R = a.force_full ? PB_KRAD : ci->radius;
     j.cls = 8 * sep + (R <= 4 ? 0 : (R <= 8 ? 1 : 2));
     return j;
-}
-
-// A tile is "simple" when nothing about it needs border handling: Horner epilogue, 16-byte-aligned pitches,
-// the whole (64+2R)^2 input window inside the source, all 64x64 outputs inside the output region and their
-// x operands inside the x source.  The persistent rank-1 kernel (conv_persist.hip) takes exactly these tiles;
-// conv_tile_kernel takes the others of the same pass.
-__device__ __forceinline__ bool pb_tile_is_simple(const ConvPass &a, int R, int ty, int tx) {
-    if (a.epilogue != EPI_HORNER || ((a.in_pitch | a.x_pitch | a.out_pitch) & 3) != 0) return false;
-    const OutRegion rg = out_region(a);
-    const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
-    if (oy0 + GT > rg.y_hi || ox0 + GT > rg.x_hi) return false;
-    const int H = a.H, W = a.W;
-    const int in_off = a.in_kind == SRC_VIRTUAL ? PB_PAD : 0, x_off = a.x_kind == SRC_VIRTUAL ? PB_PAD : 0;
-    const int in_rows = a.in_kind == SRC_VIRTUAL ? H : H + 2 * PB_PAD, in_cols = a.in_kind == SRC_VIRTUAL ? W : W + 2 * PB_PAD;
-    const int x_rows = a.x_kind == SRC_VIRTUAL ? H : H + 2 * PB_PAD, x_cols = a.x_kind == SRC_VIRTUAL ? W : W + 2 * PB_PAD;
-    if (oy0 - R - in_off < 0 || oy0 + GT + R - in_off > in_rows || ox0 - R - in_off < 0 || ox0 + GT + R - in_off > in_cols) return false;
-    if (oy0 - x_off < 0 || oy0 + GT - x_off > x_rows || ox0 - x_off < 0 || ox0 + GT - x_off > x_cols) return false;
-    return ((ox0 - R - in_off) & 3) == 0 && ((ox0 - x_off) & 3) == 0 &&
-           ((ox0 - (a.out_kind == OUT_INTERIOR ? PB_PAD : 0)) & 3) == 0;
 }
 
 // Four consecutive padded columns px..px+3 of source row iy (iy < 0: the row reads as zero): one 16-byte load

@@ -64,6 +64,21 @@ template <typename T> static T *upload(pb_ctx *ctx, const std::vector<T> &h) {
 
 }  // namespace
 
+// The spectral derivative keeps whole lines in LDS (160 KB): lengths up to 20480 when every prime factor is <= 7,
+// up to 8192 otherwise (Bluestein with a power-of-two core of at least 2n-1 points).
+extern "C" int pb_fft_length_supported(int n) {
+    if (n < 2) return 0;
+    std::vector<int> radix;
+    int rest = 1;
+    factorize(n, radix, rest);
+    long core = n;
+    if (rest != 1) {
+        core = 1;
+        while (core < 2L * n - 1) core *= 2;
+    }
+    return core * (long)sizeof(float2) <= 160 * 1024;
+}
+
 const FftPlan *pb_get_plan(pb_ctx *ctx, int n) {
     auto it = ctx->plans.find(n);
     if (it != ctx->plans.end()) return &it->second;

@@ -16,7 +16,7 @@ constexpr int NT = 256;
 // ------------------------------------------------------------------------------------
 // nM[plane] = sum_{H,W} gx^2 + gy^2          (deblurring.py:178-179,206)
 __global__ __launch_bounds__(NT) void grad_energy_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
-                                                         float *__restrict__ nM, long HW, int blocks_per_plane) {
+                                                         float *__restrict__ partial, long HW, int blocks_per_plane) {
     const int plane = blockIdx.x / blocks_per_plane;
     const int blk = blockIdx.x - plane * blocks_per_plane;
     const float *a = gx + (long)plane * HW, *b = gy + (long)plane * HW;
@@ -30,8 +30,18 @@ __global__ __launch_bounds__(NT) void grad_energy_kernel(const float *__restrict
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int w = 0; w < NT / 64; ++w) t += red[w];
-        atomicAdd(nM + plane, t);
+        partial[blockIdx.x] = t;
     }
+}
+// one wave per plane folds that plane's per-block partial sums in a fixed order: nM is bit-reproducible
+__global__ __launch_bounds__(64) void grad_energy_fold_kernel(const float *__restrict__ partial, float *__restrict__ nM,
+                                                              int blocks_per_plane) {
+    const float *p = partial + (long)blockIdx.x * blocks_per_plane;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < blocks_per_plane; i += 64) s += p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) nM[blockIdx.x] = s;
 }
 
 // M = -gx*ox - gy*gy  (sic: deblurring.py:174 multiplies grad_y by itself, not by gout_y)
@@ -40,10 +50,10 @@ template <typename TX, typename TOut>
 __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int x_pitch, long x_plane,
                                                   const float *__restrict__ y, const float *__restrict__ gx,
                                                   const float *__restrict__ gy, const float *__restrict__ ox,
-                                                  const float *__restrict__ nM, TOut *__restrict__ out, int H, int W,
+                                                  const float *__restrict__ nM, TOut *__restrict__ out, int P, int H, int W,
                                                   int clamp01) {
-    const int plane = blockIdx.y;
     const long HW = (long)H * W;
+    for (int plane = blockIdx.y; plane < P; plane += gridDim.y) {      // (grid.y is capped at 65535)
     const float nm = nM[plane];
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
         const int r = (int)(i / W), c = (int)(i - (long)r * W);
@@ -56,6 +66,7 @@ __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int 
         float v = yv + z * (xv - yv);
         if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
         pb_st(out + k, v);
+    }
     }
 }
 
@@ -74,12 +85,13 @@ __global__ __launch_bounds__(NT) void recombine_kernel(const float *__restrict__
 // bilateral 5x5
 // ------------------------------------------------------------------------------------
 template <typename TIn, typename TOut>
-__global__ __launch_bounds__(NT) void bilateral5_kernel(const TIn *__restrict__ in, TOut *__restrict__ out, int H, int W,
+__global__ __launch_bounds__(NT) void bilateral5_kernel(const TIn *__restrict__ in, TOut *__restrict__ out, int P, int H, int W,
                                                         float inv_var2_color, float inv_var2_space) {
     constexpr int TWB = 64, THB = 16, R = 2, LW = TWB + 2 * R, LH = THB + 2 * R;
     __shared__ float s[LH * LW];
-    const int plane = blockIdx.z;
     const int x0 = blockIdx.x * TWB, y0 = blockIdx.y * THB;
+    for (int plane = blockIdx.z; plane < P; plane += gridDim.z) {      // (grid.z is capped at 65535)
+    if (plane != (int)blockIdx.z) __syncthreads();
     const TIn *src = in + (long)plane * H * W;
     for (int e = threadIdx.x; e < LH * LW; e += NT) {
         const int r = e / LW, c = e - r * LW;
@@ -105,6 +117,7 @@ __global__ __launch_bounds__(NT) void bilateral5_kernel(const TIn *__restrict__ 
                 den += w;
             }
         pb_st(out + (long)plane * H * W + (long)yy * W + xx, num / (den + 1e-5f));
+    }
     }
 }
 
@@ -262,11 +275,13 @@ unsigned grid_for(long n, int per_block = NT, int cap = 8192) {
 // ---- internal entry points used by api.hip --------------------------------------------------
 int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int P, long HW) {
     ProfScope prof(ctx, PB_PROF_HALO);
-    PB_HIP(hipMemsetAsync(nM, 0, sizeof(float) * P, ctx->stream));
     int bpp = (int)((HW + NT * 16 - 1) / (NT * 16));
     if (bpp > 256) bpp = 256;
     if (bpp < 1) bpp = 1;
-    hipLaunchKernelGGL(grad_energy_kernel, dim3(P * bpp), dim3(NT), 0, ctx->stream, gx, gy, nM, HW, bpp);
+    float *partial = static_cast<float *>(pb_scratch(ctx, "halo.partial", sizeof(float) * (size_t)P * bpp));
+    if (!partial) return PB_ERR_NOMEM;
+    hipLaunchKernelGGL(grad_energy_kernel, dim3(P * bpp), dim3(NT), 0, ctx->stream, gx, gy, partial, HW, bpp);
+    hipLaunchKernelGGL(grad_energy_fold_kernel, dim3(P), dim3(64), 0, ctx->stream, partial, nM, bpp);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
@@ -274,11 +289,11 @@ int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int
 int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
                   const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
                   int clamp01) {
-    dim3 grid(grid_for((long)H * W, NT, 2048), P);
+    dim3 grid(grid_for((long)H * W, NT, 2048), P < 65535 ? P : 65535);
     ProfScope prof(ctx, PB_PROF_HALO);
 #define PB_HALO(TX, TO)                                                                                           \
     hipLaunchKernelGGL((halo_kernel<TX, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
-                       x_plane, y, gx, gy, ox, nM, static_cast<TO *>(out), H, W, clamp01)
+                       x_plane, y, gx, gy, ox, nM, static_cast<TO *>(out), P, H, W, clamp01)
     if (x_dtype == PB_F32 && out_dtype == PB_F32) PB_HALO(float, float);
     else if (x_dtype == PB_F32 && out_dtype == PB_F16) PB_HALO(float, __half);
     else if (x_dtype == PB_F16 && out_dtype == PB_F32) PB_HALO(__half, float);
@@ -306,11 +321,11 @@ int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, int cur_dtype, co
 int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int out_dtype, int P, int H, int W) {
     const float sigma_color = 0.1f, sigma_space = 5.0f;
     const float ivc = 1.f / (2.f * sigma_color * sigma_color), ivs = 1.f / (2.f * sigma_space * sigma_space);
-    dim3 grid((W + 63) / 64, (H + 15) / 16, P);
+    dim3 grid((W + 63) / 64, (H + 15) / 16, P < 65535 ? P : 65535);
     ProfScope prof(ctx, PB_PROF_PREFILTER);
 #define PB_BIL(TI, TO)                                                                                           \
     hipLaunchKernelGGL((bilateral5_kernel<TI, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TI *>(in),  \
-                       static_cast<TO *>(out), H, W, ivc, ivs)
+                       static_cast<TO *>(out), P, H, W, ivc, ivs)
     if (in_dtype == PB_F32 && out_dtype == PB_F32) PB_BIL(float, float);
     else if (in_dtype == PB_F16 && out_dtype == PB_F32) PB_BIL(__half, float);
     else if (in_dtype == PB_F16 && out_dtype == PB_F16) PB_BIL(__half, __half);

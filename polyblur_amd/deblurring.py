@@ -31,10 +31,19 @@ import numpy as np
 from . import _capi as capi
 from .engine import get_engine
 
-_METHODS = {"fft": capi.PB_WRAP, "direct": capi.PB_ZERO, "direct_separable": capi.PB_ZERO}
+_METHODS = {"fft": capi.PB_WRAP, "direct": capi.PB_ZERO}
 _SUPPORT = {"full": capi.PB_SUPPORT_FULL, "adaptive": capi.PB_SUPPORT_ADAPTIVE}
 _PREFILTER = {"bilateral": capi.PB_PREFILTER_BILATERAL, "domain_transform": capi.PB_PREFILTER_DOMAIN_TRANSFORM,
               "normalized_convolution": capi.PB_PREFILTER_NORMALIZED_CONVOLUTION}
+
+
+def _check_image_size(h, w):
+    """The spectral derivative keeps whole image lines in LDS (include/polyblur_hip.h: pb_fft_length_supported)."""
+    lib = capi.load_library()
+    for n, what in ((int(h), "height"), (int(w), "width")):
+        if n >= 2 and not lib.pb_fft_length_supported(n):
+            raise ValueError("image %s %d is beyond the engine's in-LDS transform: sides up to 20480 are supported when "
+                             "all their prime factors are <= 7, up to 8192 otherwise" % (what, n))
 
 
 def _is_torch_tensor(x) -> bool:
@@ -44,6 +53,12 @@ def _is_torch_tensor(x) -> bool:
 def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles, n_interpolated_angles,
                    remove_halo, edgetaping, prefiltering, discard_saturation, multichannel_kernel, method, support,
                    prefilter, force_theta_deg=-1.0):
+    if method == "direct_separable":
+        # the reference's own separable path raises NameError (blur_estimation.py:77, filters.py:71,78); its intent
+        # -- an x pass followed by an oblique pass with linear interpolation, separable_gaussian2d.cpp:91-183 -- is
+        # an APPROXIMATION of the 25x25 kernel and must not silently stand in for 'direct'
+        raise NotImplementedError("method='direct_separable' is not built (rank-1 kernels already take the separable "
+                                  "stencil body under 'fft' and 'direct')")
     if method not in _METHODS:
         raise ValueError("%s not implemented" % method)          # reference: deblurring.py:119 (never raised there)
     if support not in _SUPPORT:
@@ -80,6 +95,19 @@ def _info_to_dicts(info, n_angles, n_interp):
     return out
 
 
+def _print_stage_times(prof, wall):
+    """verbose=True: device time per stage from hipEvents around every launch (the reference prints host
+    wall-clock per stage without synchronising, deblurring.py:59-90)."""
+    ms = {k: v[0] for k, v in prof.items()}
+    est = ms["gray"] + ms["grad_rows"] + ms["grad_cols"] + ms["params"]
+    print('-- blur estimation:   %1.5f  (gray/min-max %1.5f, row derivative %1.5f, column derivative + maxima %1.5f, '
+          'parameters %1.5f)' % (est / 1e3, ms["gray"] / 1e3, ms["grad_rows"] / 1e3, ms["grad_cols"] / 1e3, ms["params"] / 1e3))
+    deb = ms["conv"] + ms["halo"] + ms["prefilter"] + ms["other"]
+    print('-- deblurring:        %1.5f  (%d stencil passes %1.5f, halo masking %1.5f, prefilter %1.5f, other %1.5f)'
+          % (deb / 1e3, prof["conv"][1], ms["conv"] / 1e3, ms["halo"] / 1e3, ms["prefilter"] / 1e3, ms["other"] / 1e3))
+    print('-- polyblur (hip):    %1.5f s wall' % wall)
+
+
 def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_r=0.8, sigma_s=2.0, ker_size=25, q=0.0,
                         n_angles=6, n_interpolated_angles=30, remove_halo=False, edgetaping=False, prefiltering=False,
                         discard_saturation=False, multichannel_kernel=False, method='fft', verbose=False, *,
@@ -95,18 +123,22 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
         else:
             raise ValueError("expected an (H,W) or (H,W,C) array, got shape %r" % (img.shape,))
         x = np.ascontiguousarray(x, dtype=np.float32)
+        _check_image_size(*x.shape[-2:])
         opts = _build_options(x.shape[1], n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles,
                               n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
                               multichannel_kernel, method, support, prefilter)
         eng = get_engine(0 if device is None else int(device))
+        eng.set_stream(0)                                   # host arrays: the device's default stream
+        if verbose:
+            eng.profile_begin()
         res = eng.polyblur(x, opts, want_info=return_info)
+        if verbose:
+            _print_stage_times(eng.profile_end(), time() - start)
         out, info = res if return_info else (res, None)
         # utils.to_array (utils.py:24-31): squeeze, CHW -> HWC
         out = np.squeeze(out)
         if out.ndim == 3:
             out = np.ascontiguousarray(np.moveaxis(out, 0, -1))
-        if verbose:
-            print('-- polyblur (hip): %1.5f s' % (time() - start))
         return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
 
     if not _is_torch_tensor(img):
@@ -116,6 +148,7 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
         raise ValueError("expected a (B,C,H,W) tensor, got shape %r" % (tuple(img.shape),))
     if img.dtype not in (torch.float32, torch.float16):
         raise TypeError("tensor dtype must be float32 or float16 (the reference is float32-only)")
+    _check_image_size(*img.shape[-2:])
     opts = _build_options(img.shape[1], n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles,
                           n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
                           multichannel_kernel, method, support, prefilter)
@@ -127,15 +160,20 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
         out = torch.empty_like(xin)
         with torch.cuda.device(dev):
             eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            if verbose:
+                eng.profile_begin()
             info = eng.polyblur_ptr(xin.data_ptr(), out.data_ptr(), dtype, xin.shape, opts, want_info=return_info)
     else:
         eng = get_engine(0 if device is None else int(device))
+        eng.set_stream(0)
+        if verbose:
+            eng.profile_begin()
         arr = img.detach().contiguous().numpy()
         res = eng.polyblur(arr, opts, want_info=return_info)
         o, info = res if return_info else (res, None)
         out = torch.from_numpy(o)
     if verbose:
-        print('-- polyblur (hip): %1.5f s' % (time() - start))
+        _print_stage_times(eng.profile_end(), time() - start)
     return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
 
 
@@ -163,6 +201,7 @@ def polyblur_deblurring_uint8(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, 
                               n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
                               multichannel_kernel, method, support, prefilter)
         eng = get_engine(0 if device is None else int(device))
+        eng.set_stream(0)
         res = eng.polyblur_u8_hwc(x, opts, want_info=return_info)
         out, info = res if return_info else (res, None)
         out = out.reshape(img.shape)
@@ -185,6 +224,7 @@ def polyblur_deblurring_uint8(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, 
                 info = eng.polyblur_ptr(xin.data_ptr(), out.data_ptr(), capi.PB_U8, xin.shape, opts, want_info=return_info)
         else:
             eng = get_engine(0 if device is None else int(device))
+            eng.set_stream(0)
             res = eng.polyblur(img.detach().contiguous().numpy(), opts, want_info=return_info)
             o, info = res if return_info else (res, None)
             out = torch.from_numpy(o)
@@ -216,7 +256,20 @@ def patch_grid(h: int, w: int, patch_size, overlap: float):
                 pad_left=pad_left, n_i=n_i, n_j=n_j)
 
 
-def _patchwise_deblurring(images, patch_size, overlap, batch_size, kwargs):
+def _device_index(device):
+    """`device` of PolyblurDeblurring.forward (deblurring.py:322-330: where the patches are deblurred) -> GPU index."""
+    if device is None:
+        return None
+    if isinstance(device, int):
+        return device
+    import torch
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError("device=%r: the engine runs on a GPU only (there is no CPU implementation)" % (device,))
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def _patchwise_deblurring(images, patch_size, overlap, batch_size, kwargs, device=None):
     """PolyblurDeblurring.forward, patch branch (deblurring.py:269-340, fix-forward)."""
     import ctypes as C
 
@@ -225,8 +278,16 @@ def _patchwise_deblurring(images, patch_size, overlap, batch_size, kwargs):
         raise ValueError("patch decomposition expects a (B,C,H,W) tensor")
     if images.dtype not in (torch.float32, torch.float16):
         raise TypeError("tensor dtype must be float32 or float16")
+    if kwargs.pop("return_info", False):
+        raise TypeError("return_info is not available with patch_decomposition=True (one record set per patch group)")
     was_cuda = images.is_cuda
-    dev = (images.device.index if images.device.index is not None else torch.cuda.current_device()) if was_cuda else 0
+    want = _device_index(device)
+    if was_cuda:
+        dev = images.device.index if images.device.index is not None else torch.cuda.current_device()
+        if want is not None and want != dev:
+            raise ValueError("images live on cuda:%d but device=cuda:%d was requested" % (dev, want))
+    else:
+        dev = 0 if want is None else want                   # reference: patches.to(device) ... .cpu() (deblurring.py:322-330)
     x = images if was_cuda else images.to("cuda:%d" % dev)
     h, w = x.shape[-2:]
     if h % 2 == 1:                                      # :273-279 make the size even
@@ -238,8 +299,8 @@ def _patchwise_deblurring(images, patch_size, overlap, batch_size, kwargs):
     x = x.contiguous()
     B, Cc = x.shape[:2]
     g = patch_grid(h, w, patch_size, overlap)
-    if g["new_h"] - h > 2 * (h - 1) + 2 or g["ph"] < 2 or g["pw"] < 2:
-        raise ValueError("patch size incompatible with the image")
+    if g["ph"] < 2 or g["pw"] < 2 or g["step_h"] < 1 or g["step_w"] < 1:
+        raise ValueError("patch size / overlap incompatible: patches of at least 2x2 with a positive step are needed")
     eng = get_engine(dev)
     dtype = capi.PB_F32 if x.dtype == torch.float32 else capi.PB_F16
     n_p = g["n_i"] * g["n_j"]
@@ -303,12 +364,13 @@ class PolyblurDeblurring(_Base):
                                               edgetaping=edgetaping, prefiltering=prefiltering,
                                               discard_saturation=discard_saturation,
                                               multichannel_kernel=multichannel_kernel, method=method, q=q,
-                                              n_angles=n_angles, n_interpolated_angles=n_interpolated_angles, **extras))
+                                              n_angles=n_angles, n_interpolated_angles=n_interpolated_angles, **extras),
+                                         device=device)
         return polyblur_deblurring(images, n_iter=n_iter, c=c, b=b, alpha=alpha, beta=beta, ker_size=ker_size,
                                    sigma_s=sigma_s, sigma_r=sigma_r, remove_halo=remove_halo, edgetaping=edgetaping,
                                    prefiltering=prefiltering, discard_saturation=discard_saturation,
                                    multichannel_kernel=multichannel_kernel, method=method, q=q, n_angles=n_angles,
-                                   n_interpolated_angles=n_interpolated_angles, **extras)
+                                   n_interpolated_angles=n_interpolated_angles, device=_device_index(device), **extras)
 
     if _Base is _ModuleBase:              # pragma: no cover
         __call__ = forward

@@ -4,14 +4,21 @@ Images are independent (every reduction in the pipeline is per image), so the ba
 split into contiguous shards, one per rank (= one process per GPU): the first ``B mod n`` ranks get
 one extra image.  There is no data-path collective inside the hot path; RCCL over xGMI (the
 ``nccl`` backend of torch.distributed on ROCm) is used only to move shards from / to the root
-rank.  Transfers are per image and non-blocking, so that image k+1 travels while image k is
-deblurred and image k-1 returns.
+rank.
 
 Two usage patterns:
-  * shards already resident on every GPU (what bench.py times, "weak" scaling):
+  * shards already resident on every GPU (what ``bench.py`` times by default, "weak" scaling):
         out_local = polyblur_deblurring(x_local, ...)
-  * a whole batch on the root rank:
+  * a whole batch on the root rank (``bench.py --mode from_root``):
         out = deblur_from_root(x_or_None, shape, dtype, ...)      # returns the full batch on root
+
+``deblur_from_root`` moves one image per peer per step, all peers at once: step t is ONE grouped
+point-to-point exchange (``batch_isend_irecv`` = ncclGroupStart/End on RCCL) in which the root sends
+image t of every peer's shard and receives result t-2 from every peer, so the root's seven xGMI
+links carry traffic concurrently and each peer has image t arriving and result t-2 leaving while
+it deblurs image t-1 on its compute stream.  Nothing relies on message tags (RCCL ignores them):
+both sides enumerate the exchanges of a step in the same order.  Results land directly in the
+output batch (no staging buffers on the root).
 
 The compute function is a parameter so that the sharding logic can be exercised on CPU (gloo)
 without a GPU; in production it is polyblur_amd.polyblur_deblurring.
@@ -34,6 +41,27 @@ def shard_sizes(batch: int, world: int):
     return [shard_bounds(batch, world, r)[1] - shard_bounds(batch, world, r)[0] for r in range(world)]
 
 
+def exchange_plan(batch: int, world: int, root: int, rank: int, step: int):
+    """The point-to-point operations of `rank` in exchange step `step`, as (kind, peer, image index) in the
+    order both sides enumerate them: the root's list for a step, filtered to one peer, is that peer's list
+    with send and recv swapped.  Images travel root -> peer in step t, results come back in step t + 2."""
+    ops = []
+    peers = [r for r in range(world) if r != root] if rank == root else [rank]
+    for r in peers:
+        lo, hi = shard_bounds(batch, world, r)
+        if lo + step < hi:
+            ops.append(("send" if rank == root else "recv", r if rank == root else root, lo + step))
+        if step >= 2 and lo + step - 2 < hi:
+            ops.append(("recv" if rank == root else "send", r if rank == root else root, lo + step - 2))
+    return ops
+
+
+def exchange_steps(batch: int, world: int, root: int) -> int:
+    """Number of exchange steps: the largest peer shard plus the two-step return lag (0 without peers)."""
+    sizes = [n for r, n in enumerate(shard_sizes(batch, world)) if r != root]
+    return (max(sizes) + 2) if sizes and max(sizes) > 0 else 0
+
+
 def deblur_from_root(images, shape: Sequence[int], dtype, compute: Optional[Callable] = None, device=None,
                      root: int = 0, group=None, **kwargs):
     """Scatter a (B,C,H,W) batch that lives on `root`, deblur every shard where it lands, gather
@@ -49,41 +77,47 @@ def deblur_from_root(images, shape: Sequence[int], dtype, compute: Optional[Call
     img_shape = (1,) + tuple(int(v) for v in shape[1:])
     if device is None:
         device = images.device if (rank == root and images is not None) else torch.device("cpu")
-    out_full = None
+    nsteps = exchange_steps(B, world, root)
+
+    def post(ops, tensor_of):
+        if not ops:
+            return []
+        p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, tensor_of(kind, k), peer, group) for kind, peer, k in ops]
+        return dist.batch_isend_irecv(p2p)
+
     if rank == root:
         if images is None or tuple(images.shape) != tuple(shape):
             raise ValueError("root must pass the full batch with the announced shape")
+        images = images.contiguous()
         out_full = torch.empty_like(images)
-        sends = []
-        for r in range(world):
-            if r == root:
-                continue
-            a, b = shard_bounds(B, world, r)
-            for k in range(a, b):                                   # one message per image: pipelined
-                sends.append(dist.isend(images[k:k + 1].contiguous(), dst=r, group=group, tag=k))
-        recvs = []
-        for r in range(world):
-            if r == root:
-                continue
-            a, b = shard_bounds(B, world, r)
-            for k in range(a, b):
-                buf = torch.empty(img_shape, dtype=dtype, device=device)
-                recvs.append((k, buf, dist.irecv(buf, src=r, group=group, tag=B + k)))
-        for k in range(lo, hi):                                     # root's own shard, overlapped with the traffic
-            out_full[k:k + 1] = compute(images[k:k + 1].contiguous(), **kwargs)
-        for w in sends:
+        pending = []
+        own = list(range(lo, hi))
+        per_step = -(-len(own) // nsteps) if nsteps else len(own)
+        for t in range(nsteps):
+            pending += post(exchange_plan(B, world, root, rank, t),
+                            lambda kind, k: images[k:k + 1] if kind == "send" else out_full[k:k + 1])
+            for k in own[t * per_step:(t + 1) * per_step]:         # the root's own shard, spread over the steps
+                out_full[k:k + 1] = compute(images[k:k + 1], **kwargs)
+        for k in own[nsteps * per_step:]:
+            out_full[k:k + 1] = compute(images[k:k + 1], **kwargs)
+        for w in pending:
             w.wait()
-        for k, buf, w in recvs:
-            w.wait()
-            out_full[k:k + 1] = buf
         return out_full
-    bufs = [torch.empty(img_shape, dtype=dtype, device=device) for _ in range(lo, hi)]
-    works = [dist.irecv(bufs[i], src=root, group=group, tag=lo + i) for i in range(hi - lo)]
-    back = []
-    for i, w in enumerate(works):
-        w.wait()                                                    # image i is here; i+1.. still in flight
-        res = compute(bufs[i], **kwargs).contiguous()
-        back.append((res, dist.isend(res, dst=root, group=group, tag=B + lo + i)))
-    for _, w in back:
-        w.wait()
+
+    n = hi - lo
+    bufs = [torch.empty(img_shape, dtype=dtype, device=device) for _ in range(min(n, 3))]   # ring: arriving / in work / spare
+    res = {}
+    works = {}
+    for t in range(nsteps):
+        ops = exchange_plan(B, world, root, rank, t)
+        works[t] = post(ops, lambda kind, k: bufs[(k - lo) % 3] if kind == "recv" else res[k])
+        i = t - 1                                                   # image i arrived in step t-1: deblur it now
+        if 0 <= i < n:
+            for w in works.pop(t - 1):
+                w.wait()
+            res[lo + i] = compute(bufs[i % 3], **kwargs).contiguous()
+            res.pop(lo + i - 3, None)                               # its send (step i+1) was waited for in step i+2
+    for ws in works.values():
+        for w in ws:
+            w.wait()
     return None

@@ -292,10 +292,13 @@ _elock = threading.Lock()
 
 
 def get_engine(device: int = 0) -> Engine:
-    """The process-wide Engine of a GPU (created on first use)."""
+    """The calling thread's Engine for a GPU (created on first use).  A pb_ctx is not thread-safe and owns its
+    scratch buffers, so every host thread gets its own; within a thread, calls on different streams are ordered
+    by pb_set_stream (the new stream waits for the work queued on the previous one)."""
+    key = (int(device), threading.get_ident())
     with _elock:
-        e = _engines.get(device)
+        e = _engines.get(key)
         if e is None or e.ctx is None:
             e = Engine(device)
-            _engines[device] = e
+            _engines[key] = e
         return e
