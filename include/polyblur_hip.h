@@ -30,11 +30,12 @@
 extern "C" {
 #endif
 
-#define PB_VERSION 100           /* major*10000 + minor*100 + patch */
+#define PB_VERSION 200           /* major*10000 + minor*100 + patch */
 #define PB_KSIZE 25              /* kernel support of the reference (ker_size=25, deblurring.py:23) */
 #define PB_KRAD 12
 #define PB_MAX_ANGLES 13         /* n_angles + 1 <= 13 */
 #define PB_MAX_INTERP 64         /* n_interpolated_angles <= 64 */
+#define PB_MAX_PHASES 175        /* 25 kernel rows x 7 window chunks */
 
 typedef struct pb_ctx pb_ctx;
 
@@ -62,10 +63,12 @@ typedef enum pb_prefilter { PB_PREFILTER_NONE = 0, PB_PREFILTER_BILATERAL = 1,
                             PB_PREFILTER_NORMALIZED_CONVOLUTION = 3 /* NC variant,       N = 1  */ } pb_prefilter;
 
 /* Kernel-support policy: PB_SUPPORT_FULL evaluates every tap of the reference's 25x25 kernel
- * that is not exactly 0.0f (outer rows / columns whose taps all underflowed to zero are skipped,
- * which is bit-identical to evaluating them); PB_SUPPORT_ADAPTIVE also drops taps whose marginal
- * mass is < 1e-8 -- results agree to fp32 rounding.  Either way the evaluated radius is rounded
- * up to 4, 8 or 12.                                                                      */
+ * that is not exactly 0.0f (4-tap segments of a kernel row, and outer rows / columns, whose taps
+ * all underflowed to zero are skipped, which is bit-identical to evaluating them);
+ * PB_SUPPORT_ADAPTIVE also drops the rows / columns whose marginal mass is < 1e-8 and, inside
+ * that box, the row segments whose taps are all < 1e-10 (the corners outside the Gaussian's
+ * ellipse) -- results agree to fp32 rounding.  The staged halo is rounded up to 4, 6, 8, 10
+ * or 12 samples (4, 8 or 12 for rank-1 kernels).                                          */
 typedef enum pb_support { PB_SUPPORT_FULL = 0, PB_SUPPORT_ADAPTIVE = 1,
                           /* test/bench flag, OR-ed in: never take the rank-1 (separable) path */
                           PB_SUPPORT_FORCE_GENERAL = 16 } pb_support;
@@ -100,15 +103,22 @@ typedef struct pb_blur_info {
     float theta;                        /* radians, :167 */
     float sigma, rho;                   /* :171-185 */
     int32_t separable;                  /* 1 if the 25x25 kernel is rank-1 (theta % 90 == 0 or sigma == rho) */
-    int32_t radius;                     /* support radius class actually evaluated: 4, 8 or 12 */
+    int32_t radius;                     /* support radius class actually evaluated: 4, 6, 8, 10 or 12 */
     float kernel[PB_KSIZE * PB_KSIZE];  /* :211-232, row-major [y][x] */
     float kx[PB_KSIZE], ky[PB_KSIZE];   /* marginals kx[j] = sum_i k[i][j], ky[i] = sum_j k[i][j];
                                            the exact rank-1 factors when `separable` */
     float acorr_y[PB_KSIZE], acorr_x[PB_KSIZE]; /* autocorrelation of ky / kx at lags 0..24: the closed
                                            form of edgetaper_alpha's 1-D FFTs (edgetaper.py:11-21) */
-    float gtaps[PB_KSIZE * 32];         /* kernel rows re-laid for the tile stencil: row y = {0,0,0, k[y][0..24], 0,0,0,0} */
-    float gtaps_odd[PB_KSIZE * 32];     /* the same rows shifted by one tap (gtaps_odd[y][n] = gtaps[y][n+1]): the second
-                                           alignment of tap pairs for the packed-FMA stencil */
+    float gtaps[(PB_KSIZE + 1) * 32];   /* kernel rows re-laid for the tile stencil: row y = {0,0,0, k[y][0..24], 0,0,0,0};
+                                           row 25 is all zeros (the taps of the list's filler phases) */
+    float gtaps_odd[(PB_KSIZE + 1) * 32]; /* the same rows shifted by one tap (gtaps_odd[y][n] = gtaps[y][n+1]): the second
+                                           alignment of adjacent tap pairs for the packed-FMA stencil */
+    int32_t nphase[3];                  /* general (non rank-1) stencil: number of (kernel row, 4-tap segment) phases of
+                                           kind 0 (inner chunk of a window row), 1 (first chunk), 2 (last chunk); each
+                                           count is even (an all-zero filler phase pads an odd one)                  */
+    int32_t phase[PB_MAX_PHASES + 9];   /* their descriptors, grouped by kind, row-major inside a kind:
+                                           LDS row | segment << 8 | tap row << 16, rows counted from the top of the radius
+                                           class (0 .. 2*radius), segment = window chunk 0 .. radius/2; three pad entries (read ahead, never evaluated) */
 } pb_blur_info;
 
 /* ---- context ------------------------------------------------------------------------- */

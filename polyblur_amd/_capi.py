@@ -15,6 +15,7 @@ import numpy as np
 PB_KSIZE = 25
 PB_MAX_ANGLES = 13
 PB_MAX_INTERP = 64
+PB_MAX_PHASES = 175
 
 PB_F32, PB_F16, PB_U8 = 0, 1, 2
 PB_WRAP, PB_ZERO = 0, 1
@@ -53,7 +54,8 @@ class pb_blur_info(C.Structure):
         ("sigma", C.c_float), ("rho", C.c_float), ("separable", C.c_int32), ("radius", C.c_int32),
         ("kernel", C.c_float * (PB_KSIZE * PB_KSIZE)), ("kx", C.c_float * PB_KSIZE), ("ky", C.c_float * PB_KSIZE),
         ("acorr_y", C.c_float * PB_KSIZE), ("acorr_x", C.c_float * PB_KSIZE),
-        ("gtaps", C.c_float * (PB_KSIZE * 32)), ("gtaps_odd", C.c_float * (PB_KSIZE * 32)),
+        ("gtaps", C.c_float * ((PB_KSIZE + 1) * 32)), ("gtaps_odd", C.c_float * ((PB_KSIZE + 1) * 32)),
+        ("nphase", C.c_int32 * 3), ("phase", C.c_int32 * (PB_MAX_PHASES + 9)),
     ]
 
 
@@ -61,8 +63,8 @@ INFO_DTYPE = np.dtype([
     ("gray_min", "<f4"), ("gray_max", "<f4"), ("mags", "<f4", (PB_MAX_ANGLES,)), ("interp", "<f4", (PB_MAX_INTERP,)),
     ("i_min", "<i4"), ("theta", "<f4"), ("sigma", "<f4"), ("rho", "<f4"), ("separable", "<i4"), ("radius", "<i4"),
     ("kernel", "<f4", (PB_KSIZE, PB_KSIZE)), ("kx", "<f4", (PB_KSIZE,)), ("ky", "<f4", (PB_KSIZE,)),
-    ("acorr_y", "<f4", (PB_KSIZE,)), ("acorr_x", "<f4", (PB_KSIZE,)), ("gtaps", "<f4", (PB_KSIZE, 32)),
-    ("gtaps_odd", "<f4", (PB_KSIZE, 32)),
+    ("acorr_y", "<f4", (PB_KSIZE,)), ("acorr_x", "<f4", (PB_KSIZE,)), ("gtaps", "<f4", (PB_KSIZE + 1, 32)),
+    ("gtaps_odd", "<f4", (PB_KSIZE + 1, 32)), ("nphase", "<i4", (3,)), ("phase", "<i4", (PB_MAX_PHASES + 9,)),
 ])
 assert INFO_DTYPE.itemsize == C.sizeof(pb_blur_info)
 

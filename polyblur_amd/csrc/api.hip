@@ -56,7 +56,9 @@ void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes) {
 }
 
 static size_t dsize(int dtype) { return dtype == PB_F16 ? 2 : (dtype == PB_U8 ? 1 : 4); }
-static int pitch4(int w) { return (w + 3) & ~3; }
+// rows of the engine's own padded planes start on 128-byte lines (the stencil tiles are laid out so that their
+// windows then begin on a line as well: conv_common.h, tile_x_origin)
+static int pitch_lines(int w) { return (w + 31) & ~31; }
 
 extern "C" {
 
@@ -178,17 +180,17 @@ struct Geometry {
 Geometry geometry(int B, int C, int H, int W) {
     Geometry g;
     g.B = B; g.C = C; g.H = H; g.W = W; g.P = B * C;
-    g.Hp = H + 2 * PB_PAD; g.Wp = W + 2 * PB_PAD; g.pp = pitch4(g.Wp);
+    g.Hp = H + 2 * PB_PAD; g.Wp = W + 2 * PB_PAD; g.pp = pitch_lines(g.Wp);
     g.pplane = (long)g.Hp * g.pp;
     g.HW = (long)H * W;
     return g;
 }
 
-ConvPass base_pass(const Geometry &g, const pb_blur_info *info, int boundary, int force_full) {
+ConvPass base_pass(const Geometry &g, const pb_blur_info *info, int boundary) {
     ConvPass p;
     memset(&p, 0, sizeof(p));
     p.H = g.H; p.W = g.W; p.C = g.C; p.P = g.P; p.info = info; p.boundary = boundary;
-    p.scale = 1.f; p.coef = 0.f; p.epilogue = EPI_HORNER; p.clamp01 = 0; p.force_full = force_full;
+    p.scale = 1.f; p.coef = 0.f; p.epilogue = EPI_HORNER; p.clamp01 = 0;
     return p;
 }
 void set_in_virtual(ConvPass &p, const Geometry &g, const void *ptr, int dtype) {
@@ -214,7 +216,7 @@ void set_out_interior(ConvPass &p, const Geometry &g, void *ptr, int dtype) {
 // (virtual replicate pad).  Returns the padded fp32 result in *result (one of the two scratch planes).
 int run_edgetaper(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype, const pb_blur_info *info, int boundary,
                   float *pa, float *pb, float **result) {
-    ConvPass p = base_pass(g, info, boundary, 0);
+    ConvPass p = base_pass(g, info, boundary);
     p.epilogue = EPI_TAPER;
     set_in_virtual(p, g, src, src_dtype);
     set_x_virtual(p, g, src, src_dtype);
@@ -234,9 +236,9 @@ int run_edgetaper(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype
 // X is either the un-padded image (virtual pad) or a padded fp32 image (after edgetaper).
 int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype, const float *xpadded,
                    const pb_blur_info *info, float alpha, float beta, int boundary, float *t1, float *t2, void *dst,
-                   int dst_dtype, int clamp01, int force_full) {
+                   int dst_dtype, int clamp01) {
     const float a3 = alpha / 2 - beta + 2, a2 = 3 * beta - alpha - 6, a1 = 5 - 3 * beta + alpha / 2;
-    ConvPass p = base_pass(g, info, boundary, force_full);
+    ConvPass p = base_pass(g, info, boundary);
     auto set_x = [&](ConvPass &q) { if (xpadded) set_x_padded(q, g, xpadded); else set_x_virtual(q, g, xsrc, x_dtype); };
     // t1 = K * (a3 x) + a2 x
     if (xpadded) set_in_padded(p, g, xpadded); else set_in_virtual(p, g, xsrc, x_dtype);
@@ -262,7 +264,7 @@ struct InverseScratch {
 // src: what gets deconvolved (cur, or the smooth component).  dst: (B,C,H,W) of dst_dtype.
 int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype, void *dst, int dst_dtype,
                    const pb_blur_info *info, float alpha, float beta, int boundary, int edgetaping, int remove_halo,
-                   const float *g0x, const float *g0y, const float *nM, int final_clamp, int force_full) {
+                   const float *g0x, const float *g0y, const float *nM, int final_clamp) {
     float *t1 = static_cast<float *>(pb_scratch(ctx, "inv.t1", sizeof(float) * g.P * g.pplane));
     float *t2 = static_cast<float *>(pb_scratch(ctx, "inv.t2", sizeof(float) * g.P * g.pplane));
     if (!t1 || !t2) return PB_ERR_NOMEM;
@@ -277,11 +279,11 @@ int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtyp
     }
     if (!remove_halo)
         return run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, dst, dst_dtype,
-                              final_clamp, force_full);
+                              final_clamp);
     float *y = static_cast<float *>(pb_scratch(ctx, "inv.y", sizeof(float) * g.P * g.HW));
     float *ox = static_cast<float *>(pb_scratch(ctx, "inv.ox", sizeof(float) * g.P * g.HW));
     if (!y || !ox) return PB_ERR_NOMEM;
-    int rc = run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, y, PB_F32, 0, force_full);
+    int rc = run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, y, PB_F32, 0);
     if (rc) return rc;
     rc = pb_fourier_gradients_impl(ctx, y, g.P, g.H, g.W, ox, nullptr);     // only gout_x is used (deblurring.py:174)
     if (rc) return rc;
@@ -358,7 +360,7 @@ int pb_inverse_filter(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (rc) return rc;
     }
     return inverse_filter(ctx, g, in, dtype, out, dtype, dev_info, alpha, beta, boundary, edgetaping, remove_halo, grad0_x,
-                          grad0_y, nM, 1, 0);
+                          grad0_y, nM, 1);
 }
 
 int pb_convolve2d(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp, int Wp, const pb_blur_info *dev_info,
@@ -368,7 +370,7 @@ int pb_convolve2d(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp
     // The given image IS the padded domain: address it as a padded source with pitch Wp.
     Geometry g = geometry(B, C, Hp - 2 * PB_PAD, Wp - 2 * PB_PAD);
     g.pp = Wp; g.pplane = (long)Hp * Wp;
-    ConvPass p = base_pass(g, dev_info, boundary, 0);
+    ConvPass p = base_pass(g, dev_info, boundary);
     set_in_padded(p, g, in); set_x_padded(p, g, in); set_out_padded(p, g, out);
     p.scale = 1.f; p.coef = 0.f;
     return pb_launch_conv(ctx, p);
@@ -382,7 +384,7 @@ int pb_edgetaper(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp,
     g.pp = Wp; g.pplane = (long)Hp * Wp;
     float *tmp = static_cast<float *>(pb_scratch(ctx, "taper.tmp", sizeof(float) * g.P * g.pplane));
     if (!tmp) return PB_ERR_NOMEM;
-    ConvPass p = base_pass(g, dev_info, boundary, 0);
+    ConvPass p = base_pass(g, dev_info, boundary);
     p.epilogue = EPI_TAPER;
     set_in_padded(p, g, in); set_x_padded(p, g, in); set_out_padded(p, g, out);
     int rc = pb_launch_conv(ctx, p);
@@ -519,7 +521,6 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (!smooth || !ybuf) return PB_ERR_NOMEM;
     }
     const void *cur = in;
-    const int force_full = 0;          // the record's radius already encodes the policy (estimate.hip: finish_record)
     for (int it = 0; it < n_iter; ++it) {
         // the last iteration must land in `out`; alternate between out and tmpimg before that
         void *dst = ((n_iter - 1 - it) % 2 == 0) ? out : tmpimg;
@@ -530,7 +531,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (rc) return rc;
         if (opt->prefilter == PB_PREFILTER_NONE) {
             rc = inverse_filter(ctx, g, cur, cur_dtype, dst, dst_dtype, info, opt->alpha, opt->beta, opt->boundary,
-                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1, force_full);
+                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1);
             if (rc) return rc;
         } else {
             if (opt->prefilter == PB_PREFILTER_BILATERAL)
@@ -541,7 +542,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
                 rc = pb_dt_filter_impl(ctx, cur, nullptr, cur_dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
             if (rc) return rc;
             rc = inverse_filter(ctx, g, smooth, PB_F32, ybuf, PB_F32, info, opt->alpha, opt->beta, opt->boundary,
-                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1, force_full);
+                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1);
             if (rc) return rc;
             rc = pb_recombine(ctx, ybuf, cur, cur_dtype, smooth, dst, dst_dtype, n);
             if (rc) return rc;
@@ -626,11 +627,11 @@ int pb_time_inner_loop(pb_ctx *ctx, const void *in, void *out, int dtype, int B,
     float *t1 = static_cast<float *>(pb_scratch(ctx, "inv.t1", sizeof(float) * g.P * g.pplane));
     float *t2 = static_cast<float *>(pb_scratch(ctx, "inv.t2", sizeof(float) * g.P * g.pplane));
     if (!t1 || !t2) return PB_ERR_NOMEM;
-    rc = run_polynomial(ctx, g, in, dtype, nullptr, dev_info, alpha, beta, boundary, t1, t2, out, dtype, 1, 0);   // warm
+    rc = run_polynomial(ctx, g, in, dtype, nullptr, dev_info, alpha, beta, boundary, t1, t2, out, dtype, 1);   // warm
     if (rc) return rc;
     PB_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     for (int r = 0; r < reps; ++r) {
-        rc = run_polynomial(ctx, g, in, dtype, nullptr, dev_info, alpha, beta, boundary, t1, t2, out, dtype, 1, 0);
+        rc = run_polynomial(ctx, g, in, dtype, nullptr, dev_info, alpha, beta, boundary, t1, t2, out, dtype, 1);
         if (rc) return rc;
     }
     PB_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -119,7 +119,6 @@ struct ConvPass {
     int boundary;
     int epilogue;
     int clamp01;
-    int force_full;      // ignore info->radius, evaluate all 25 taps
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);

@@ -30,39 +30,130 @@ namespace {
 // general kernels: workgroup tile body
 // =============================================================================================
 
-// One window row of the general stencil: element m of the thread's window (column c0 - R + m) feeds
-// the four outputs c0 .. c0+3 with taps t[m+3], t[m+2], t[m+1], t[m] (t = the kernel row, zero padded by
-// 3).  Two packed FMAs per element: (x,y) += (t[m+3], t[m+2]) * s,  (z,w) += (t[m+1], t[m]) * s, with
-// the tap pair in an aligned SGPR pair -- TA[i] = (t[2i], t[2i+1]) or TB[i] = (t[2i+1], t[2i+2]) -- read
-// swapped through op_sel, and the sample broadcast from its register pair.
-template <int R, int M, int NP> struct GenRow {
-    static __device__ __forceinline__ void run(f2 &axy, f2 &azw, const f2 (&TA)[NP], const f2 (&TB)[NP], const f2 (&d)[R + 2]) {
-        constexpr bool full = R == PB_KRAD;              // at R = 12 the padding taps are exact zeros: skip them
-        if constexpr (!(full && M >= 2 * R + 2)) {       // (t[m+3], t[m+2])
-            constexpr int n = M + 2;
-            if constexpr ((n & 1) == 0) pk_bcast_data<1, M & 1>(axy, TA[n >> 1], d[M >> 1]);
-            else pk_bcast_data<1, M & 1>(axy, TB[(n - 1) >> 1], d[M >> 1]);
-        }
-        if constexpr (!(full && M < 2)) {                // (t[m+1], t[m])
-            if constexpr ((M & 1) == 0) pk_bcast_data<1, M & 1>(azw, TA[M >> 1], d[M >> 1]);
-            else pk_bcast_data<1, M & 1>(azw, TB[(M - 1) >> 1], d[M >> 1]);
-        }
-        if constexpr (M + 1 < 2 * R + 4) GenRow<R, M + 1, NP>::run(axy, azw, TA, TB, d);
+// The general stencil is evaluated as a list of PHASES read from the image's record (estimate.hip: finish_record):
+// phase = (kernel row dy, window chunk q).  In a phase a thread reads, for each of its four output rows r, the four
+// window elements m = 4q .. 4q+3 of LDS row r + dy (one ds_read_b128) and feeds its four outputs c0 .. c0+3:
+// element m meets the taps t[m+3], t[m+2], t[m+1], t[m] (t = the kernel row, zero padded by 3 on the left), i.e. two
+// packed FMAs  (x,y) += (t[m+3], t[m+2]) * s,  (z,w) += (t[m+1], t[m]) * s  with the tap pair in an aligned SGPR pair
+// read swapped through op_sel and the sample broadcast from its register.  The seven taps a chunk meets are loaded
+// twice, from t[n0] and from t[n0+1], which gives both alignments of adjacent pairs.  Phases whose taps are all dead
+// (exact zeros; under the adaptive policy also the corners outside the Gaussian's ellipse) are simply not in the list.
+//
+// The loop is software-pipelined by hand, one step ahead: while the 8 packed FMAs of (phase, r) issue, the window
+// chunk of (phase, r+1) -- or of the next phase's r = 0 -- is in flight from LDS, and during a whole phase the taps of
+// the next phase and the descriptor of the one after are in flight from the scalar cache.  Every wait is therefore for
+// something issued at least 8 FMAs earlier, and is placed (wait_for) BEFORE the next prefetch is issued, so that the
+// lgkmcnt(0) the mixed LDS / scalar traffic forces never drains a load that has only just been issued.
+struct PhaseTaps { f2 a[3], b[3]; };      // a[k] = (t[n0+2k], t[n0+2k+1]),  b[k] = (t[n0+2k+1], t[n0+2k+2])
+
+// (the odd-aligned pairs come from the record's second, shifted copy of the taps: building them from the first with
+// scalar moves would put a wait for the scalar loads right behind their issue)
+__device__ __forceinline__ void load_phase_taps(PhaseTaps &T, const PB_CONSTANT float *t, const PB_CONSTANT float *todd) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        T.a[k] = (f2){t[2 * k], t[2 * k + 1]};
+        T.b[k] = (f2){todd[2 * k], todd[2 * k + 1]};
     }
+}
+// a use of v the compiler cannot see through: whatever is still loading v is waited for HERE
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wait_for(f4 &v) { asm volatile("" : "+v"(v)); }
+
+// The packed FMAs of one (phase, r) step as ONE asm statement (nothing is scheduled in between, no pad states are
+// inserted between the dependent pairs): element j of the chunk feeds (x,y) with the tap pair starting at n0+j+2 and
+// (z,w) with the pair starting at n0+j, both read swapped.  KIND 1: first chunk of a window row -- its elements 0, 1
+// meet only padding on the (z,w) side; KIND 2: last chunk -- elements 2, 3 meet only padding on the (x,y) side.
+template <int KIND> __device__ __forceinline__ void chunk_fma(f2 &axy, f2 &azw, const PhaseTaps &T, const f4 &v) {
+    const f2 lo = v.xy, hi = v.zw;
+    if (KIND == 0)
+        asm("v_pk_fma_f32 %0, %2, %8, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %1, %3, %8, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %0, %5, %8, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %1, %6, %8, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %0, %4, %9, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %1, %2, %9, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %0, %7, %9, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]"
+            : "+v"(axy), "+v"(azw)
+            : "s"(T.a[1]), "s"(T.a[0]), "s"(T.a[2]), "s"(T.b[1]), "s"(T.b[0]), "s"(T.b[2]), "v"(lo), "v"(hi));
+    if (KIND == 1)
+        asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %0, %3, %7, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %1, %2, %7, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %0, %5, %7, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]"
+            : "+v"(axy), "+v"(azw)
+            : "s"(T.a[1]), "s"(T.a[2]), "s"(T.b[1]), "s"(T.b[2]), "v"(lo), "v"(hi));
+    if (KIND == 2)
+        asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %1, %3, %6, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %1, %5, %6, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 %1, %2, %7, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]"
+            : "+v"(axy), "+v"(azw)
+            : "s"(T.a[1]), "s"(T.a[0]), "s"(T.b[1]), "s"(T.b[0]), "v"(lo), "v"(hi));
+}
+
+// descriptor (LDS row | chunk << 8 | tap row << 16) -> tap offset row * 32 + 4 * chunk, LDS offset row * LP + 4 * chunk
+#define PB_TAP_OFF(d) ((((d) >> 16) << 5) + (((d) >> 6) & 0x1c))
+#define PB_LDS_OFF(d, LP) (((d) & 255) * (LP) + (((d) >> 6) & 0x1c))
+
+struct PhaseCursor {
+    int d0, d1, d2;                         // descriptors of the current phase and the two after it
+    const PB_CONSTANT int *next;            // where the descriptor after those is read from
+    const PB_CONSTANT float *taps, *taps_odd;
 };
+
+// One phase: TC = its taps, `cur` = its r = 0 chunk (both requested a phase ago).  Issues, in its first step, the
+// scalar loads of the NEXT phase's taps (into TN) and of the descriptor three phases ahead; prefetches every chunk one
+// step ahead; leaves the next phase's r = 0 chunk in `cur`.
+template <int KIND, int LP>
+__device__ __forceinline__ void run_phase(f2 (&axy)[4], f2 (&azw)[4], const PhaseTaps &TC, PhaseTaps &TN, f4 &cur,
+                                          PhaseCursor &pc, const float *base) {
+    const float *rowc = base + PB_LDS_OFF(pc.d0, LP), *rown = base + PB_LDS_OFF(pc.d1, LP);
+    f4 nxt;
+    int d3 = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        wait_for(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (r == 0) {
+            d3 = *pc.next;
+            load_phase_taps(TN, pc.taps + PB_TAP_OFF(pc.d1), pc.taps_odd + PB_TAP_OFF(pc.d1));
+        }
+        nxt = *reinterpret_cast<const f4 *>(r < 3 ? rowc + (r + 1) * LP : rown);
+        __builtin_amdgcn_sched_barrier(0);
+        chunk_fma<KIND>(axy[r], azw[r], TC, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    pc.d0 = pc.d1; pc.d1 = pc.d2; pc.d2 = d3; ++pc.next;
+}
+
+// All `count` (even, > 0) phases of one kind.  On entry and on exit TA holds the taps of the cursor's current phase.
+template <int KIND, int LP>
+__device__ __forceinline__ void run_phases(f2 (&axy)[4], f2 (&azw)[4], PhaseTaps &TA, f4 &cur, int count, PhaseCursor &pc,
+                                           const float *base) {
+    PhaseTaps TB;
+#pragma unroll 1
+    for (int i = 0; i < count; i += 2) {
+        run_phase<KIND, LP>(axy, azw, TA, TB, cur, pc, base);
+        run_phase<KIND, LP>(axy, azw, TB, TA, cur, pc, base);
+    }
+}
 
 template <typename TIn, typename TX, typename TOut, int R>
 __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info *info, const TIn *ipl, const TX *xpl,
                                           TOut *opl, int tile, int tiles_x, float *smem) {
-    constexpr int LW = GT + 2 * R, LH = GT + 2 * R, NTAP = 2 * R + 1;
-    constexpr int LP = LW;                     // unpadded LDS rows (5 workgroups per CU); conflicts avoided by YROT
+    constexpr int LW = GT + 2 * R, LH = GT + 2 * R;
+    constexpr int LP = LW;                     // unpadded LDS rows; conflicts avoided by YROT
     constexpr int YROT = (16 - (LP % 16)) % 16;  // odd row groups start YROT column groups further along the row
-    constexpr int WCH = 1 + R / 2;             // float4 chunks per window row
-    constexpr int NP = 2 * WCH + 2;            // tap pairs per copy (taps n = 0 .. 4 WCH + 3)
     constexpr int PR = 4;
     const OutRegion rg = out_region(a);
     const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
-    const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
+    const int oy0 = rg.y_lo + ty * GT, ox0 = tile_x_origin(a.out_kind) + tx * GT;
     if (oy0 >= rg.y_hi) return;
     const int tid = threadIdx.x;
     // 16 column groups x 16 row groups.  The two row groups that share a 32-lane half are 4 LDS rows
@@ -73,30 +164,22 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     f2 axy[PR], azw[PR];
 #pragma unroll
     for (int r = 0; r < PR; ++r) { axy[r] = (f2){0.f, 0.f}; azw[r] = (f2){0.f, 0.f}; }
-    // gtaps[y] = {0,0,0, k[y][0..24], 0,0,0,0}, gtaps_odd[y][n] = gtaps[y][n+1]; class R reads from column 12-R
-    const PB_CONSTANT float *ta = as_constant(info->gtaps) + (PB_KRAD - R) * 32 + (PB_KRAD - R);
-    const PB_CONSTANT float *tb = as_constant(info->gtaps_odd) + (PB_KRAD - R) * 32 + (PB_KRAD - R);
+    // gtaps[y] = {0,0,0, k[y][0..24], 0,0,0,0}; class R starts at kernel row / column 12 - R
+    const PB_CONSTANT pb_blur_info *ci = as_constant(info);
+    const PB_CONSTANT int *plist = ci->phase;
     const float *base = smem + (rgp * PR) * LP + 4 * g;
-#pragma unroll 1
-    for (int dy = 0; dy < NTAP; ++dy) {
-        f2 TA[NP], TB[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            TA[i] = (f2){ta[dy * 32 + 2 * i], ta[dy * 32 + 2 * i + 1]};
-            TB[i] = (f2){tb[dy * 32 + 2 * i], tb[dy * 32 + 2 * i + 1]};
-        }
-#pragma unroll
-        for (int r = 0; r < PR; ++r) {
-            const float4 *src = reinterpret_cast<const float4 *>(base + (r + dy) * LP);
-            f2 d[R + 2];
-#pragma unroll
-            for (int q = 0; q < WCH; ++q) {
-                const float4 v = src[q];
-                d[2 * q] = (f2){v.x, v.y};
-                d[2 * q + 1] = (f2){v.z, v.w};
-            }
-            GenRow<R, 0, NP>::run(axy[r], azw[r], TA, TB, d);
-        }
+    const int n_mid = ci->nphase[0], n_first = ci->nphase[1], n_last = ci->nphase[2];
+    if (n_mid + n_first + n_last > 0) {
+        PhaseCursor pc;
+        pc.d0 = plist[0]; pc.d1 = plist[1]; pc.d2 = plist[2]; pc.next = plist + 3;
+        pc.taps = ci->gtaps + (PB_KRAD - R) * 32 + (PB_KRAD - R);
+        pc.taps_odd = ci->gtaps_odd + (PB_KRAD - R) * 32 + (PB_KRAD - R);
+        PhaseTaps TA;
+        load_phase_taps(TA, pc.taps + PB_TAP_OFF(pc.d0), pc.taps_odd + PB_TAP_OFF(pc.d0));
+        f4 cur = *reinterpret_cast<const f4 *>(base + PB_LDS_OFF(pc.d0, LP));
+        if (n_mid) run_phases<0, LP>(axy, azw, TA, cur, n_mid, pc, base);
+        if (n_first) run_phases<1, LP>(axy, azw, TA, cur, n_first, pc, base);
+        if (n_last) run_phases<2, LP>(axy, azw, TA, cur, n_last, pc, base);
     }
     float4 acc[PR];
 #pragma unroll
@@ -119,7 +202,7 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     constexpr int XROT = (16 - ((LP / 4) % 16)) % 16, YROT = (16 - (LP % 16)) % 16;   // lane -> column-group rotations
     const OutRegion rg = out_region(a);
     const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
-    const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
+    const int oy0 = rg.y_lo + ty * GT, ox0 = tile_x_origin(a.out_kind) + tx * GT;
     if (oy0 >= rg.y_hi) return;
     Block4x4Epilogue<TX, TOut> epi;
     const int rgp = threadIdx.x >> 4, gy = ((threadIdx.x & 15) + YROT * (rgp & 1)) & 15;   // y-pass / output mapping
@@ -175,7 +258,7 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
 constexpr size_t kTileLds = sizeof(float) * (GT + 2 * PB_KRAD) * (GT + 2 * PB_KRAD);   // 88 x 88 floats
 
 template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int total_tiles) {
+__global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int tiles_per_plane, int tiles_x, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only), so
     // give every XCD one contiguous run of tiles -- row-neighbours then share their halos in that
@@ -193,7 +276,7 @@ __global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int 
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
-    const int R = a.force_full ? PB_KRAD : cinfo->radius;
+    const int R = cinfo->radius;
     if (sep) {
         if (R <= 4) body_tile_sep<TIn, TX, TOut, 4>(a, info, ipl, xpl, opl, local, tiles_x, smem);
         else if (R <= 8) body_tile_sep<TIn, TX, TOut, 8>(a, info, ipl, xpl, opl, local, tiles_x, smem);
@@ -201,7 +284,9 @@ __global__ __launch_bounds__(NT, 5) void conv_tile_kernel(const ConvPass a, int 
         return;
     }
     if (R <= 4) body_tile<TIn, TX, TOut, 4>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+    else if (R <= 6) body_tile<TIn, TX, TOut, 6>(a, info, ipl, xpl, opl, local, tiles_x, smem);
     else if (R <= 8) body_tile<TIn, TX, TOut, 8>(a, info, ipl, xpl, opl, local, tiles_x, smem);
+    else if (R <= 10) body_tile<TIn, TX, TOut, 10>(a, info, ipl, xpl, opl, local, tiles_x, smem);
     else body_tile<TIn, TX, TOut, 12>(a, info, ipl, xpl, opl, local, tiles_x, smem);
 }
 
@@ -209,7 +294,8 @@ template <typename TIn, typename TX, typename TOut>
 int launch_typed(pb_ctx *ctx, const ConvPass &p) {
     const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * PB_PAD;
     const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * PB_PAD;
-    const int tiles_x = (ow + GT - 1) / GT, tiles_y = (oh + GT - 1) / GT;
+    const int x_lo = (p.out_kind == OUT_INTERIOR) ? PB_PAD : 0;
+    const int tiles_x = (ow + x_lo - tile_x_origin(p.out_kind) + GT - 1) / GT, tiles_y = (oh + GT - 1) / GT;
     const long tpp = (long)tiles_x * tiles_y;
     const long blocks = tpp * p.P;
     if (blocks <= 0 || blocks > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "conv pass: bad grid");

@@ -23,7 +23,7 @@ __device__ __forceinline__ TileJob decode_tile(const ConvPass &a, int tile_id, i
     j.info = a.info + j.plane / a.C;
     const PB_CONSTANT pb_blur_info *ci = as_constant(j.info);
     const int sep = ci->separable != 0;
-    const int R = a.force_full ? PB_KRAD : ci->radius;
+    const int R = ci->radius;
     j.cls = 8 * sep + (R <= 4 ? 0 : (R <= 8 ? 1 : 2));
     return j;
 }
@@ -164,7 +164,7 @@ template <typename TX, typename TOut> struct Block4x4Epilogue {
     __device__ __forceinline__ void prefetch(const ConvPass &a, const TX *xpl, TOut *opl, const OutRegion &rg, int py, int px) {
         const int xo = a.x_kind == SRC_VIRTUAL ? PB_PAD : 0, oo = a.out_kind == OUT_INTERIOR ? PB_PAD : 0;
         const int xrows = a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * PB_PAD, xcols = a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * PB_PAD;
-        fast = a.epilogue == EPI_HORNER && py + 3 < rg.y_hi && px + 3 < rg.x_hi && py - xo >= 0 && py - xo + 3 < xrows &&
+        fast = a.epilogue == EPI_HORNER && py + 3 < rg.y_hi && px >= rg.x_lo && px + 3 < rg.x_hi && py - xo >= 0 && py - xo + 3 < xrows &&
                px - xo >= 0 && px - xo + 3 < xcols && ((a.x_pitch | a.out_pitch) & 3) == 0;
         if (fast) {
             xp = xpl + (long)(py - xo) * a.x_pitch + (px - xo);
@@ -176,7 +176,7 @@ template <typename TX, typename TOut> struct Block4x4Epilogue {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xr[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (py + r >= rg.y_lo && py + r < rg.y_hi && px < rg.x_hi) xr[r] = load_x4<TX>(a, xpl, py + r, px);
+                if (py + r >= rg.y_lo && py + r < rg.y_hi && px < rg.x_hi && px + 3 >= rg.x_lo) xr[r] = load_x4<TX>(a, xpl, py + r, px);
             }
         }
     }

@@ -704,10 +704,11 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         info->acorr_x[tid] = ax;
         info->acorr_y[tid] = ay;
     }
-    for (int idx = tid; idx < PB_KSIZE * 32; idx += NT) {
+    for (int idx = tid; idx < (PB_KSIZE + 1) * 32; idx += NT) {
         const int y = idx >> 5, j = (idx & 31) - 3;
-        info->gtaps[idx] = (j >= 0 && j < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j] : 0.f;
-        info->gtaps_odd[idx] = (j + 1 >= 0 && j + 1 < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j + 1] : 0.f;
+        const bool row = y < PB_KSIZE;                  // row 25: zeros, the taps of filler phases
+        info->gtaps[idx] = (row && j >= 0 && j < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j] : 0.f;
+        info->gtaps_odd[idx] = (row && j + 1 >= 0 && j + 1 < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j + 1] : 0.f;
     }
     __shared__ int nz[PB_KSIZE];
     if (tid < PB_KSIZE) {
@@ -733,7 +734,46 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
             const bool live = thr > 0.f ? (fabsf(info->kx[t]) >= thr || fabsf(info->ky[t]) >= thr) : (nz[t] != 0);
             if (live && d > rad) rad = d;
         }
-        info->radius = rad <= 4 ? 4 : (rad <= 8 ? 8 : PB_KRAD);
+        info->radius = rad <= 4 ? 4 : (rad <= 6 ? 6 : (rad <= 8 ? 8 : (rad <= 10 ? 10 : PB_KRAD)));
+    }
+    __syncthreads();
+    // The general stencil body walks a list of live (kernel row, window chunk) phases.  Chunk q of class R covers
+    // window elements 4q .. 4q+3, which meet the taps gtaps[row][n0 .. n0+6], n0 = 4q + 12 - R.  A phase is live when
+    // one of its seven taps counts under the policy: FULL -- not exactly 0.0f; ADAPTIVE -- at least 1e-10 (inside the
+    // box the marginals selected, the dropped taps are the corners outside the Gaussian's ellipse: < 7e-8 in total).
+    {
+        __shared__ int wcount[NT / 64];
+        const int R = info->radius, off = PB_KRAD - R, nq = R / 2 + 1;
+        const int row = tid / 7, q = tid - row * 7;
+        const float tap_thr = (support & 15) == PB_SUPPORT_ADAPTIVE ? 1e-10f : 0.f;
+        bool live = false;
+        if (row <= 2 * R && q < nq) {
+            const float *t = info->gtaps + (row + off) * 32 + 4 * q + off;
+            for (int i = 0; i < 7; ++i) live |= tap_thr > 0.f ? (fabsf(t[i]) >= tap_thr) : (t[i] != 0.f);
+        }
+        // grouped by kind (inner chunks, then first chunks, then last chunks of a window row), row-major within a kind;
+        // every group is padded to an even length with a filler phase (LDS row 0, the all-zero tap row 25): the
+        // stencil loop is unrolled by two with the taps double-buffered in scalar registers
+        const int kind = q == 0 ? 1 : (q == nq - 1 ? 2 : 0);
+        const int lane = tid & 63, wave = tid >> 6;
+        int before = 0, total = 0;
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long bal = __ballot(live && kind == k);
+            __syncthreads();
+            if (lane == 0) wcount[wave] = __popcll(bal);
+            __syncthreads();
+            int mine = total + __popcll(bal & ((1ull << lane) - 1ull)), cnt = 0;
+            for (int w = 0; w < NT / 64; ++w) { if (w < wave) mine += wcount[w]; cnt += wcount[w]; }
+            if (kind == k) before = mine;
+            if (tid == 0) {
+                if (cnt & 1) info->phase[total + cnt] = ((PB_KSIZE - off) << 16);
+                info->nphase[k] = cnt + (cnt & 1);
+            }
+            total += cnt + (cnt & 1);
+        }
+        if (live) info->phase[before] = row | (q << 8) | (row << 16);
+        __syncthreads();
+        if (tid < 3) info->phase[total + tid] = total ? info->phase[0] : 0;     // harmless targets for the prefetches
     }
 }
 

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pb_version() == 100
+    assert lib.pb_version() == 200
 
 
 def test_struct_layout_matches_header(lib):
@@ -39,7 +39,7 @@ def test_struct_layout_matches_header(lib):
     assert abs(o.c - 0.352) < 1e-7 and abs(o.b - 0.768) < 1e-7 and o.alpha == 2 and o.beta == 3
     assert abs(o.sigma_r - 0.8) < 1e-7 and o.sigma_s == 2.0 and o.q == 0 and o.force_theta_deg == -1.0
     assert (o.remove_halo, o.edgetaping, o.prefilter, o.discard_saturation, o.boundary, o.support) == (0,) * 6
-    assert ctypes.sizeof(capi.pb_blur_info) == capi.INFO_DTYPE.itemsize == 4 * (2 + 13 + 64 + 4 + 2 + 625 + 100 + 800 + 800)
+    assert ctypes.sizeof(capi.pb_blur_info) == capi.INFO_DTYPE.itemsize == 4 * (2 + 13 + 64 + 4 + 2 + 625 + 100 + 832 + 832 + 3 + 184)
 
 
 def test_no_gpu_fails_loudly(lib):

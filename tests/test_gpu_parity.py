@@ -95,7 +95,7 @@ def test_make_kernels_grid(eng, golden):
     k = info["kernel"].reshape(-1, 25, 25) != 0
     d = np.abs(np.arange(25) - 12)
     ext = np.maximum((k.any(axis=1) * d).max(axis=1), (k.any(axis=2) * d).max(axis=1))
-    assert np.array_equal(info["radius"], np.where(ext <= 4, 4, np.where(ext <= 8, 8, 12)))
+    assert np.array_equal(info["radius"], np.where(ext <= 4, 4, np.where(ext <= 6, 6, np.where(ext <= 8, 8, np.where(ext <= 10, 10, 12)))))
     assert np.all(info["radius"][np.maximum(g["sigma"], g["rho"]) >= 1.0] == 12)
     # adaptive support: radius class follows the wider std
     buf = eng.make_kernels(g["sigma"], g["rho"], g["theta"], support=capi.PB_SUPPORT_ADAPTIVE)
@@ -103,7 +103,18 @@ def test_make_kernels_grid(eng, golden):
     smax = np.maximum(g["sigma"], g["rho"])
     assert np.all(info["radius"][smax <= 0.55] == 4)
     assert np.all(info["radius"][smax >= 4.0] == 12)
-    assert set(np.unique(info["radius"])) <= {4, 8, 12}
+    assert set(np.unique(info["radius"])) <= {4, 6, 8, 10, 12}
+    # the phase lists of the general body: even per-kind counts, full rows under the full policy at sigma = 4, and
+    # under the adaptive policy only the segments inside the Gaussian's ellipse
+    gen = info["separable"] == 0
+    assert np.all(info["nphase"] % 2 == 0) and np.all(info["nphase"].sum(axis=1)[gen] > 0)
+    full = eng.read_info(eng.make_kernels(g["sigma"], g["rho"], g["theta"]), g["sigma"].size)
+    wide = gen & (np.minimum(g["sigma"], g["rho"]) >= 2.0)
+    assert np.all(full["nphase"].sum(axis=1)[wide] == 178)          # 25 rows x 7 chunks (+1 filler per kind)
+    na, nf = info["nphase"].sum(axis=1), full["nphase"].sum(axis=1)
+    assert np.all(na[gen] <= nf[gen]) and np.any(na[gen] < 0.7 * nf[gen])
+    thin = gen & (smax >= 2.0) & (np.minimum(g["sigma"], g["rho"]) <= 0.55)
+    assert thin.any() and np.all(nf[thin] < 178)                   # taps that underflowed to 0.0f are skipped even when "full"
 
 
 @pytest.mark.parametrize("name", ["stages_A.npz", "stages_B.npz"])
@@ -253,7 +264,7 @@ def test_adaptive_support_matches_full(eng, sigma, rho, deg):
     full = eng.make_kernels([sigma] * 2, [rho] * 2, [th] * 2, support=capi.PB_SUPPORT_FULL)
     a = eng.inverse_filter(x, full, 6.0, 1.0, capi.PB_WRAP)
     adap = eng.make_kernels([sigma] * 2, [rho] * 2, [th] * 2, support=capi.PB_SUPPORT_ADAPTIVE, name="np.info2")
-    assert eng.read_info(adap, 2)["radius"][0] in ((4, 8, 12) if sigma < 1.5 else (12,))
+    assert eng.read_info(adap, 2)["radius"][0] in ((4, 6, 8, 10, 12) if sigma < 1.5 else (10, 12))
     b = eng.inverse_filter(x, adap, 6.0, 1.0, capi.PB_WRAP)
     assert maxabs(a, b) < 2e-6
 
