@@ -116,9 +116,9 @@ typedef struct pb_blur_info {
     int32_t nphase[3];                  /* general (non rank-1) stencil: number of (kernel row, 4-tap segment) phases of
                                            kind 0 (inner chunk of a window row), 1 (first chunk), 2 (last chunk); each
                                            count is even (an all-zero filler phase pads an odd one)                  */
-    int32_t phase[PB_MAX_PHASES + 9];   /* their descriptors, grouped by kind, row-major inside a kind:
-                                           LDS row | segment << 8 | tap row << 16, rows counted from the top of the radius
-                                           class (0 .. 2*radius), segment = window chunk 0 .. radius/2; three pad entries (read ahead, never evaluated) */
+    int32_t phase[PB_MAX_PHASES + 9];   /* their descriptors, grouped by kind, row-major inside a kind: byte offset of the
+                                           segment in the (64 + 2*radius)-wide staged tile | index of its first tap in
+                                           gtaps << 16; three pad entries (read ahead, never evaluated) */
 } pb_blur_info;
 
 /* ---- context ------------------------------------------------------------------------- */

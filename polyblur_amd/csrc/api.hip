@@ -56,9 +56,7 @@ void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes) {
 }
 
 static size_t dsize(int dtype) { return dtype == PB_F16 ? 2 : (dtype == PB_U8 ? 1 : 4); }
-// rows of the engine's own padded planes start on 128-byte lines (the stencil tiles are laid out so that their
-// windows then begin on a line as well: conv_common.h, tile_x_origin)
-static int pitch_lines(int w) { return (w + 31) & ~31; }
+static int pitch4(int w) { return (w + 3) & ~3; }
 
 extern "C" {
 
@@ -180,7 +178,7 @@ struct Geometry {
 Geometry geometry(int B, int C, int H, int W) {
     Geometry g;
     g.B = B; g.C = C; g.H = H; g.W = W; g.P = B * C;
-    g.Hp = H + 2 * PB_PAD; g.Wp = W + 2 * PB_PAD; g.pp = pitch_lines(g.Wp);
+    g.Hp = H + 2 * PB_PAD; g.Wp = W + 2 * PB_PAD; g.pp = pitch4(g.Wp);
     g.pplane = (long)g.Hp * g.pp;
     g.HW = (long)H * W;
     return g;

@@ -39,11 +39,11 @@ namespace {
 // twice, from t[n0] and from t[n0+1], which gives both alignments of adjacent pairs.  Phases whose taps are all dead
 // (exact zeros; under the adaptive policy also the corners outside the Gaussian's ellipse) are simply not in the list.
 //
-// The loop is software-pipelined by hand, one step ahead: while the 8 packed FMAs of (phase, r) issue, the window
-// chunk of (phase, r+1) -- or of the next phase's r = 0 -- is in flight from LDS, and during a whole phase the taps of
-// the next phase and the descriptor of the one after are in flight from the scalar cache.  Every wait is therefore for
-// something issued at least 8 FMAs earlier, and is placed (wait_for) BEFORE the next prefetch is issued, so that the
-// lgkmcnt(0) the mixed LDS / scalar traffic forces never drains a load that has only just been issued.
+// The loop is software-pipelined by hand, half a phase ahead: while the 16 packed FMAs of two output rows issue, the
+// window chunks of the next two rows (of this phase or the next) are in flight from LDS, and during a whole phase the
+// taps of the next phase and the descriptor of the one after are in flight from the scalar cache.  Every wait is
+// therefore for something issued at least 16 FMAs earlier, and is placed (wait_for) BEFORE the next prefetch is
+// issued, so that the lgkmcnt(0) the mixed LDS / scalar traffic forces never drains a load that has only just been issued.
 struct PhaseTaps { f2 a[3], b[3]; };      // a[k] = (t[n0+2k], t[n0+2k+1]),  b[k] = (t[n0+2k+1], t[n0+2k+2])
 
 // (the odd-aligned pairs come from the record's second, shifted copy of the taps: building them from the first with
@@ -59,83 +59,84 @@ __device__ __forceinline__ void load_phase_taps(PhaseTaps &T, const PB_CONSTANT 
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wait_for(f4 &v) { asm volatile("" : "+v"(v)); }
 
-// The packed FMAs of one (phase, r) step as ONE asm statement (nothing is scheduled in between, no pad states are
-// inserted between the dependent pairs): element j of the chunk feeds (x,y) with the tap pair starting at n0+j+2 and
-// (z,w) with the pair starting at n0+j, both read swapped.  KIND 1: first chunk of a window row -- its elements 0, 1
-// meet only padding on the (z,w) side; KIND 2: last chunk -- elements 2, 3 meet only padding on the (x,y) side.
-template <int KIND> __device__ __forceinline__ void chunk_fma(f2 &axy, f2 &azw, const PhaseTaps &T, const f4 &v) {
-    const f2 lo = v.xy, hi = v.zw;
+// The packed FMAs of one half-phase -- two output rows, 16 instructions -- as ONE asm statement (nothing is scheduled
+// in between, no pad states are inserted), the four accumulators interleaved so that dependent FMAs are four issue
+// slots apart.  Element j of a chunk feeds (x,y) with the tap pair starting at n0+j+2 and (z,w) with the pair starting
+// at n0+j, both read swapped.  KIND 1: first chunk of a window row -- its elements 0, 1 meet only padding on the (z,w)
+// side; KIND 2: last chunk -- elements 2, 3 meet only padding on the (x,y) side.
+#define PB_FMA(acc, tap, dat, sel) "v_pk_fma_f32 " acc ", " tap ", " dat ", " acc " op_sel:[1," sel ",0] op_sel_hi:[0," sel ",1]\n\t"
+template <int KIND>
+__device__ __forceinline__ void chunk_fma2(f2 &axy0, f2 &azw0, f2 &axy1, f2 &azw1, const PhaseTaps &T, const f4 &v0, const f4 &v1) {
+    const f2 lo0 = v0.xy, hi0 = v0.zw, lo1 = v1.xy, hi1 = v1.zw;
+    // operands: 0-3 accumulators (xy0, zw0, xy1, zw1); 4-9 taps a0 a1 a2 b0 b1 b2; 10-13 data lo0 hi0 lo1 hi1
     if (KIND == 0)
-        asm("v_pk_fma_f32 %0, %2, %8, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %1, %3, %8, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %0, %5, %8, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %1, %6, %8, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %0, %4, %9, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %1, %2, %9, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %0, %7, %9, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]"
-            : "+v"(axy), "+v"(azw)
-            : "s"(T.a[1]), "s"(T.a[0]), "s"(T.a[2]), "s"(T.b[1]), "s"(T.b[0]), "s"(T.b[2]), "v"(lo), "v"(hi));
+        asm(PB_FMA("%0", "%5", "%10", "0") PB_FMA("%1", "%4", "%10", "0") PB_FMA("%2", "%5", "%12", "0") PB_FMA("%3", "%4", "%12", "0")
+            PB_FMA("%0", "%8", "%10", "1") PB_FMA("%1", "%7", "%10", "1") PB_FMA("%2", "%8", "%12", "1") PB_FMA("%3", "%7", "%12", "1")
+            PB_FMA("%0", "%6", "%11", "0") PB_FMA("%1", "%5", "%11", "0") PB_FMA("%2", "%6", "%13", "0") PB_FMA("%3", "%5", "%13", "0")
+            PB_FMA("%0", "%9", "%11", "1") PB_FMA("%1", "%8", "%11", "1") PB_FMA("%2", "%9", "%13", "1") PB_FMA("%3", "%8", "%13", "1")
+            : "+v"(axy0), "+v"(azw0), "+v"(axy1), "+v"(azw1)
+            : "s"(T.a[0]), "s"(T.a[1]), "s"(T.a[2]), "s"(T.b[0]), "s"(T.b[1]), "s"(T.b[2]), "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1));
     if (KIND == 1)
-        asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %0, %3, %7, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %1, %2, %7, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %0, %5, %7, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]"
-            : "+v"(axy), "+v"(azw)
-            : "s"(T.a[1]), "s"(T.a[2]), "s"(T.b[1]), "s"(T.b[2]), "v"(lo), "v"(hi));
+        asm(PB_FMA("%0", "%5", "%10", "0") PB_FMA("%2", "%5", "%12", "0")
+            PB_FMA("%0", "%8", "%10", "1") PB_FMA("%2", "%8", "%12", "1")
+            PB_FMA("%0", "%6", "%11", "0") PB_FMA("%1", "%5", "%11", "0") PB_FMA("%2", "%6", "%13", "0") PB_FMA("%3", "%5", "%13", "0")
+            PB_FMA("%0", "%9", "%11", "1") PB_FMA("%1", "%8", "%11", "1") PB_FMA("%2", "%9", "%13", "1") PB_FMA("%3", "%8", "%13", "1")
+            : "+v"(axy0), "+v"(azw0), "+v"(axy1), "+v"(azw1)
+            : "s"(T.a[0]), "s"(T.a[1]), "s"(T.a[2]), "s"(T.b[0]), "s"(T.b[1]), "s"(T.b[2]), "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1));
     if (KIND == 2)
-        asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %1, %3, %6, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %1, %5, %6, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %1, %2, %7, %1 op_sel:[1,0,0] op_sel_hi:[0,0,1]\n\t"
-            "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1]"
-            : "+v"(axy), "+v"(azw)
-            : "s"(T.a[1]), "s"(T.a[0]), "s"(T.b[1]), "s"(T.b[0]), "v"(lo), "v"(hi));
+        asm(PB_FMA("%0", "%5", "%10", "0") PB_FMA("%1", "%4", "%10", "0") PB_FMA("%2", "%5", "%12", "0") PB_FMA("%3", "%4", "%12", "0")
+            PB_FMA("%0", "%8", "%10", "1") PB_FMA("%1", "%7", "%10", "1") PB_FMA("%2", "%8", "%12", "1") PB_FMA("%3", "%7", "%12", "1")
+            PB_FMA("%1", "%5", "%11", "0") PB_FMA("%3", "%5", "%13", "0")
+            PB_FMA("%1", "%8", "%11", "1") PB_FMA("%3", "%8", "%13", "1")
+            : "+v"(axy0), "+v"(azw0), "+v"(axy1), "+v"(azw1)
+            : "s"(T.a[0]), "s"(T.a[1]), "s"(T.a[2]), "s"(T.b[0]), "s"(T.b[1]), "s"(T.b[2]), "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1));
 }
+#undef PB_FMA
 
-// descriptor (LDS row | chunk << 8 | tap row << 16) -> tap offset row * 32 + 4 * chunk, LDS offset row * LP + 4 * chunk
-#define PB_TAP_OFF(d) ((((d) >> 16) << 5) + (((d) >> 6) & 0x1c))
-#define PB_LDS_OFF(d, LP) (((d) & 255) * (LP) + (((d) >> 6) & 0x1c))
+// descriptor: byte offset of the chunk in the LDS tile (of the record's radius class) | index of its first tap << 16
+#define PB_TAP_OFF(d) ((unsigned)(d) >> 16)
+#define PB_LDS_OFF(d) ((unsigned)(d) & 0xffffu)
 
 struct PhaseCursor {
-    int d0, d1, d2;                         // descriptors of the current phase and the two after it
-    const PB_CONSTANT int *next;            // where the descriptor after those is read from
+    const char *rowc;                       // LDS address of the current phase's row-0 chunk (this thread's window)
+    unsigned d1, d2;                        // descriptors of the two phases after the current one
+    const PB_CONSTANT unsigned *next;       // where the descriptor after those is read from
     const PB_CONSTANT float *taps, *taps_odd;
 };
 
-// One phase: TC = its taps, `cur` = its r = 0 chunk (both requested a phase ago).  Issues, in its first step, the
-// scalar loads of the NEXT phase's taps (into TN) and of the descriptor three phases ahead; prefetches every chunk one
-// step ahead; leaves the next phase's r = 0 chunk in `cur`.
+// One phase: TC = its taps, `cur` = its chunks of rows 0 and 1 (requested half a phase ago).  Two half-phases of 16
+// packed FMAs; the first requests the NEXT phase's taps (into TN), the descriptor three phases ahead and the chunks of
+// rows 2, 3; the second the next phase's rows 0, 1, which are left in `cur`.
 template <int KIND, int LP>
-__device__ __forceinline__ void run_phase(f2 (&axy)[4], f2 (&azw)[4], const PhaseTaps &TC, PhaseTaps &TN, f4 &cur,
-                                          PhaseCursor &pc, const float *base) {
-    const float *rowc = base + PB_LDS_OFF(pc.d0, LP), *rown = base + PB_LDS_OFF(pc.d1, LP);
-    f4 nxt;
-    int d3 = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        wait_for(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        if (r == 0) {
-            d3 = *pc.next;
-            load_phase_taps(TN, pc.taps + PB_TAP_OFF(pc.d1), pc.taps_odd + PB_TAP_OFF(pc.d1));
-        }
-        nxt = *reinterpret_cast<const f4 *>(r < 3 ? rowc + (r + 1) * LP : rown);
-        __builtin_amdgcn_sched_barrier(0);
-        chunk_fma<KIND>(axy[r], azw[r], TC, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    }
-    pc.d0 = pc.d1; pc.d1 = pc.d2; pc.d2 = d3; ++pc.next;
+__device__ __forceinline__ void run_phase(f2 (&axy)[4], f2 (&azw)[4], const PhaseTaps &TC, PhaseTaps &TN, f4 (&cur)[2],
+                                          PhaseCursor &pc, const char *base) {
+    f4 nxt[2];
+    // rows 0, 1: their chunks were requested half a phase ago; request rows 2, 3 and the next phase's scalars
+    wait_for(cur[0]); wait_for(cur[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned d3 = *pc.next;
+    load_phase_taps(TN, pc.taps + PB_TAP_OFF(pc.d1), pc.taps_odd + PB_TAP_OFF(pc.d1));
+    nxt[0] = *reinterpret_cast<const f4 *>(pc.rowc + 2 * LP * 4);
+    nxt[1] = *reinterpret_cast<const f4 *>(pc.rowc + 3 * LP * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_fma2<KIND>(axy[0], azw[0], axy[1], azw[1], TC, cur[0], cur[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // rows 2, 3; request rows 0, 1 of the next phase
+    wait_for(nxt[0]); wait_for(nxt[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    pc.rowc = base + PB_LDS_OFF(pc.d1);
+    cur[0] = *reinterpret_cast<const f4 *>(pc.rowc);
+    cur[1] = *reinterpret_cast<const f4 *>(pc.rowc + LP * 4);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_fma2<KIND>(axy[2], azw[2], axy[3], azw[3], TC, nxt[0], nxt[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    pc.d1 = pc.d2; pc.d2 = d3; ++pc.next;
 }
 
 // All `count` (even, > 0) phases of one kind.  On entry and on exit TA holds the taps of the cursor's current phase.
 template <int KIND, int LP>
-__device__ __forceinline__ void run_phases(f2 (&axy)[4], f2 (&azw)[4], PhaseTaps &TA, f4 &cur, int count, PhaseCursor &pc,
-                                           const float *base) {
+__device__ __forceinline__ void run_phases(f2 (&axy)[4], f2 (&azw)[4], PhaseTaps &TA, f4 (&cur)[2], int count, PhaseCursor &pc,
+                                           const char *base) {
     PhaseTaps TB;
 #pragma unroll 1
     for (int i = 0; i < count; i += 2) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     constexpr int PR = 4;
     const OutRegion rg = out_region(a);
     const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
-    const int oy0 = rg.y_lo + ty * GT, ox0 = tile_x_origin(a.out_kind) + tx * GT;
+    const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
     const int tid = threadIdx.x;
     // 16 column groups x 16 row groups.  The two row groups that share a 32-lane half are 4 LDS rows
@@ -166,17 +167,21 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     for (int r = 0; r < PR; ++r) { axy[r] = (f2){0.f, 0.f}; azw[r] = (f2){0.f, 0.f}; }
     // gtaps[y] = {0,0,0, k[y][0..24], 0,0,0,0}; class R starts at kernel row / column 12 - R
     const PB_CONSTANT pb_blur_info *ci = as_constant(info);
-    const PB_CONSTANT int *plist = ci->phase;
-    const float *base = smem + (rgp * PR) * LP + 4 * g;
+    const PB_CONSTANT unsigned *plist = reinterpret_cast<const PB_CONSTANT unsigned *>(ci->phase);
+    const char *base = reinterpret_cast<const char *>(smem + (rgp * PR) * LP + 4 * g);
     const int n_mid = ci->nphase[0], n_first = ci->nphase[1], n_last = ci->nphase[2];
     if (n_mid + n_first + n_last > 0) {
         PhaseCursor pc;
-        pc.d0 = plist[0]; pc.d1 = plist[1]; pc.d2 = plist[2]; pc.next = plist + 3;
-        pc.taps = ci->gtaps + (PB_KRAD - R) * 32 + (PB_KRAD - R);
-        pc.taps_odd = ci->gtaps_odd + (PB_KRAD - R) * 32 + (PB_KRAD - R);
+        const unsigned d0 = plist[0];
+        pc.d1 = plist[1]; pc.d2 = plist[2]; pc.next = plist + 3;
+        pc.taps = ci->gtaps;
+        pc.taps_odd = ci->gtaps_odd;
+        pc.rowc = base + PB_LDS_OFF(d0);
         PhaseTaps TA;
-        load_phase_taps(TA, pc.taps + PB_TAP_OFF(pc.d0), pc.taps_odd + PB_TAP_OFF(pc.d0));
-        f4 cur = *reinterpret_cast<const f4 *>(base + PB_LDS_OFF(pc.d0, LP));
+        load_phase_taps(TA, pc.taps + PB_TAP_OFF(d0), pc.taps_odd + PB_TAP_OFF(d0));
+        f4 cur[2];
+        cur[0] = *reinterpret_cast<const f4 *>(pc.rowc);
+        cur[1] = *reinterpret_cast<const f4 *>(pc.rowc + LP * 4);
         if (n_mid) run_phases<0, LP>(axy, azw, TA, cur, n_mid, pc, base);
         if (n_first) run_phases<1, LP>(axy, azw, TA, cur, n_first, pc, base);
         if (n_last) run_phases<2, LP>(axy, azw, TA, cur, n_last, pc, base);
@@ -202,7 +207,7 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     constexpr int XROT = (16 - ((LP / 4) % 16)) % 16, YROT = (16 - (LP % 16)) % 16;   // lane -> column-group rotations
     const OutRegion rg = out_region(a);
     const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
-    const int oy0 = rg.y_lo + ty * GT, ox0 = tile_x_origin(a.out_kind) + tx * GT;
+    const int oy0 = rg.y_lo + ty * GT, ox0 = rg.x_lo + tx * GT;
     if (oy0 >= rg.y_hi) return;
     Block4x4Epilogue<TX, TOut> epi;
     const int rgp = threadIdx.x >> 4, gy = ((threadIdx.x & 15) + YROT * (rgp & 1)) & 15;   // y-pass / output mapping
@@ -294,8 +299,7 @@ template <typename TIn, typename TX, typename TOut>
 int launch_typed(pb_ctx *ctx, const ConvPass &p) {
     const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * PB_PAD;
     const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * PB_PAD;
-    const int x_lo = (p.out_kind == OUT_INTERIOR) ? PB_PAD : 0;
-    const int tiles_x = (ow + x_lo - tile_x_origin(p.out_kind) + GT - 1) / GT, tiles_y = (oh + GT - 1) / GT;
+    const int tiles_x = (ow + GT - 1) / GT, tiles_y = (oh + GT - 1) / GT;
     const long tpp = (long)tiles_x * tiles_y;
     const long blocks = tpp * p.P;
     if (blocks <= 0 || blocks > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "conv pass: bad grid");

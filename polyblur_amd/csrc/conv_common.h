@@ -76,14 +76,6 @@ __device__ __forceinline__ OutRegion out_region(const ConvPass &a) {
     return OutRegion{0, a.H + 2 * PB_PAD, 0, a.W + 2 * PB_PAD};
 }
 
-// Tiles are 64 outputs wide and start at padded columns = 12 (mod 64) for both kinds of output (the interior crop
-// starts at column 12; a padded output gets a first, mostly empty tile column at -52).  With that origin the
-// (64 + 2R)-wide window of a tile begins at a multiple of 64 samples minus (12 - R): on the engine's own padded planes
-// (rows start on 128-byte lines) an R = 12 window covers exactly three lines, and the x operand / the cropped output of
-// an un-padded image whose rows are line-aligned cover exactly two -- the stencil pass is bound by the number of
-// 128-byte lines a CU requests from L2, not by bytes (profiles/r02_inner_rank1_counters.txt).
-__device__ __host__ __forceinline__ int tile_x_origin(int out_kind) { return out_kind == OUT_INTERIOR ? PB_PAD : PB_PAD - 64; }
-
 // The x operand of 4 horizontally adjacent outputs at padded (py, px..px+3): rows and columns of a virtual
 // (un-padded) source clamp (replicate pad); a 16-byte load when the four columns are contiguous in the source.
 template <typename TX>

@@ -766,12 +766,13 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
             for (int w = 0; w < NT / 64; ++w) { if (w < wave) mine += wcount[w]; cnt += wcount[w]; }
             if (kind == k) before = mine;
             if (tid == 0) {
-                if (cnt & 1) info->phase[total + cnt] = ((PB_KSIZE - off) << 16);
+                if (cnt & 1) info->phase[total + cnt] = (PB_KSIZE * 32) << 16;
                 info->nphase[k] = cnt + (cnt & 1);
             }
             total += cnt + (cnt & 1);
         }
-        if (live) info->phase[before] = row | (q << 8) | (row << 16);
+        // descriptor: byte offset of the chunk in the (64 + 2R)-wide LDS tile | index of its first tap in gtaps << 16
+        if (live) info->phase[before] = ((row * (64 + 2 * R) + 4 * q) * 4) | (((row + off) * 32 + 4 * q + off) << 16);
         __syncthreads();
         if (tid < 3) info->phase[total + tid] = total ? info->phase[0] : 0;     // harmless targets for the prefetches
     }

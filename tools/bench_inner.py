@@ -1,6 +1,6 @@
 """Quick inner-loop timing for kernel tuning: python tools/bench_inner.py [H W B]"""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.environ.get('PB_PKG_ROOT', '.'))
 from polyblur_amd import _capi as capi
 from polyblur_amd.engine import get_engine
 only = None
