@@ -7,6 +7,9 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int GT = 64;   // 64 x 64 outputs per workgroup tile, 4 x 4 per thread
+#ifndef PB_TILE_DMA
+#define PB_TILE_DMA 1
+#endif
 
 // What a workgroup needs to know about one tile.
 struct TileJob {
@@ -64,6 +67,24 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
         const T *base = plane + (long)sy0 * pitch + sx0;
         constexpr int C4 = LW / 4;
         constexpr int NLD = (LH * C4 + NT - 1) / NT;
+        if constexpr (PB_TILE_DMA && __is_same(T, float) && LP == LW) {
+            // fp32 interior tile: global -> LDS directly, 1 KiB of the row-major tile per wave instruction (see load_rows_wave)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+            typedef __attribute__((address_space(3))) char lds_char;
+            lds_char *dst = (lds_char *)s + (tid >> 6) * 1024;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int e = tid + k * NT;
+                const int r = e / C4, c = e - r * C4;
+                if (e < LH * C4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (long)r * pitch + 4 * c),
+                                                     (__attribute__((address_space(3))) void *)(dst + k * (NT * 16)), 16, 0, 0);
+            }
+#pragma clang diagnostic pop
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         float4 buf[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -119,6 +140,26 @@ __device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kin
     if (inside && ((pitch | sx0) & 3) == 0) {
         const T *base = plane + (long)(sy0 + r0) * pitch + sx0;
         constexpr int NLD = (RPW * C4 + 63) / 64;
+        if constexpr (PB_TILE_DMA && __is_same(T, float) && LP == LW) {
+            // fp32 interior tile: global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, lane l
+            // lands at the wave-uniform base + 16 l, which with unpadded rows IS the row-major tile), no staging
+            // registers, no ds_write pass.  The wave waits for its own rows only.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+            typedef __attribute__((address_space(3))) char lds_char;
+            lds_char *dst = (lds_char *)(s + r0 * LP);
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int e = lane + k * 64;
+                const int r = e / C4, c = e - r * C4;
+                if (r < nrows)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (long)r * pitch + 4 * c),
+                                                     (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+            }
+#pragma clang diagnostic pop
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         float4 buf[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
