@@ -91,6 +91,8 @@ typedef struct pb_options {
     int32_t support;            /* pb_support */
     float force_theta_deg;      /* < 0: estimate (default); >= 0: bench knob, overrides the
                                    estimated direction so that every kernel is rank-1 */
+    int32_t ker_size;           /* support of the estimated Gaussian and, halved, the replicate pad (deblurring.py:23,
+                                   blur_estimation.py:211-232, utils.py:48-53): odd, 3 .. 25 (default 25; 0 means 25) */
 } pb_options;
 
 /* Per-image, per-iteration estimation record (device or host copy). Mirrors the values the

@@ -68,7 +68,7 @@ void pb_default_options(pb_options *o) {
     o->n_iter = 1; o->c = 0.352f; o->b = 0.768f; o->alpha = 2.f; o->beta = 3.f;
     o->sigma_r = 0.8f; o->sigma_s = 2.0f; o->q = 0.f; o->n_angles = 6; o->n_interpolated_angles = 30;
     o->remove_halo = 0; o->edgetaping = 0; o->prefilter = PB_PREFILTER_NONE; o->discard_saturation = 0;
-    o->boundary = PB_WRAP; o->support = PB_SUPPORT_FULL; o->force_theta_deg = -1.f;
+    o->boundary = PB_WRAP; o->support = PB_SUPPORT_FULL; o->force_theta_deg = -1.f; o->ker_size = PB_KSIZE;
 }
 
 int pb_create(pb_ctx **out, int device, void *stream) {
@@ -170,15 +170,15 @@ int pb_memcpy_d2h(pb_ctx *ctx, void *dst, const void *src, size_t bytes) {
 namespace {
 
 struct Geometry {
-    int B, C, H, W, P, Hp, Wp, pp;     // pp = pitch of padded fp32 planes
+    int B, C, H, W, P, pad, Hp, Wp, pp;     // pad = ker_size / 2; pp = pitch of padded fp32 planes
     long pplane;                        // elements per padded plane
     long HW;
 };
 
-Geometry geometry(int B, int C, int H, int W) {
+Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
     Geometry g;
-    g.B = B; g.C = C; g.H = H; g.W = W; g.P = B * C;
-    g.Hp = H + 2 * PB_PAD; g.Wp = W + 2 * PB_PAD; g.pp = pitch4(g.Wp);
+    g.B = B; g.C = C; g.H = H; g.W = W; g.P = B * C; g.pad = pad;
+    g.Hp = H + 2 * pad; g.Wp = W + 2 * pad; g.pp = pitch4(g.Wp);
     g.pplane = (long)g.Hp * g.pp;
     g.HW = (long)H * W;
     return g;
@@ -187,7 +187,7 @@ Geometry geometry(int B, int C, int H, int W) {
 ConvPass base_pass(const Geometry &g, const pb_blur_info *info, int boundary) {
     ConvPass p;
     memset(&p, 0, sizeof(p));
-    p.H = g.H; p.W = g.W; p.C = g.C; p.P = g.P; p.info = info; p.boundary = boundary;
+    p.H = g.H; p.W = g.W; p.pad = g.pad; p.C = g.C; p.P = g.P; p.info = info; p.boundary = boundary;
     p.scale = 1.f; p.coef = 0.f; p.epilogue = EPI_HORNER; p.clamp01 = 0;
     return p;
 }
@@ -286,7 +286,7 @@ int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtyp
     rc = pb_fourier_gradients_impl(ctx, y, g.P, g.H, g.W, ox, nullptr);     // only gout_x is used (deblurring.py:174)
     if (rc) return rc;
     if (xpadded)
-        return pb_halo_apply(ctx, xpadded + (long)PB_PAD * g.pp + PB_PAD, PB_F32, g.pp, g.pplane, y, g0x, g0y, ox, nM, dst,
+        return pb_halo_apply(ctx, xpadded + (long)g.pad * g.pp + g.pad, PB_F32, g.pp, g.pplane, y, g0x, g0y, ox, nM, dst,
                              dst_dtype, g.P, g.H, g.W, final_clamp);
     return pb_halo_apply(ctx, src, src_dtype, g.W, g.HW, y, g0x, g0y, ox, nM, dst, dst_dtype, g.P, g.H, g.W, final_clamp);
 }
@@ -363,10 +363,10 @@ int pb_inverse_filter(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
 
 int pb_convolve2d(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp, int Wp, const pb_blur_info *dev_info,
                   int boundary) {
-    if (!ctx || !in || !out || !dev_info || Hp <= 2 * PB_PAD || Wp <= 2 * PB_PAD) return PB_ERR_BADARG;
+    if (!ctx || !in || !out || !dev_info || Hp <= 2 * PB_KRAD || Wp <= 2 * PB_KRAD) return PB_ERR_BADARG;
     PB_HIP(hipSetDevice(ctx->device));
     // The given image IS the padded domain: address it as a padded source with pitch Wp.
-    Geometry g = geometry(B, C, Hp - 2 * PB_PAD, Wp - 2 * PB_PAD);
+    Geometry g = geometry(B, C, Hp - 2 * PB_KRAD, Wp - 2 * PB_KRAD);
     g.pp = Wp; g.pplane = (long)Hp * Wp;
     ConvPass p = base_pass(g, dev_info, boundary);
     set_in_padded(p, g, in); set_x_padded(p, g, in); set_out_padded(p, g, out);
@@ -376,9 +376,9 @@ int pb_convolve2d(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp
 
 int pb_edgetaper(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp, int Wp, const pb_blur_info *dev_info,
                  int boundary) {
-    if (!ctx || !in || !out || !dev_info || Hp <= 2 * PB_PAD || Wp <= 2 * PB_PAD) return PB_ERR_BADARG;
+    if (!ctx || !in || !out || !dev_info || Hp <= 2 * PB_KRAD || Wp <= 2 * PB_KRAD) return PB_ERR_BADARG;
     PB_HIP(hipSetDevice(ctx->device));
-    Geometry g = geometry(B, C, Hp - 2 * PB_PAD, Wp - 2 * PB_PAD);
+    Geometry g = geometry(B, C, Hp - 2 * PB_KRAD, Wp - 2 * PB_KRAD);
     g.pp = Wp; g.pplane = (long)Hp * Wp;
     float *tmp = static_cast<float *>(pb_scratch(ctx, "taper.tmp", sizeof(float) * g.P * g.pplane));
     if (!tmp) return PB_ERR_NOMEM;
@@ -458,8 +458,10 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (in == out) return pb_fail(ctx, PB_ERR_BADARG, "out may not alias in");
     if (opt->n_iter < 0) return pb_fail(ctx, PB_ERR_BADARG, "n_iter < 0");
     if (opt->boundary != PB_WRAP && opt->boundary != PB_ZERO) return pb_fail(ctx, PB_ERR_BADARG, "bad boundary");
+    const int ksize = pb_kernel_size(opt);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", opt->ker_size, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
-    const Geometry g = geometry(B, C, H, W);
+    const Geometry g = geometry(B, C, H, W, ksize / 2);
     const long n = (long)g.P * g.HW;
     const int n_iter = opt->n_iter;
     if (n_iter == 0) {

@@ -11,7 +11,6 @@
 
 #include "../../include/polyblur_hip.h"
 
-#define PB_PAD PB_KRAD
 
 // ------------------------------------------------------------------------------------
 // context
@@ -111,7 +110,8 @@ struct ConvPass {
     const void *in;  int in_kind;  int in_dtype;  int in_pitch;  long in_plane;
     const void *x;   int x_kind;   int x_dtype;   int x_pitch;   long x_plane;
     void *out;       int out_kind; int out_dtype; int out_pitch; long out_plane;
-    int H, W;            // un-padded size; Hp = H + 2*PB_PAD, Wp = W + 2*PB_PAD
+    int H, W;            // un-padded size; Hp = H + 2*pad, Wp = W + 2*pad
+    int pad;             // replicate pad = ker_size / 2 (utils.py:48-53): 12 for the reference's default 25x25 kernel
     int C;               // planes per image
     int P;               // number of planes (B*C)
     const pb_blur_info *info;
@@ -128,8 +128,9 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
 // ------------------------------------------------------------------------------------
 int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W,
                      const pb_options *opt, pb_blur_info *dev_info);
+int pb_kernel_size(const pb_options *opt);      // validated ker_size (odd, 3..25); 0 if unsupported
 int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy);
-int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps);
+int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps, int ksize = PB_KSIZE);
 
 // ------------------------------------------------------------------------------------
 // device helpers

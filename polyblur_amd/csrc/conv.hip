@@ -160,7 +160,7 @@ __device__ __forceinline__ void body_tile(const ConvPass &a, const pb_blur_info 
     // 16 column groups x 16 row groups.  The two row groups that share a 32-lane half are 4 LDS rows
     // (4 * LP floats) apart; rotating the odd one's column group keeps every ds_read_b128 conflict-free.
     const int rgp = tid >> 4, g = ((tid & 15) + YROT * (rgp & 1)) & 15;
-    load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
+    load_tile<TIn, LH, LW, LP>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary, a.pad);
     __syncthreads();
     f2 axy[PR], azw[PR];
 #pragma unroll
@@ -213,7 +213,7 @@ __device__ __forceinline__ void body_tile_sep(const ConvPass &a, const pb_blur_i
     const int rgp = threadIdx.x >> 4, gy = ((threadIdx.x & 15) + YROT * (rgp & 1)) & 15;   // y-pass / output mapping
     epi.prefetch(a, xpl, opl, rg, oy0 + rgp * 4, ox0 + 4 * gy);
     constexpr int RPW = (LH + 3) / 4;                  // rows staged and x-filtered by each wave
-    load_rows_wave<TIn, LH, LW, LP, RPW>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary);
+    load_rows_wave<TIn, LH, LW, LP, RPW>(smem, ipl, a.in_kind, a.in_pitch, a.H, a.W, oy0 - R, ox0 - R, a.boundary, a.pad);
     // taps: TP[p] = (h[p], h[p-1]),  HY[m] = (hy[2m], hy[2m+1]),  h = marginal taps 0..R of the class
     const PB_CONSTANT float *ckx = as_constant(info->kx) + (PB_KRAD - R), *cky = as_constant(info->ky) + (PB_KRAD - R);
     f2 TP[R + 1], HY[(R + 2) / 2];
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int 
 
 template <typename TIn, typename TX, typename TOut>
 int launch_typed(pb_ctx *ctx, const ConvPass &p) {
-    const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * PB_PAD;
-    const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * PB_PAD;
+    const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * p.pad;
+    const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * p.pad;
     const int tiles_x = (ow + GT - 1) / GT, tiles_y = (oh + GT - 1) / GT;
     const long tpp = (long)tiles_x * tiles_y;
     const long blocks = tpp * p.P;

@@ -27,11 +27,11 @@ __device__ __forceinline__ int wrap_idx(int v, int n) {
 }
 
 // padded coordinate -> source index along one axis, or -1 for "reads as zero"
-__device__ __forceinline__ int map_axis(int p, int n_unpadded, int kind, int boundary) {
-    const int np = n_unpadded + 2 * PB_PAD;
+__device__ __forceinline__ int map_axis(int p, int n_unpadded, int kind, int boundary, int pad) {
+    const int np = n_unpadded + 2 * pad;
     if (boundary == PB_WRAP) p = wrap_idx(p, np);
     else if (p < 0 || p >= np) return -1;
-    if (kind == SRC_VIRTUAL) return min(max(p - PB_PAD, 0), n_unpadded - 1);
+    if (kind == SRC_VIRTUAL) return min(max(p - pad, 0), n_unpadded - 1);
     return p;
 }
 
@@ -72,8 +72,8 @@ template <> __device__ __forceinline__ void st4<__half>(__half *p, float4 v) {
 // Where the outputs of a pass live, in padded coordinates.
 struct OutRegion { int y_lo, y_hi, x_lo, x_hi; };
 __device__ __forceinline__ OutRegion out_region(const ConvPass &a) {
-    if (a.out_kind == OUT_INTERIOR) return OutRegion{PB_PAD, PB_PAD + a.H, PB_PAD, PB_PAD + a.W};
-    return OutRegion{0, a.H + 2 * PB_PAD, 0, a.W + 2 * PB_PAD};
+    if (a.out_kind == OUT_INTERIOR) return OutRegion{a.pad, a.pad + a.H, a.pad, a.pad + a.W};
+    return OutRegion{0, a.H + 2 * a.pad, 0, a.W + 2 * a.pad};
 }
 
 // The x operand of 4 horizontally adjacent outputs at padded (py, px..px+3): rows and columns of a virtual
@@ -81,9 +81,9 @@ __device__ __forceinline__ OutRegion out_region(const ConvPass &a) {
 template <typename TX>
 __device__ __forceinline__ float4 load_x4(const ConvPass &a, const TX *xpl, int py, int px) {
     const int H = a.H, W = a.W;
-    const int xr = (a.x_kind == SRC_VIRTUAL) ? min(max(py - PB_PAD, 0), H - 1) : py;
-    const int xc0 = (a.x_kind == SRC_VIRTUAL) ? px - PB_PAD : px;
-    const int xcmax = (a.x_kind == SRC_VIRTUAL) ? W : W + 2 * PB_PAD;
+    const int xr = (a.x_kind == SRC_VIRTUAL) ? min(max(py - a.pad, 0), H - 1) : py;
+    const int xc0 = (a.x_kind == SRC_VIRTUAL) ? px - a.pad : px;
+    const int xcmax = (a.x_kind == SRC_VIRTUAL) ? W : W + 2 * a.pad;
     const TX *xrow = xpl + (long)xr * a.x_pitch;
     if (xc0 >= 0 && xc0 + 3 < xcmax && ((a.x_pitch | xc0) & 3) == 0) return ld4<TX>(xrow + xc0);
     float4 t;
@@ -99,7 +99,7 @@ template <typename TOut>
 __device__ __forceinline__ void finish4(const ConvPass &a, const pb_blur_info *info, TOut *opl, const OutRegion &rg, int py,
                                         int px, float4 acc, float4 xq) {
     if (py < rg.y_lo || py >= rg.y_hi || px >= rg.x_hi || px + 3 < rg.x_lo) return;
-    const int Hp = a.H + 2 * PB_PAD, Wp = a.W + 2 * PB_PAD;
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
     float av[4] = {acc.x, acc.y, acc.z, acc.w};
     const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
     const bool full = px >= rg.x_lo && px + 3 < rg.x_hi;
@@ -117,8 +117,8 @@ __device__ __forceinline__ void finish4(const ConvPass &a, const pb_blur_info *i
         if (a.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
         av[i] = v;
     }
-    const int orow = (a.out_kind == OUT_INTERIOR) ? py - PB_PAD : py;
-    const int oc0 = (a.out_kind == OUT_INTERIOR) ? px - PB_PAD : px;
+    const int orow = (a.out_kind == OUT_INTERIOR) ? py - a.pad : py;
+    const int oc0 = (a.out_kind == OUT_INTERIOR) ? px - a.pad : px;
     TOut *orow_p = opl + (long)orow * a.out_pitch;
     if (full && ((a.out_pitch | oc0) & 3) == 0) {
         st4<TOut>(orow_p + oc0, make_float4(av[0], av[1], av[2], av[3]));

@@ -35,15 +35,15 @@ __device__ __forceinline__ TileJob decode_tile(const ConvPass &a, int tile_id, i
 // where the columns map to themselves and are aligned, four mapped loads in the pad / wrap region.
 template <typename T>
 __device__ __forceinline__ float4 load_chunk_mapped(const T *plane, int pitch, int iy, int px, int W, int kind, int boundary,
-                                                    bool aligned) {
+                                                    bool aligned, int pad) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (iy < 0) return v;
     const T *row = plane + (long)iy * pitch;
-    const int shift = (kind == SRC_VIRTUAL) ? PB_PAD : 0;
-    const int lo = shift, hi = (kind == SRC_VIRTUAL) ? PB_PAD + W : W + 2 * PB_PAD;
+    const int shift = (kind == SRC_VIRTUAL) ? pad : 0;
+    const int lo = shift, hi = (kind == SRC_VIRTUAL) ? pad + W : W + 2 * pad;
     if (aligned && px >= lo && px + 3 < hi) return ld4<T>(row + (px - shift));
-    const int i0 = map_axis(px, W, kind, boundary), i1 = map_axis(px + 1, W, kind, boundary);
-    const int i2 = map_axis(px + 2, W, kind, boundary), i3 = map_axis(px + 3, W, kind, boundary);
+    const int i0 = map_axis(px, W, kind, boundary, pad), i1 = map_axis(px + 1, W, kind, boundary, pad);
+    const int i2 = map_axis(px + 2, W, kind, boundary, pad), i3 = map_axis(px + 3, W, kind, boundary, pad);
     if (i0 >= 0) v.x = pb_ld(row + i0);
     if (i1 >= 0) v.y = pb_ld(row + i1);
     if (i2 >= 0) v.z = pb_ld(row + i2);
@@ -53,13 +53,13 @@ __device__ __forceinline__ float4 load_chunk_mapped(const T *plane, int pitch, i
 
 template <typename T, int LH, int LW, int LP>
 __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
-                                          int boundary) {
-    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
+                                          int boundary, int pad) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
     int sy0 = py0, sx0 = px0;
     if (kind == SRC_VIRTUAL) {
-        inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
-        sy0 -= PB_PAD; sx0 -= PB_PAD;
+        inside = inside && py0 >= pad && px0 >= pad && py0 + LH <= pad + H && px0 + LW <= pad + W;
+        sy0 -= pad; sx0 -= pad;
     }
     const int tid = threadIdx.x;
     if (inside && ((pitch | sx0) & 3) == 0) {
@@ -109,7 +109,7 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
             const int e = tid + k * NT;
             const int r = e / C4, c = e - r * C4;
             if (e < LH * C4)
-                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r, H, kind, boundary), px0 + 4 * c, W, kind, boundary, aligned);
+                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r, H, kind, boundary, pad), px0 + 4 * c, W, kind, boundary, aligned, pad);
         }
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -125,13 +125,13 @@ __device__ __forceinline__ void load_tile(float *s, const T *plane, int kind, in
 // waves of a workgroup drift apart (one's loads overlap another's arithmetic).
 template <typename T, int LH, int LW, int LP, int RPW>
 __device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kind, int pitch, int H, int W, int py0, int px0,
-                                               int boundary, int tid = threadIdx.x) {
-    const int Hp = H + 2 * PB_PAD, Wp = W + 2 * PB_PAD;
+                                               int boundary, int pad, int tid = threadIdx.x) {
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     bool inside = py0 >= 0 && px0 >= 0 && py0 + LH <= Hp && px0 + LW <= Wp;
     int sy0 = py0, sx0 = px0;
     if (kind == SRC_VIRTUAL) {
-        inside = inside && py0 >= PB_PAD && px0 >= PB_PAD && py0 + LH <= PB_PAD + H && px0 + LW <= PB_PAD + W;
-        sy0 -= PB_PAD; sx0 -= PB_PAD;
+        inside = inside && py0 >= pad && px0 >= pad && py0 + LH <= pad + H && px0 + LW <= pad + W;
+        sy0 -= pad; sx0 -= pad;
     }
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = wave * RPW;
@@ -182,8 +182,8 @@ __device__ __forceinline__ void load_rows_wave(float *s, const T *plane, int kin
             const int e = lane + k * 64;
             const int r = e / C4, c = e - r * C4;
             if (r < nrows)
-                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r0 + r, H, kind, boundary), px0 + 4 * c, W, kind,
-                                              boundary, aligned);
+                buf[k] = load_chunk_mapped<T>(plane, pitch, map_axis(py0 + r0 + r, H, kind, boundary, pad), px0 + 4 * c, W, kind,
+                                              boundary, aligned, pad);
         }
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -203,8 +203,8 @@ template <typename TX, typename TOut> struct Block4x4Epilogue {
     const TX *xp;
     TOut *op;
     __device__ __forceinline__ void prefetch(const ConvPass &a, const TX *xpl, TOut *opl, const OutRegion &rg, int py, int px) {
-        const int xo = a.x_kind == SRC_VIRTUAL ? PB_PAD : 0, oo = a.out_kind == OUT_INTERIOR ? PB_PAD : 0;
-        const int xrows = a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * PB_PAD, xcols = a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * PB_PAD;
+        const int xo = a.x_kind == SRC_VIRTUAL ? a.pad : 0, oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
+        const int xrows = a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * a.pad, xcols = a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * a.pad;
         fast = a.epilogue == EPI_HORNER && py + 3 < rg.y_hi && px >= rg.x_lo && px + 3 < rg.x_hi && py - xo >= 0 && py - xo + 3 < xrows &&
                px - xo >= 0 && px - xo + 3 < xcols && ((a.x_pitch | a.out_pitch) & 3) == 0;
         if (fast) {

@@ -644,7 +644,7 @@ __device__ float block_sum(float v, float *red) {
 
 // Fills kernel (unless from_taps), marginals, autocorrelations, separability and radius of one
 // record.  Called by all NT threads of a block.
-__device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red) {
+__device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red, int ksize) {
     const int tid = threadIdx.x;
     if (!from_taps) {
         // blur_estimation.py:189-232
@@ -661,9 +661,11 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
             const int idx = tid + q * NT;
             e[q] = 0.f;
             if (idx < PB_KSIZE * PB_KSIZE) {
-                const float Y = (float)(idx / PB_KSIZE - PB_KRAD), X = (float)(idx % PB_KSIZE - PB_KRAD);
+                const int iy = idx / PB_KSIZE - PB_KRAD, ix = idx % PB_KSIZE - PB_KRAD;
+                const float Y = (float)iy, X = (float)ix;
                 const float quad = (X * a00 + Y * a01) * X + (X * a01 + Y * a11) * Y;
-                e[q] = expf(-0.5f * quad);
+                // a ker_size x ker_size kernel (blur_estimation.py:222) sits in the centre of the 25 x 25 record
+                e[q] = (abs(iy) <= ksize / 2 && abs(ix) <= ksize / 2) ? expf(-0.5f * quad) : 0.f;
                 part += e[q];
             }
         }
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
                                                          const unsigned *__restrict__ mags_u,
                                                          const float *__restrict__ wts, int n_angles, int n_interp,
                                                          float c, float b, int support, float force_theta_deg,
-                                                         int tiles_per_image) {
+                                                         int tiles_per_image, int ksize) {
     __shared__ float red[NT / 64];
     __shared__ float s_mags[PB_MAX_ANGLES], s_interp[PB_MAX_INTERP];
     pb_blur_info *info = infos + blockIdx.x;
@@ -839,12 +841,12 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
         info->i_min = i_min;
     }
     __syncthreads();
-    finish_record(info, support, false, red);
+    finish_record(info, support, false, red, ksize);
 }
 
-__global__ __launch_bounds__(NT) void make_kernels_kernel(pb_blur_info *infos, int support, int from_taps) {
+__global__ __launch_bounds__(NT) void make_kernels_kernel(pb_blur_info *infos, int support, int from_taps, int ksize) {
     __shared__ float red[NT / 64];
-    finish_record(infos + blockIdx.x, support, from_taps != 0, red);
+    finish_record(infos + blockIdx.x, support, from_taps != 0, red, ksize);
 }
 
 size_t fft_lds_bytes(const FftPlan *pl, int nb) {
@@ -930,6 +932,8 @@ int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, in
 int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, const pb_options *opt,
                      pb_blur_info *dev_info) {
     if (opt->q < 0.f || opt->q >= 0.5f) return pb_fail(ctx, PB_ERR_BADARG, "q must be in [0, 0.5)");
+    const int ksize = pb_kernel_size(opt);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", opt->ker_size, PB_KSIZE);
     if (opt->n_angles < 1 || opt->n_angles + 1 > PB_MAX_ANGLES || opt->n_interpolated_angles < 1 ||
         opt->n_interpolated_angles > PB_MAX_INTERP)
         return pb_fail(ctx, PB_ERR_BADARG, "n_angles / n_interpolated_angles out of range");
@@ -994,14 +998,19 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (rc) return rc;
     ProfScope prof(ctx, PB_PROF_PARAMS);
     hipLaunchKernelGGL(blur_params_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
-                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles);
+                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles, ksize);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
 
-int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps) {
+int pb_kernel_size(const pb_options *opt) {
+    const int k = opt->ker_size == 0 ? PB_KSIZE : opt->ker_size;
+    return (k >= 3 && k <= PB_KSIZE && (k & 1)) ? k : 0;
+}
+
+int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps, int ksize) {
     ProfScope prof(ctx, PB_PROF_PARAMS);
-    hipLaunchKernelGGL(make_kernels_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, support, from_taps);
+    hipLaunchKernelGGL(make_kernels_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, support, from_taps, ksize);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

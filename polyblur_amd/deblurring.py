@@ -65,8 +65,11 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
         raise ValueError("support must be 'full' or 'adaptive'")
     if prefilter not in _PREFILTER:
         raise ValueError("prefilter must be 'bilateral', 'domain_transform' or 'normalized_convolution'")
-    if ker_size != capi.PB_KSIZE:
-        raise NotImplementedError("only ker_size=25 (the reference default) is built")
+    if not (isinstance(ker_size, (int, np.integer)) and 3 <= ker_size <= capi.PB_KSIZE and ker_size % 2 == 1):
+        # the kernel lives in the centre of a 25 x 25 record and the replicate pad is ker_size // 2; the reference's
+        # even sizes are asymmetric (blur_estimation.py:222: arange(k) - (k-1)//2) and are not built, nor is anything
+        # beyond the default 25 (sigma is clamped to 4, so 25 already holds +-3 sigma)
+        raise NotImplementedError("ker_size must be odd and between 3 and 25 (the reference default)")
     if not (0 <= q < 0.5):
         raise ValueError("q must be in [0, 0.5)")
     if multichannel_kernel and C not in (1, 3):
@@ -79,7 +82,7 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
                                edgetaping=edgetaping,
                                prefilter=_PREFILTER[prefilter] if prefiltering else capi.PB_PREFILTER_NONE,
                                discard_saturation=discard_saturation, boundary=_METHODS[method],
-                               support=_SUPPORT[support], force_theta_deg=force_theta_deg)
+                               support=_SUPPORT[support], force_theta_deg=force_theta_deg, ker_size=ker_size)
 
 
 def _info_to_dicts(info, n_angles, n_interp):

@@ -39,6 +39,7 @@ def test_struct_layout_matches_header(lib):
     assert abs(o.c - 0.352) < 1e-7 and abs(o.b - 0.768) < 1e-7 and o.alpha == 2 and o.beta == 3
     assert abs(o.sigma_r - 0.8) < 1e-7 and o.sigma_s == 2.0 and o.q == 0 and o.force_theta_deg == -1.0
     assert (o.remove_halo, o.edgetaping, o.prefilter, o.discard_saturation, o.boundary, o.support) == (0,) * 6
+    assert o.ker_size == 25
     assert ctypes.sizeof(capi.pb_blur_info) == capi.INFO_DTYPE.itemsize == 4 * (2 + 13 + 64 + 4 + 2 + 625 + 100 + 832 + 832 + 3 + 184)
 
 
@@ -60,6 +61,10 @@ def test_argument_validation_before_any_device_work():
         polyblur_deblurring(x, q=0.5)
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=31)
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(x, ker_size=12)
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(x, method="direct_separable")
     with pytest.raises(ValueError):
         polyblur_deblurring(np.zeros((4,), np.float32))
     with pytest.raises(TypeError):

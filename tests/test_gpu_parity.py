@@ -750,3 +750,31 @@ def test_streams_and_threads_do_not_share_scratch(eng):
     torch.cuda.synchronize()
     assert res["eng"] is not eng and torch.equal(res["out"], want[0])
     assert all(torch.equal(a, b) for a, b in zip(other, want[1:]))
+
+
+@pytest.mark.parametrize("k", [5, 13, 21])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_kernel_sizes_against_reference_goldens(golden, k, method):
+    """ker_size != 25 (deblurring.py:23): the estimated Gaussian is k x k and the replicate pad k // 2, so the wrap /
+    zero boundary of the three reblurring passes sits closer to the image"""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    g = golden("pipeline_kersize.npz")
+    out = polyblur_deblurring(torch.from_numpy(g["x"]).cuda(), n_iter=2, ker_size=k, method=method, **KW).cpu().numpy()
+    assert maxabs(out, g["k%d_%s" % (k, method)]) < 2e-5
+    if k == 13 and method == "fft":
+        out = polyblur_deblurring(torch.from_numpy(g["x"]).cuda(), n_iter=2, ker_size=13, edgetaping=True, remove_halo=True,
+                                  **KW).cpu().numpy()
+        assert maxabs(out, g["k13_fft_taper_halo"]) < 2e-5
+
+
+@pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64))])
+def test_kernel_sizes_against_oracle(k, shape):
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    x, _ = synthetic_blurry_batch(shape[0], shape[1], shape[2], shape[3], seed0=61)
+    for method in ("fft", "direct"):
+        out, infos = polyblur_deblurring(torch.from_numpy(x).cuda(), n_iter=2, ker_size=k, method=method, return_info=True, **KW)
+        want, winfos = ref.polyblur_deblurring(x, n_iter=2, ker_size=k, method=method, return_info=True, **KW)
+        assert [float(i["theta"][0]) for i in infos] == [float(i["theta"][0]) for i in winfos]
+        assert maxabs(out.cpu().numpy(), want) < 2e-5, (k, method)

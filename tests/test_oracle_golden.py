@@ -201,3 +201,16 @@ def test_pipeline_extra_defaults_and_odd_batch(golden):
     assert np.max(np.abs(out - g["module_defaults_n3"])) < 3e-5
     out = ref.polyblur_deblurring(g["x"], n_iter=2)
     assert np.max(np.abs(out - g["functional_defaults_n2"])) < 3e-5
+
+
+@pytest.mark.parametrize("k", [5, 13, 21])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_pipeline_kernel_sizes(golden, k, method):
+    """ker_size sets the Gaussian's support AND the replicate pad (blur_estimation.py:211-232, utils.py:48-53)"""
+    g = golden("pipeline_kersize.npz")
+    out = ref.polyblur_deblurring(g["x"], n_iter=2, ker_size=k, method=method, c=0.362, b=0.468, alpha=6, beta=1)
+    assert np.max(np.abs(out - g["k%d_%s" % (k, method)])) < 1e-5
+    if k == 13 and method == "fft":
+        out = ref.polyblur_deblurring(g["x"], n_iter=2, ker_size=13, edgetaping=True, remove_halo=True, c=0.362, b=0.468,
+                                      alpha=6, beta=1)
+        assert np.max(np.abs(out - g["k13_fft_taper_halo"])) < 1e-5
