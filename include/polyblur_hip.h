@@ -237,7 +237,7 @@ int pb_time_inner_loop(pb_ctx *ctx, const void *in, void *out, int dtype, int B,
 /* Per-kernel-class device timing with hipEvents on the context's stream.  Between begin and
  * end every launch is bracketed by two events; end synchronises and returns, per tag, the
  * summed milliseconds and the launch count (arrays of PB_PROF_NTAGS).                        */
-#define PB_PROF_NTAGS 8
+#define PB_PROF_NTAGS 9
 typedef enum pb_prof_tag {
     PB_PROF_CONV = 0,        /* stencil pass (one Horner step / taper blend) */
     PB_PROF_GRAY = 1,        /* gray + min/max */
@@ -246,7 +246,8 @@ typedef enum pb_prof_tag {
     PB_PROF_PARAMS = 4,      /* parameter / kernel generation */
     PB_PROF_HALO = 5,        /* halo masking + its reductions */
     PB_PROF_PREFILTER = 6,   /* bilateral / domain transform / recombination */
-    PB_PROF_OTHER = 7
+    PB_PROF_OTHER = 7,
+    PB_PROF_CONV_FUSED = 8   /* Horner steps 2 + 3 in one launch (rank-1 kernels) */
 } pb_prof_tag;
 int pb_profile_begin(pb_ctx *ctx);
 int pb_profile_end(pb_ctx *ctx, float *host_ms, int *host_count);

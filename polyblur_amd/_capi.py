@@ -34,7 +34,7 @@ SYMBOLS = [
     "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
     "pb_fft_length_supported",
 ]
-PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other"]
+PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused"]
 
 
 class pb_options(C.Structure):

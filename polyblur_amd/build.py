@@ -39,7 +39,10 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+EXPERIMENTAL = ["conv_fused.hip"]      # measured slower than the default path; built only on request (-DPB_WITH_FUSED)
+
+
+def build(force: bool = False, verbose: bool = True, experimental: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
@@ -48,12 +51,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers.append(os.path.join(os.path.dirname(HERE), "include", "polyblur_hip.h"))
     jobs = []
     objs = []
-    for src in SOURCES:
+    flags = FLAGS + (["-DPB_WITH_FUSED"] if experimental else [])
+    stamp = os.path.join(objdir, "experimental" if experimental else "default")
+    if not os.path.exists(stamp):                      # switching flavours rebuilds everything
+        force = True
+        for f in ("experimental", "default"):
+            if os.path.exists(os.path.join(objdir, f)):
+                os.remove(os.path.join(objdir, f))
+        open(stamp, "w").close()
+    for src in SOURCES + (EXPERIMENTAL if experimental else []):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -73,4 +84,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experimental="--experimental" in sys.argv))

@@ -2,6 +2,7 @@
 // drivers that chain the kernels of conv.hip / estimate.hip / filters.hip on one stream.
 // Mirrors polyblur_deblurring's main loop (reference deblurring.py:58-96) and
 // inverse_filtering_rank3 (deblurring.py:211-239).
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -244,6 +245,21 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     p.scale = a3; p.coef = a2;
     int rc = pb_launch_conv(ctx, p);
     if (rc) return rc;
+#ifdef PB_WITH_FUSED
+    // EXPERIMENT (python -m polyblur_amd.build --experimental, then PB_FUSE=1): rank-1 kernels take steps 2 and 3 in one
+    // launch, t2 stays in LDS (conv_fused.hip); each image's record decides on the device which path does its tiles.
+    // Measured on MI355X at 4K: 167 us against 2 x 74 us for the two one-step launches -- not
+    // part of the default build.
+    static const bool fuse = [] { const char *e = getenv("PB_FUSE"); return e && e[0] == '1'; }();
+    if (fuse) {
+        ConvPass f = p;
+        set_in_padded(f, g, t1); set_out_interior(f, g, dst, dst_dtype);
+        f.scale = 1.f; f.coef = beta; f.clamp01 = clamp01;
+        rc = pb_launch_conv_fused(ctx, f, a1);
+        if (rc == PB_OK) p.skip_sep = 1;
+        else if (rc != PB_ERR_UNSUPPORTED) return rc;
+    }
+#endif
     // t2 = K * t1 + a1 x
     set_in_padded(p, g, t1); set_out_padded(p, g, t2);
     p.scale = 1.f; p.coef = a1;

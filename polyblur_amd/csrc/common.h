@@ -119,9 +119,11 @@ struct ConvPass {
     int boundary;
     int epilogue;
     int clamp01;
+    int skip_sep;        // rank-1 images were handled by the fused two-step launch: their tiles exit at once
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
+int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // conv_fused.hip
 
 // ------------------------------------------------------------------------------------
 // estimation (estimate.hip)

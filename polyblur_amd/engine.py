@@ -274,8 +274,8 @@ class Engine:
 
     def profile_end(self):
         """-> {tag: (total_ms, launches)} for the launches issued since profile_begin()."""
-        ms = (C.c_float * 8)()
-        cnt = (C.c_int * 8)()
+        ms = (C.c_float * len(capi.PROF_TAGS))()
+        cnt = (C.c_int * len(capi.PROF_TAGS))()
         self._check(self.lib.pb_profile_end(self.ctx, ms, cnt))
         return {t: (float(ms[i]), int(cnt[i])) for i, t in enumerate(capi.PROF_TAGS)}
 
