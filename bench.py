@@ -327,6 +327,18 @@ def main():
         dt_ad, _ = timed(args.steps, lambda: step("adaptive"))
         ms_ad = 1e3 * dt_ad / args.steps
         side["end_to_end_adaptive_support"] = dict(ms_per_step=round(ms_ad, 4), mp_per_s=round(B * H * W / 1e6 / (ms_ad * 1e-3), 1))
+        # the opt-in x-t separable APPROXIMATION of the oblique kernels (method='direct_separable', zero boundary):
+        # its speed, and its distance to the exact zero-boundary result on this image
+        sep_kw = dict(kw, method="direct_separable")
+        for _ in range(2):
+            o_sep = polyblur_deblurring(x, **sep_kw)
+        dt_sep, o_sep = timed(args.steps, lambda: polyblur_deblurring(x, **sep_kw))
+        ms_sep = 1e3 * dt_sep / args.steps
+        dev = (o_sep.float() - polyblur_deblurring(x, **dict(kw, method="direct")).float()).abs()
+        side["end_to_end_direct_separable_approximation"] = dict(
+            ms_per_step=round(ms_sep, 4), mp_per_s=round(B * H * W / 1e6 / (ms_sep * 1e-3), 1),
+            max_abs_vs_exact_direct=float(dev.max()), mean_abs_vs_exact_direct=float(dev.mean()),
+            note="approximate by design; not the headline")
         # host buffers in and out (PCIe-inclusive; never the headline value)
         xn = x_np.astype(np.float32 if s == 4 else np.float16)
         polyblur_deblurring(torch.from_numpy(xn), **kw)

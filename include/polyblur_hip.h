@@ -91,6 +91,15 @@ typedef struct pb_options {
     int32_t support;            /* pb_support */
     float force_theta_deg;      /* < 0: estimate (default); >= 0: bench knob, overrides the
                                    estimated direction so that every kernel is rank-1 */
+    int32_t separable_approx;   /* method='direct_separable': every reblurring K is replaced by the x-t separable
+                                   APPROXIMATION of the same Gaussian (intent of separable_gaussian2d.cpp:91-183, whose own
+                                   formulas do not run).  With q = A X^2 + 2 B X Y + C Y^2 the kernel's quadratic form
+                                   (blur_estimation.py:204-207), q = A (X + (B/A) Y)^2 + (C - B^2/A) Y^2: a 1-D Gaussian of
+                                   variance 1/A along X, then one of variance A/(AC - B^2) in Y taken along the line
+                                   X = -(B/A) Y, each offset split between the two nearest samples by linear
+                                   interpolation; X and Y swap roles when C > A (keeps |shear| <= 1).  Both 1-D kernels
+                                   are sampled on the ker_size grid and normalised to sum 1.  Opt-in: deviates from the
+                                   exact kernel by ~1e-2 (tests state the bound).  Zero boundary; not with edgetaping. */
     int32_t ker_size;           /* support of the estimated Gaussian and, halved, the replicate pad (deblurring.py:23,
                                    blur_estimation.py:211-232, utils.py:48-53): odd, 3 .. 25 (default 25; 0 means 25) */
 } pb_options;
@@ -168,6 +177,12 @@ int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *ho
                     const float *host_theta_rad, int support, pb_blur_info *dev_info);
 /* Same, but the caller supplies arbitrary 25x25 taps (host, B*625 floats). */
 int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_blur_info *dev_info);
+
+/* method='direct_separable' (pb_options.separable_approx): from B records that hold (sigma, rho, theta) build the two
+ * correlation kernels of the x-t separable approximation -- dev_sep[b] the 1-D pass, dev_sep[B + b] the oblique pass
+ * with linear interpolation (intent of separable_gaussian2d.cpp:91-183; definition at pb_options.separable_approx). */
+int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *dev_sep, int support,
+                              int ker_size);
 
 /* filters.fourier_gradients (filters.py:159-186) on P = B*C planes of H x W float32.
  * gx or gy may be NULL.  The transform keeps whole image lines in LDS: each of H and W must

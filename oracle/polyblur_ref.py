@@ -265,6 +265,65 @@ def gaussian_kernel_2d(theta, sigma, rho, ksize: int = 25) -> np.ndarray:
     return (k / k.sum(axis=(-2, -1), keepdims=True, dtype=F32)).astype(F32)
 
 
+def separable_xt_kernels(theta, sigma, rho, ksize: int = 25):
+    """The x-t separable APPROXIMATION of gaussian_kernel_2d -- method='direct_separable'.
+
+    Intent of the reference's dead side-car separable_gaussian2d.cpp:91-183 (a 1-D Gaussian along x followed by a
+    1-D Gaussian along an oblique line, sampled with linear interpolation -- Geusebroek et al.), whose own
+    formulas do not run (`tan_phi` at :103 drops the cos*sin factor; the Python stub filters.py:96-98 returns
+    its input).  The decomposition is derived from the quadratic form the live kernel uses, so that it
+    approximates the SAME Gaussian: with q = A X^2 + 2 B X Y + C Y^2 (A, B, C as in blur_estimation.py:204-207),
+        q = A (X + (B/A) Y)^2 + (C - B^2/A) Y^2
+    = a Gaussian in X of variance 1/A, then one in Y of variance A/(AC - B^2) taken along the line
+    X = -(B/A) Y.  The axis with the larger coefficient (the narrower Gaussian) goes first -- X if A >= C, else the
+    roles of X and Y are swapped -- which keeps the line within 45 degrees of the second axis (|shear| <= 1).
+    Every 1-D kernel is sampled on -r..r and normalised to sum 1; the oblique one puts, for each offset i along
+    its axis, the weights g[i] (1-f) and g[i] f on the two samples next to the line (f = fractional part).
+
+    Returns (K1, K2), two (B, ksize, ksize) float32 correlation kernels; K ~= K2 applied after K1.
+    PARITY UNPINNED: there is no running reference for this path; the GPU engine is tested against THIS
+    restatement, and its distance to the exact kernel is what the tests state as the method's tolerance."""
+    theta = -np.asarray(theta, dtype=F32)
+    sigma = np.asarray(sigma, dtype=F32)
+    rho = np.asarray(rho, dtype=F32)
+    co, si = np.cos(theta, dtype=F32), np.sin(theta, dtype=F32)
+    i1 = F32(1) / (sigma * sigma)
+    i2 = F32(1) / (rho * rho)
+    a00 = co * co * i1 + si * si * i2
+    a01 = si * co * (i1 - i2)
+    a11 = co * co * i2 + si * si * i1
+    r = (ksize - 1) // 2
+    t = np.arange(-r, r + 1).astype(F32)
+    B = theta.shape[0]
+    K1 = np.zeros((B, ksize, ksize), F32)
+    K2 = np.zeros((B, ksize, ksize), F32)
+    for n in range(B):
+        A, Bq, C = a00[n], a01[n], a11[n]
+        x_first = bool(A >= C)                     # the narrower axis first: |B| <= sqrt(AC) <= max(A, C), so |shear| <= 1
+        p, o = (A, C) if x_first else (C, A)       # first axis coefficient, other axis coefficient
+        det = p * o - Bq * Bq
+        g1 = np.exp(F32(-0.5) * p * t * t, dtype=F32)
+        g1 = (g1 / g1.sum(dtype=F32)).astype(F32)
+        g2 = np.exp(F32(-0.5) * (det / p) * t * t, dtype=F32)
+        g2 = (g2 / g2.sum(dtype=F32)).astype(F32)
+        shear = F32(-Bq / p)
+        for i in range(-r, r + 1):
+            if x_first:
+                K1[n, r, r + i] = g1[r + i]
+            else:
+                K1[n, r + i, r] = g1[r + i]
+            pos = F32(shear * F32(i))
+            m = int(np.floor(pos))
+            f = F32(pos - F32(m))
+            for mm, wgt in ((m, F32(g2[r + i] * (F32(1) - f))), (m + 1, F32(g2[r + i] * f))):
+                if abs(mm) <= r and wgt != 0:
+                    if x_first:
+                        K2[n, r + i, r + mm] += wgt
+                    else:
+                        K2[n, r + mm, r + i] += wgt
+    return K1, K2
+
+
 def estimate_gaussian_blur(img: np.ndarray, c: float, b: float, q: float = 0.0,
                            n_angles: int = 6, n_interpolated_angles: int = 30,
                            ker_size: int = 25, discard_saturation: bool = False,
@@ -387,11 +446,18 @@ def polynomial_deconvolution(x: np.ndarray, kernel: np.ndarray, alpha: float, be
         X = K * X + F32(a1) * Y
         X = K * X + F32(b0) * Y
         return _fft.ifft2(X).real.astype(F32)
-    if method in ("direct", "direct_separable"):
+    if method == "direct":
         t = F32(a3) * x
         t = correlate_same_zero(t, kernel) + F32(a2) * x
         t = correlate_same_zero(t, kernel) + F32(a1) * x
         return correlate_same_zero(t, kernel) + F32(b0) * x
+    if method == "direct_separable":               # kernel = (K1, K2) of separable_xt_kernels: K ~= K2 after K1
+        k1, k2 = kernel
+        blur = lambda v: correlate_same_zero(correlate_same_zero(v, k1), k2)
+        t = F32(a3) * x
+        t = blur(t) + F32(a2) * x
+        t = blur(t) + F32(a1) * x
+        return blur(t) + F32(b0) * x
     raise ValueError("%s not implemented" % method)
 
 
@@ -582,9 +648,11 @@ def inverse_filtering_rank3(x: np.ndarray, kernel: np.ndarray, alpha: float = 2,
                             remove_halo: bool = False, do_edgetaper: bool = False,
                             grad_img=None, method: str = "direct") -> np.ndarray:
     """deblurring.py:211-239: pad -> [edgetaper] -> polynomial -> crop -> [halo] -> clamp."""
-    r = np.asarray(kernel).shape[-1] // 2
+    r = np.asarray(kernel[0] if method == "direct_separable" else kernel).shape[-1] // 2
     xp = replicate_pad(np.asarray(x, dtype=F32), r)
     if do_edgetaper:
+        if method == "direct_separable":
+            raise NotImplementedError("edgetaping is not defined for the separable approximation")
         xp = edgetaper(xp, kernel, method=method)
     y = crop(polynomial_deconvolution(xp, kernel, alpha, b, method=method), r)
     if remove_halo:
@@ -603,7 +671,7 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
     x = to_planar(a) if as_image else np.asarray(a, dtype=F32)
     if x.ndim != 4:
         raise ValueError("expected (H,W), (H,W,C) or (B,C,H,W)")
-    if method not in ("fft", "direct"):
+    if method not in ("fft", "direct", "direct_separable"):
         raise ValueError("method %r is not runnable in the reference" % (method,))
     grad_img = spectral_gradients(x)                                       # :61
     pred = x
@@ -614,6 +682,9 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
                                               ker_size=ker_size, discard_saturation=discard_saturation,
                                               multichannel=multichannel_kernel, return_info=True)
         info["kernel"] = kernel[:, 0]
+        if method == "direct_separable":           # the opt-in x-t approximation of the same Gaussian (unpinned)
+            k1, k2 = separable_xt_kernels(info["theta"], info["sigma"], info["rho"], ker_size)
+            kernel = (k1[:, None], k2[:, None])
         if prefiltering:                                                   # :80-84
             smooth, detail = edge_aware_filtering(pred, sigma_s, sigma_r, prefilter)
             pred = inverse_filtering_rank3(smooth, kernel, alpha=alpha, b=beta, remove_halo=remove_halo,

@@ -32,7 +32,7 @@ SYMBOLS = [
     "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
     "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
-    "pb_fft_length_supported",
+    "pb_fft_length_supported", "pb_make_separable_kernels",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused"]
 
@@ -43,7 +43,7 @@ class pb_options(C.Structure):
         ("sigma_s", C.c_float), ("sigma_r", C.c_float), ("q", C.c_float), ("n_angles", C.c_int32),
         ("n_interpolated_angles", C.c_int32), ("remove_halo", C.c_int32), ("edgetaping", C.c_int32),
         ("prefilter", C.c_int32), ("discard_saturation", C.c_int32), ("boundary", C.c_int32),
-        ("support", C.c_int32), ("force_theta_deg", C.c_float), ("ker_size", C.c_int32),
+        ("support", C.c_int32), ("force_theta_deg", C.c_float), ("separable_approx", C.c_int32), ("ker_size", C.c_int32),
     ]
 
 
@@ -129,6 +129,7 @@ def load_library():
             "pb_extract_patches": (ci, [vp, vp, vp] + [ci] * 15),
             "pb_overlap_add": (ci, [vp, vp, vp] + [ci] * 13 + [vp, vp]),
             "pb_fft_length_supported": (ci, [ci]),
+            "pb_make_separable_kernels": (ci, [vp, ci, vp, vp, ci, ci]),
             "pb_profile_begin": (ci, [vp]),
             "pb_profile_end": (ci, [vp, fp, C.POINTER(ci)]),
         }

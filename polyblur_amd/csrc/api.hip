@@ -174,6 +174,9 @@ struct Geometry {
     int B, C, H, W, P, pad, Hp, Wp, pp;     // pad = ker_size / 2; pp = pitch of padded fp32 planes
     long pplane;                        // elements per padded plane
     long HW;
+    // method='direct_separable': records of the two 1-D passes that stand in for every reblurring, and the plane between them
+    const pb_blur_info *sep1 = nullptr, *sep2 = nullptr;
+    float *sep_u = nullptr;
 };
 
 Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
@@ -237,6 +240,24 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
                    const pb_blur_info *info, float alpha, float beta, int boundary, float *t1, float *t2, void *dst,
                    int dst_dtype, int clamp01) {
     const float a3 = alpha / 2 - beta + 2, a2 = 3 * beta - alpha - 6, a1 = 5 - 3 * beta + alpha / 2;
+    if (g.sep1) {
+        // K ~= K2 after K1 (estimate.hip: sep_records_kernel): u = K1 * t, then t' = scale (K2 * u) + coef x
+        ConvPass p1 = base_pass(g, g.sep1, boundary), p2 = base_pass(g, g.sep2, boundary);
+        set_x_virtual(p1, g, xsrc, x_dtype); set_out_padded(p1, g, g.sep_u);          // coef = 0: x is not used
+        set_in_padded(p2, g, g.sep_u); set_x_virtual(p2, g, xsrc, x_dtype);
+        const float scale[3] = {a3, 1.f, 1.f}, coef[3] = {a2, a1, beta};
+        float *tmp[2] = {t1, t2};
+        for (int step = 0; step < 3; ++step) {
+            if (step == 0) set_in_virtual(p1, g, xsrc, x_dtype); else set_in_padded(p1, g, tmp[step - 1]);
+            int rc = pb_launch_conv(ctx, p1);
+            if (rc) return rc;
+            if (step < 2) set_out_padded(p2, g, tmp[step]); else set_out_interior(p2, g, dst, dst_dtype);
+            p2.scale = scale[step]; p2.coef = coef[step]; p2.clamp01 = step == 2 ? clamp01 : 0;
+            rc = pb_launch_conv(ctx, p2);
+            if (rc) return rc;
+        }
+        return PB_OK;
+    }
     ConvPass p = base_pass(g, info, boundary);
     auto set_x = [&](ConvPass &q) { if (xpadded) set_x_padded(q, g, xpadded); else set_x_virtual(q, g, xsrc, x_dtype); };
     // t1 = K * (a3 x) + a2 x
@@ -338,6 +359,18 @@ int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *ho
     PB_HIP(hipMemcpyAsync(dev_info, h.data(), sizeof(pb_blur_info) * B, hipMemcpyHostToDevice, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
     return pb_make_kernels_dev(ctx, B, dev_info, support, 0);
+}
+
+int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *dev_sep, int support,
+                              int ker_size) {
+    if (!ctx || B < 1 || !dev_info || !dev_sep) return PB_ERR_BADARG;
+    pb_options o;
+    pb_default_options(&o);
+    o.ker_size = ker_size;
+    const int ksize = pb_kernel_size(&o);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", ker_size, PB_KSIZE);
+    PB_HIP(hipSetDevice(ctx->device));
+    return pb_make_sep_records(ctx, B, dev_info, dev_sep, support, ksize);
 }
 
 int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_blur_info *dev_info) {
@@ -476,8 +509,10 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (opt->boundary != PB_WRAP && opt->boundary != PB_ZERO) return pb_fail(ctx, PB_ERR_BADARG, "bad boundary");
     const int ksize = pb_kernel_size(opt);
     if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", opt->ker_size, PB_KSIZE);
+    if (opt->separable_approx && opt->edgetaping)
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "edgetaping is not defined for the separable approximation");
     PB_HIP(hipSetDevice(ctx->device));
-    const Geometry g = geometry(B, C, H, W, ksize / 2);
+    Geometry g = geometry(B, C, H, W, ksize / 2);
     const long n = (long)g.P * g.HW;
     const int n_iter = opt->n_iter;
     if (n_iter == 0) {
@@ -536,6 +571,13 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         ybuf = static_cast<float *>(pb_scratch(ctx, "pipe.y", sizeof(float) * n));
         if (!smooth || !ybuf) return PB_ERR_NOMEM;
     }
+    pb_blur_info *sep = nullptr;
+    if (opt->separable_approx && n_iter > 0) {
+        sep = static_cast<pb_blur_info *>(pb_scratch(ctx, "pipe.sepinfo", sizeof(pb_blur_info) * 2 * (size_t)B));
+        g.sep_u = static_cast<float *>(pb_scratch(ctx, "inv.u", sizeof(float) * g.P * g.pplane));
+        if (!sep || !g.sep_u) return PB_ERR_NOMEM;
+        g.sep1 = sep; g.sep2 = sep + B;
+    }
     const void *cur = in;
     for (int it = 0; it < n_iter; ++it) {
         // the last iteration must land in `out`; alternate between out and tmpimg before that
@@ -545,6 +587,10 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         pb_blur_info *info = infos + (size_t)it * B;
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
         if (rc) return rc;
+        if (sep) {
+            rc = pb_make_sep_records(ctx, B, info, sep, opt->support, ksize);
+            if (rc) return rc;
+        }
         if (opt->prefilter == PB_PREFILTER_NONE) {
             rc = inverse_filter(ctx, g, cur, cur_dtype, dst, dst_dtype, info, opt->alpha, opt->beta, opt->boundary,
                                 opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1);

@@ -130,6 +130,7 @@ int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // c
 // ------------------------------------------------------------------------------------
 int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W,
                      const pb_options *opt, pb_blur_info *dev_info);
+int pb_make_sep_records(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *sep, int support, int ksize);
 int pb_kernel_size(const pb_options *opt);      // validated ker_size (odd, 3..25); 0 if unsupported
 int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy);
 int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps, int ksize = PB_KSIZE);

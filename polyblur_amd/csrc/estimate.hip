@@ -844,6 +844,65 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     finish_record(info, support, false, red, ksize);
 }
 
+// method='direct_separable': the two correlation kernels of the x-t separable approximation of the image's Gaussian
+// (intent of separable_gaussian2d.cpp:91-183; include/polyblur_hip.h, pb_options.separable_approx, states the definition).
+// sep[b] = the 1-D pass along the narrower axis, sep[B + b] = the oblique pass (two taps per offset: linear
+// interpolation).  Both go through finish_record like caller-supplied taps, so the first is evaluated by the rank-1
+// body and the second by the general body over its ~25-50 live phases instead of 175.
+__global__ __launch_bounds__(NT) void sep_records_kernel(const pb_blur_info *infos, pb_blur_info *sep, int B, int support,
+                                                         int ksize) {
+    __shared__ float red[NT / 64];
+    __shared__ float g1[PB_KSIZE], g2[PB_KSIZE], sums[2];
+    const pb_blur_info *src = infos + blockIdx.x;
+    pb_blur_info *r1 = sep + blockIdx.x, *r2 = sep + B + blockIdx.x;
+    const int tid = threadIdx.x, rad = ksize / 2;
+    const float th = -src->theta;
+    const float c = cosf(th), sn = sinf(th);
+    const float i1 = 1.f / (src->sigma * src->sigma), i2 = 1.f / (src->rho * src->rho);
+    const float A = c * c * i1 + sn * sn * i2, Bq = sn * c * (i1 - i2), C = c * c * i2 + sn * sn * i1;
+    const bool x_first = A >= C;                       // the narrower axis first: |shear| <= 1
+    const float p = x_first ? A : C, o = x_first ? C : A;
+    const float det = p * o - Bq * Bq;
+    if (tid < PB_KSIZE) {
+        const float t = (float)(tid - PB_KRAD);
+        const bool in = abs(tid - PB_KRAD) <= rad;
+        g1[tid] = in ? expf(-0.5f * p * t * t) : 0.f;
+        g2[tid] = in ? expf(-0.5f * (det / p) * t * t) : 0.f;
+    }
+    for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT) { r1->kernel[idx] = 0.f; r2->kernel[idx] = 0.f; }
+    __syncthreads();
+    if (tid < 2) {
+        const float *g = tid ? g2 : g1;
+        float s = 0.f;
+        for (int i = 0; i < PB_KSIZE; ++i) s += g[i];
+        sums[tid] = s;
+    }
+    __syncthreads();
+    if (tid < PB_KSIZE && abs(tid - PB_KRAD) <= rad) {
+        const int i = tid - PB_KRAD;
+        const float w1 = g1[tid] / sums[0], w2 = g2[tid] / sums[1];
+        const float pos = (-Bq / p) * (float)i;
+        const float fl = floorf(pos), f = pos - fl;
+        const int m = (int)fl;
+        if (x_first) r1->kernel[PB_KRAD * PB_KSIZE + tid] = w1; else r1->kernel[tid * PB_KSIZE + PB_KRAD] = w1;
+        const float wa = w2 * (1.f - f), wb = w2 * f;
+        if (abs(m) <= rad && wa != 0.f) {
+            if (x_first) r2->kernel[tid * PB_KSIZE + PB_KRAD + m] = wa; else r2->kernel[(PB_KRAD + m) * PB_KSIZE + tid] = wa;
+        }
+        if (abs(m + 1) <= rad && wb != 0.f) {
+            if (x_first) r2->kernel[tid * PB_KSIZE + PB_KRAD + m + 1] = wb; else r2->kernel[(PB_KRAD + m + 1) * PB_KSIZE + tid] = wb;
+        }
+    }
+    if (tid == 0) {
+        r1->theta = r2->theta = src->theta; r1->sigma = r2->sigma = src->sigma; r1->rho = r2->rho = src->rho;
+        r1->i_min = r2->i_min = src->i_min; r1->gray_min = r2->gray_min = src->gray_min; r1->gray_max = r2->gray_max = src->gray_max;
+    }
+    __syncthreads();
+    finish_record(r1, support, true, red, ksize);
+    __syncthreads();
+    finish_record(r2, support, true, red, ksize);
+}
+
 __global__ __launch_bounds__(NT) void make_kernels_kernel(pb_blur_info *infos, int support, int from_taps, int ksize) {
     __shared__ float red[NT / 64];
     finish_record(infos + blockIdx.x, support, from_taps != 0, red, ksize);
@@ -1006,6 +1065,13 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 int pb_kernel_size(const pb_options *opt) {
     const int k = opt->ker_size == 0 ? PB_KSIZE : opt->ker_size;
     return (k >= 3 && k <= PB_KSIZE && (k & 1)) ? k : 0;
+}
+
+int pb_make_sep_records(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *sep, int support, int ksize) {
+    ProfScope prof(ctx, PB_PROF_PARAMS);
+    hipLaunchKernelGGL(sep_records_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, sep, B, support, ksize);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
 }
 
 int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps, int ksize) {

@@ -31,7 +31,10 @@ import numpy as np
 from . import _capi as capi
 from .engine import get_engine
 
-_METHODS = {"fft": capi.PB_WRAP, "direct": capi.PB_ZERO}
+# 'direct_separable': the reference's own separable path raises NameError (blur_estimation.py:77, filters.py:71,78); its
+# intent -- a 1-D pass followed by an oblique 1-D pass with linear interpolation, separable_gaussian2d.cpp:91-183 -- is an
+# opt-in APPROXIMATION of the 25x25 kernel here (zero boundary like 'direct'); rank-1 kernels are exact either way
+_METHODS = {"fft": capi.PB_WRAP, "direct": capi.PB_ZERO, "direct_separable": capi.PB_ZERO}
 _SUPPORT = {"full": capi.PB_SUPPORT_FULL, "adaptive": capi.PB_SUPPORT_ADAPTIVE}
 _PREFILTER = {"bilateral": capi.PB_PREFILTER_BILATERAL, "domain_transform": capi.PB_PREFILTER_DOMAIN_TRANSFORM,
               "normalized_convolution": capi.PB_PREFILTER_NORMALIZED_CONVOLUTION}
@@ -53,12 +56,8 @@ def _is_torch_tensor(x) -> bool:
 def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles, n_interpolated_angles,
                    remove_halo, edgetaping, prefiltering, discard_saturation, multichannel_kernel, method, support,
                    prefilter, force_theta_deg=-1.0):
-    if method == "direct_separable":
-        # the reference's own separable path raises NameError (blur_estimation.py:77, filters.py:71,78); its intent
-        # -- an x pass followed by an oblique pass with linear interpolation, separable_gaussian2d.cpp:91-183 -- is
-        # an APPROXIMATION of the 25x25 kernel and must not silently stand in for 'direct'
-        raise NotImplementedError("method='direct_separable' is not built (rank-1 kernels already take the separable "
-                                  "stencil body under 'fft' and 'direct')")
+    if method == "direct_separable" and edgetaping:
+        raise NotImplementedError("edgetaping is not defined for method='direct_separable'")
     if method not in _METHODS:
         raise ValueError("%s not implemented" % method)          # reference: deblurring.py:119 (never raised there)
     if support not in _SUPPORT:
@@ -82,7 +81,8 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
                                edgetaping=edgetaping,
                                prefilter=_PREFILTER[prefilter] if prefiltering else capi.PB_PREFILTER_NONE,
                                discard_saturation=discard_saturation, boundary=_METHODS[method],
-                               support=_SUPPORT[support], force_theta_deg=force_theta_deg, ker_size=ker_size)
+                               support=_SUPPORT[support], force_theta_deg=force_theta_deg, ker_size=ker_size,
+                               separable_approx=(method == "direct_separable"))
 
 
 def _info_to_dicts(info, n_angles, n_interp):

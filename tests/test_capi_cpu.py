@@ -64,7 +64,7 @@ def test_argument_validation_before_any_device_work():
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=12)
     with pytest.raises(NotImplementedError):
-        polyblur_deblurring(x, method="direct_separable")
+        polyblur_deblurring(x, method="direct_separable", edgetaping=True)
     with pytest.raises(ValueError):
         polyblur_deblurring(np.zeros((4,), np.float32))
     with pytest.raises(TypeError):

@@ -778,3 +778,41 @@ def test_kernel_sizes_against_oracle(k, shape):
         want, winfos = ref.polyblur_deblurring(x, n_iter=2, ker_size=k, method=method, return_info=True, **KW)
         assert [float(i["theta"][0]) for i in infos] == [float(i["theta"][0]) for i in winfos]
         assert maxabs(out.cpu().numpy(), want) < 2e-5, (k, method)
+
+
+# ---------------------------------------------------------------------------------------------
+# method='direct_separable': the opt-in x-t separable APPROXIMATION (intent of separable_gaussian2d.cpp:91-183).
+# Parity is against the oracle's restatement of the same approximation (unpinned: the reference's own code for this path
+# does not run); its distance to the exact 'direct' result is the method's stated tolerance.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,seed", [((1, 3, 96, 128), 3), ((2, 1, 70, 90), 8), ((1, 3, 200, 264), 12)])
+def test_direct_separable_matches_its_oracle(shape, seed):
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    x, _ = synthetic_blurry_batch(shape[0], shape[1], shape[2], shape[3], seed0=seed)
+    out, infos = polyblur_deblurring(torch.from_numpy(x).cuda(), n_iter=3, method="direct_separable", return_info=True, **KW)
+    want, winfos = ref.polyblur_deblurring(x, n_iter=3, method="direct_separable", return_info=True, **KW)
+    for k in range(shape[0]):
+        assert [float(i["theta"][k]) for i in infos] == [float(i["theta"][k]) for i in winfos]
+    assert maxabs(out.cpu().numpy(), want) < 3e-5
+    # stated tolerance of the approximation itself: within 5e-2 of the exact zero-boundary result, 5e-3 on average
+    exact = polyblur_deblurring(torch.from_numpy(x).cuda(), n_iter=3, method="direct", **KW).cpu().numpy()
+    d = np.abs(out.cpu().numpy() - exact)
+    assert d.max() < 5e-2 and d.mean() < 5e-3, (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("sigma,rho,deg", [(2.0, 1.0, 30.0), (4.0, 0.3, 42.0), (0.74, 0.4, 24.0), (3.0, 2.0, 66.0), (2.0, 1.0, 0.0),
+                                           (3.5, 0.5, 96.0), (1.5, 1.5, 48.0)])
+def test_direct_separable_records(eng, sigma, rho, deg):
+    """the two 1-D kernels built on the device equal the oracle's; the first is rank-1, the oblique one sparse"""
+    import ctypes as C
+    th = np.deg2rad(np.float32(deg))
+    base = eng.make_kernels([sigma], [rho], [th])
+    sep = eng.info_buffer("np.sep", 2)
+    eng._check(eng.lib.pb_make_separable_kernels(eng.ctx, 1, C.c_void_p(base.ptr), C.c_void_p(sep.ptr), capi.PB_SUPPORT_FULL, 25))
+    rec = eng.read_info(sep, 2)
+    k1, k2 = ref.separable_xt_kernels([th], [sigma], [rho])
+    assert maxabs(rec["kernel"][0], k1[0]) < 1e-6 and maxabs(rec["kernel"][1], k2[0]) < 2e-6
+    assert rec["separable"][0] == 1
+    if deg % 90 != 0 and sigma != rho:
+        assert rec["separable"][1] == 0 and 0 < rec["nphase"][1].sum() <= 80
