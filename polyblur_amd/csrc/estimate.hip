@@ -645,7 +645,12 @@ __device__ float block_sum(float v, float *red) {
 // Fills kernel (unless from_taps), marginals, autocorrelations, separability and radius of one
 // record.  Called by all NT threads of a block.
 __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red, int ksize) {
+    // Everything is derived in LDS from the taps; the record in global memory is only written (a dependent chain of
+    // global round trips made this single-workgroup kernel the longest latency of small calls).
+    __shared__ float sk[PB_KSIZE * PB_KSIZE], skx[PB_KSIZE], sky[PB_KSIZE];
+    __shared__ int nz[PB_KSIZE], s_radius, s_first;
     const int tid = threadIdx.x;
+    __syncthreads();                                    // (a previous call's readers of the shared arrays are done)
     if (!from_taps) {
         // blur_estimation.py:189-232
         const float th = -info->theta;
@@ -673,35 +678,41 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int idx = tid + q * NT;
-            if (idx < PB_KSIZE * PB_KSIZE) info->kernel[idx] = e[q] / total;
+            if (idx < PB_KSIZE * PB_KSIZE) { sk[idx] = e[q] / total; info->kernel[idx] = sk[idx]; }
         }
+    } else {
+        for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT) sk[idx] = info->kernel[idx];
     }
     __syncthreads();
+    float sx = 0.f, sy = 0.f;
     if (tid < PB_KSIZE) {
-        float sx = 0.f, sy = 0.f;
+        int any = 0;
         for (int i = 0; i < PB_KSIZE; ++i) {
-            sx += info->kernel[i * PB_KSIZE + tid];     // column sum -> kx[tid]
-            sy += info->kernel[tid * PB_KSIZE + i];     // row sum    -> ky[tid]
+            const float cv = sk[i * PB_KSIZE + tid], rv = sk[tid * PB_KSIZE + i];
+            sx += cv;                                   // column sum -> kx[tid]
+            sy += rv;                                   // row sum    -> ky[tid]
+            any |= (cv != 0.f) | (rv != 0.f);
         }
-        info->kx[tid] = sx;
-        info->ky[tid] = sy;
+        nz[tid] = any;
+        skx[tid] = sx;
+        sky[tid] = sy;
     }
     __syncthreads();
     // Symmetrise the marginals (a Gaussian's are symmetric up to the rounding of the sums above):
-    // the streaming stencil body keeps only taps 0..12 of each in scalar registers.
+    // the rank-1 stencil body keeps only taps 0..12 of each in scalar registers.
     float sxm = 0.f, sym = 0.f;
     if (tid < PB_KSIZE) {
-        sxm = 0.5f * (info->kx[tid] + info->kx[PB_KSIZE - 1 - tid]);
-        sym = 0.5f * (info->ky[tid] + info->ky[PB_KSIZE - 1 - tid]);
+        sxm = 0.5f * (skx[tid] + skx[PB_KSIZE - 1 - tid]);
+        sym = 0.5f * (sky[tid] + sky[PB_KSIZE - 1 - tid]);
     }
     __syncthreads();
-    if (tid < PB_KSIZE) { info->kx[tid] = sxm; info->ky[tid] = sym; }
+    if (tid < PB_KSIZE) { skx[tid] = sxm; sky[tid] = sym; info->kx[tid] = sxm; info->ky[tid] = sym; }
     __syncthreads();
     if (tid < PB_KSIZE) {
         float ax = 0.f, ay = 0.f;
         for (int n = 0; n + tid < PB_KSIZE; ++n) {
-            ax += info->kx[n] * info->kx[n + tid];
-            ay += info->ky[n] * info->ky[n + tid];
+            ax += skx[n] * skx[n + tid];
+            ay += sky[n] * sky[n + tid];
         }
         info->acorr_x[tid] = ax;
         info->acorr_y[tid] = ay;
@@ -709,20 +720,13 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     for (int idx = tid; idx < (PB_KSIZE + 1) * 32; idx += NT) {
         const int y = idx >> 5, j = (idx & 31) - 3;
         const bool row = y < PB_KSIZE;                  // row 25: zeros, the taps of filler phases
-        info->gtaps[idx] = (row && j >= 0 && j < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j] : 0.f;
-        info->gtaps_odd[idx] = (row && j + 1 >= 0 && j + 1 < PB_KSIZE) ? info->kernel[y * PB_KSIZE + j + 1] : 0.f;
-    }
-    __shared__ int nz[PB_KSIZE];
-    if (tid < PB_KSIZE) {
-        int any = 0;
-        for (int i = 0; i < PB_KSIZE; ++i)
-            any |= (info->kernel[i * PB_KSIZE + tid] != 0.f) | (info->kernel[tid * PB_KSIZE + i] != 0.f);
-        nz[tid] = any;
+        info->gtaps[idx] = (row && j >= 0 && j < PB_KSIZE) ? sk[y * PB_KSIZE + j] : 0.f;
+        info->gtaps_odd[idx] = (row && j + 1 >= 0 && j + 1 < PB_KSIZE) ? sk[y * PB_KSIZE + j + 1] : 0.f;
     }
     // rank-1 residual  sum |k - ky (x) kx|  and the total mass (for arbitrary taps)
     float res = 0.f;
     for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT)
-        res += fabsf(info->kernel[idx] - info->ky[idx / PB_KSIZE] * info->kx[idx % PB_KSIZE]);
+        res += fabsf(sk[idx] - sky[idx / PB_KSIZE] * skx[idx % PB_KSIZE]);
     const float resid = block_sum(res, red);
     if (tid == 0) {
         info->separable = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL)) ? 1 : 0;
@@ -733,10 +737,12 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         int rad = 0;
         for (int t = 0; t < PB_KSIZE; ++t) {
             const int d = t > PB_KRAD ? t - PB_KRAD : PB_KRAD - t;
-            const bool live = thr > 0.f ? (fabsf(info->kx[t]) >= thr || fabsf(info->ky[t]) >= thr) : (nz[t] != 0);
+            const bool live = thr > 0.f ? (fabsf(skx[t]) >= thr || fabsf(sky[t]) >= thr) : (nz[t] != 0);
             if (live && d > rad) rad = d;
         }
-        info->radius = rad <= 4 ? 4 : (rad <= 6 ? 6 : (rad <= 8 ? 8 : (rad <= 10 ? 10 : PB_KRAD)));
+        s_radius = rad <= 4 ? 4 : (rad <= 6 ? 6 : (rad <= 8 ? 8 : (rad <= 10 ? 10 : PB_KRAD)));
+        info->radius = s_radius;
+        s_first = 0;
     }
     __syncthreads();
     // The general stencil body walks a list of live (kernel row, window chunk) phases.  Chunk q of class R covers
@@ -745,13 +751,16 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     // box the marginals selected, the dropped taps are the corners outside the Gaussian's ellipse: < 7e-8 in total).
     {
         __shared__ int wcount[NT / 64];
-        const int R = info->radius, off = PB_KRAD - R, nq = R / 2 + 1;
+        const int R = s_radius, off = PB_KRAD - R, nq = R / 2 + 1;
         const int row = tid / 7, q = tid - row * 7;
         const float tap_thr = (support & 15) == PB_SUPPORT_ADAPTIVE ? 1e-10f : 0.f;
         bool live = false;
         if (row <= 2 * R && q < nq) {
-            const float *t = info->gtaps + (row + off) * 32 + 4 * q + off;
-            for (int i = 0; i < 7; ++i) live |= tap_thr > 0.f ? (fabsf(t[i]) >= tap_thr) : (t[i] != 0.f);
+            for (int i = 0; i < 7; ++i) {
+                const int j = 4 * q + off + i - 3;          // gtaps[y][n] = k[y][n - 3]
+                const float t = (j >= 0 && j < PB_KSIZE) ? sk[(row + off) * PB_KSIZE + j] : 0.f;
+                live |= tap_thr > 0.f ? (fabsf(t) >= tap_thr) : (t != 0.f);
+            }
         }
         // grouped by kind (inner chunks, then first chunks, then last chunks of a window row), row-major within a kind;
         // every group is padded to an even length with a filler phase (LDS row 0, the all-zero tap row 25): the
@@ -774,9 +783,11 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
             total += cnt + (cnt & 1);
         }
         // descriptor: byte offset of the chunk in the (64 + 2R)-wide LDS tile | index of its first tap in gtaps << 16
-        if (live) info->phase[before] = ((row * (64 + 2 * R) + 4 * q) * 4) | (((row + off) * 32 + 4 * q + off) << 16);
+        const int desc = ((row * (64 + 2 * R) + 4 * q) * 4) | (((row + off) * 32 + 4 * q + off) << 16);
+        if (live) info->phase[before] = desc;
+        if (live && before == 0) s_first = desc;         // phase[0] is always a live phase (fillers come after their group)
         __syncthreads();
-        if (tid < 3) info->phase[total + tid] = total ? info->phase[0] : 0;     // harmless targets for the prefetches
+        if (tid < 3) info->phase[total + tid] = total ? s_first : 0;     // harmless targets for the prefetches
     }
 }
 
