@@ -294,7 +294,13 @@ def main():
         # The synthetic blur is oblique (2 of the 30 candidate angles give a rank-1 kernel), so the estimated 25x25
         # kernels are dense and the stencil pass is fp32-VALU-bound, not HBM-bound: say how close to THAT ceiling it
         # runs (multiply-adds actually issued per launch / launch time; peak = 256 CU x 128 lanes x 2 x 2.4 GHz).
-        macs = [sum((2 * int(r) + 1) * (2 if sp else (2 * int(r) + 1)) for r, sp in zip(i["radius"], i["separable"])) / B
+        # multiply-adds issued per output sample and pass: rank-1 body 2 (2R+1) with R rounded up to 4/8/12; general body
+        # 4 per inner (kernel row, 4-tap segment) phase, 3 per first / last segment of a row (polyblur_hip.h: nphase)
+        def issued(r, sp, nph):
+            if sp:
+                return 2 * (2 * (4 if r <= 4 else (8 if r <= 8 else 12)) + 1)
+            return 4 * int(nph[0]) + 3 * (int(nph[1]) + int(nph[2]))
+        macs = [sum(issued(int(r), int(sp), nph) for r, sp, nph in zip(i["radius"], i["separable"], i["nphase"])) / B
                 for i in infos]                                   # per sample, per pass
         tflops = 2.0 * samples * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12 if conv_n else 0.0
         roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",

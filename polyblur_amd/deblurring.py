@@ -94,7 +94,8 @@ def _info_to_dicts(info, n_angles, n_interp):
         out.append(dict(mags=rec["mags"][:, :n_angles + 1].copy(), interp=rec["interp"][:, :n_interp].copy(),
                         i_min=rec["i_min"].copy(), theta=rec["theta"].copy(), sigma=rec["sigma"].copy(),
                         rho=rec["rho"].copy(), kernel=rec["kernel"].copy(), separable=rec["separable"].copy(),
-                        radius=rec["radius"].copy(), lo=rec["gray_min"].copy(), hi=rec["gray_max"].copy()))
+                        radius=rec["radius"].copy(), nphase=rec["nphase"].copy(), lo=rec["gray_min"].copy(),
+                        hi=rec["gray_max"].copy()))
     return out
 
 
