@@ -909,7 +909,7 @@ __global__ __launch_bounds__(NT) void sep_records_kernel(const pb_blur_info *inf
         r1->i_min = r2->i_min = src->i_min; r1->gray_min = r2->gray_min = src->gray_min; r1->gray_max = r2->gray_max = src->gray_max;
     }
     __syncthreads();
-    finish_record(r1, support, true, red, ksize);
+    finish_record(r1, support | PB_SUPPORT_FORCE_GENERAL, true, red, ksize);   // 7 live phases: cheaper than the rank-1 body, whose y pass would multiply by 24 zero taps
     __syncthreads();
     finish_record(r2, support, true, red, ksize);
 }
