@@ -100,6 +100,10 @@ typedef struct pb_options {
                                    interpolation; X and Y swap roles when C > A (keeps |shear| <= 1).  Both 1-D kernels
                                    are sampled on the ker_size grid and normalised to sum 1.  Opt-in: deviates from the
                                    exact kernel by ~1e-2 (tests state the bound).  Zero boundary; not with edgetaping. */
+    int32_t half_temporaries;   /* fp16 images only: store the two Horner temporaries t1, t2 as fp16 (accumulation and the
+                                   x operand stay fp32; the images between iterations stay fp32).  Opt-in: the temporaries
+                                   reach 9x the image range, where an fp16 ulp is 7.8e-3 -- measured 2e-3 .. 4.4e-3 from
+                                   the fp32-temporary result; default 0 = fp32 temporaries             */
     int32_t ker_size;           /* support of the estimated Gaussian and, halved, the replicate pad (deblurring.py:23,
                                    blur_estimation.py:211-232, utils.py:48-53): odd, 3 .. 25 (default 25; 0 means 25) */
 } pb_options;

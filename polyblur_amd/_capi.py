@@ -43,7 +43,7 @@ class pb_options(C.Structure):
         ("sigma_s", C.c_float), ("sigma_r", C.c_float), ("q", C.c_float), ("n_angles", C.c_int32),
         ("n_interpolated_angles", C.c_int32), ("remove_halo", C.c_int32), ("edgetaping", C.c_int32),
         ("prefilter", C.c_int32), ("discard_saturation", C.c_int32), ("boundary", C.c_int32),
-        ("support", C.c_int32), ("force_theta_deg", C.c_float), ("separable_approx", C.c_int32), ("ker_size", C.c_int32),
+        ("support", C.c_int32), ("force_theta_deg", C.c_float), ("separable_approx", C.c_int32), ("half_temporaries", C.c_int32), ("ker_size", C.c_int32),
     ]
 
 

@@ -177,6 +177,8 @@ struct Geometry {
     // method='direct_separable': records of the two 1-D passes that stand in for every reblurring, and the plane between them
     const pb_blur_info *sep1 = nullptr, *sep2 = nullptr;
     float *sep_u = nullptr;
+    // pb_options.half_temporaries: the two Horner temporaries are stored as fp16 (fp32 accumulation, fp32 x operand)
+    void *t1h = nullptr, *t2h = nullptr;
 };
 
 Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
@@ -198,8 +200,8 @@ ConvPass base_pass(const Geometry &g, const pb_blur_info *info, int boundary) {
 void set_in_virtual(ConvPass &p, const Geometry &g, const void *ptr, int dtype) {
     p.in = ptr; p.in_kind = SRC_VIRTUAL; p.in_dtype = dtype; p.in_pitch = g.W; p.in_plane = g.HW;
 }
-void set_in_padded(ConvPass &p, const Geometry &g, const float *ptr) {
-    p.in = ptr; p.in_kind = SRC_PADDED; p.in_dtype = PB_F32; p.in_pitch = g.pp; p.in_plane = g.pplane;
+void set_in_padded(ConvPass &p, const Geometry &g, const void *ptr, int dtype = PB_F32) {
+    p.in = ptr; p.in_kind = SRC_PADDED; p.in_dtype = dtype; p.in_pitch = g.pp; p.in_plane = g.pplane;
 }
 void set_x_virtual(ConvPass &p, const Geometry &g, const void *ptr, int dtype) {
     p.x = ptr; p.x_kind = SRC_VIRTUAL; p.x_dtype = dtype; p.x_pitch = g.W; p.x_plane = g.HW;
@@ -207,8 +209,8 @@ void set_x_virtual(ConvPass &p, const Geometry &g, const void *ptr, int dtype) {
 void set_x_padded(ConvPass &p, const Geometry &g, const float *ptr) {
     p.x = ptr; p.x_kind = SRC_PADDED; p.x_dtype = PB_F32; p.x_pitch = g.pp; p.x_plane = g.pplane;
 }
-void set_out_padded(ConvPass &p, const Geometry &g, float *ptr) {
-    p.out = ptr; p.out_kind = OUT_PADDED; p.out_dtype = PB_F32; p.out_pitch = g.pp; p.out_plane = g.pplane;
+void set_out_padded(ConvPass &p, const Geometry &g, void *ptr, int dtype = PB_F32) {
+    p.out = ptr; p.out_kind = OUT_PADDED; p.out_dtype = dtype; p.out_pitch = g.pp; p.out_plane = g.pplane;
 }
 void set_out_interior(ConvPass &p, const Geometry &g, void *ptr, int dtype) {
     p.out = ptr; p.out_kind = OUT_INTERIOR; p.out_dtype = dtype; p.out_pitch = g.W; p.out_plane = g.HW;
@@ -260,9 +262,11 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     }
     ConvPass p = base_pass(g, info, boundary);
     auto set_x = [&](ConvPass &q) { if (xpadded) set_x_padded(q, g, xpadded); else set_x_virtual(q, g, xsrc, x_dtype); };
+    const int tdt = g.t1h ? PB_F16 : PB_F32;
+    void *T1 = g.t1h ? g.t1h : static_cast<void *>(t1), *T2 = g.t2h ? g.t2h : static_cast<void *>(t2);
     // t1 = K * (a3 x) + a2 x
     if (xpadded) set_in_padded(p, g, xpadded); else set_in_virtual(p, g, xsrc, x_dtype);
-    set_x(p); set_out_padded(p, g, t1);
+    set_x(p); set_out_padded(p, g, T1, tdt);
     p.scale = a3; p.coef = a2;
     int rc = pb_launch_conv(ctx, p);
     if (rc) return rc;
@@ -282,12 +286,12 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     }
 #endif
     // t2 = K * t1 + a1 x
-    set_in_padded(p, g, t1); set_out_padded(p, g, t2);
+    set_in_padded(p, g, T1, tdt); set_out_padded(p, g, T2, tdt);
     p.scale = 1.f; p.coef = a1;
     rc = pb_launch_conv(ctx, p);
     if (rc) return rc;
     // y = K * t2 + beta x   (only the crop is needed)
-    set_in_padded(p, g, t2); set_out_interior(p, g, dst, dst_dtype);
+    set_in_padded(p, g, T2, tdt); set_out_interior(p, g, dst, dst_dtype);
     p.coef = beta; p.clamp01 = clamp01;
     return pb_launch_conv(ctx, p);
 }
@@ -300,9 +304,12 @@ struct InverseScratch {
 int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype, void *dst, int dst_dtype,
                    const pb_blur_info *info, float alpha, float beta, int boundary, int edgetaping, int remove_halo,
                    const float *g0x, const float *g0y, const float *nM, int final_clamp) {
-    float *t1 = static_cast<float *>(pb_scratch(ctx, "inv.t1", sizeof(float) * g.P * g.pplane));
-    float *t2 = static_cast<float *>(pb_scratch(ctx, "inv.t2", sizeof(float) * g.P * g.pplane));
-    if (!t1 || !t2) return PB_ERR_NOMEM;
+    float *t1 = nullptr, *t2 = nullptr;
+    if (!g.t1h) {
+        t1 = static_cast<float *>(pb_scratch(ctx, "inv.t1", sizeof(float) * g.P * g.pplane));
+        t2 = static_cast<float *>(pb_scratch(ctx, "inv.t2", sizeof(float) * g.P * g.pplane));
+        if (!t1 || !t2) return PB_ERR_NOMEM;
+    }
     const float *xpadded = nullptr;
     if (edgetaping) {
         float *pa = static_cast<float *>(pb_scratch(ctx, "inv.pa", sizeof(float) * g.P * g.pplane));
@@ -570,6 +577,13 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         smooth = static_cast<float *>(pb_scratch(ctx, "pipe.smooth", sizeof(float) * n));
         ybuf = static_cast<float *>(pb_scratch(ctx, "pipe.y", sizeof(float) * n));
         if (!smooth || !ybuf) return PB_ERR_NOMEM;
+    }
+    if (opt->half_temporaries) {
+        if (dtype != PB_F16 || opt->edgetaping || opt->separable_approx)
+            return pb_fail(ctx, PB_ERR_UNSUPPORTED, "half_temporaries: fp16 images only, not with edgetaping / separable_approx");
+        g.t1h = pb_scratch(ctx, "inv.t1h", sizeof(__half) * g.P * g.pplane);
+        g.t2h = pb_scratch(ctx, "inv.t2h", sizeof(__half) * g.P * g.pplane);
+        if (!g.t1h || !g.t2h) return PB_ERR_NOMEM;
     }
     pb_blur_info *sep = nullptr;
     if (opt->separable_approx && n_iter > 0) {

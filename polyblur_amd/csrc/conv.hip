@@ -324,6 +324,9 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p) {
         case 1: return launch_typed<float, float, __half>(ctx, p);
         case 3: return launch_typed<float, __half, float>(ctx, p);
         case 4: return launch_typed<float, __half, __half>(ctx, p);
+        // fp16 Horner temporaries (pb_options.half_temporaries) next to an fp32 x operand
+        case 9: return launch_typed<__half, float, float>(ctx, p);
+        case 10: return launch_typed<__half, float, __half>(ctx, p);
         case 12: return launch_typed<__half, __half, float>(ctx, p);
         case 13: return launch_typed<__half, __half, __half>(ctx, p);
         // 8-bit images: first pass of the first iteration, the later passes that still read the 8-bit x, and the

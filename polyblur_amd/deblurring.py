@@ -20,7 +20,8 @@ stencil kernels (no FFT convolution on the device).
 Extras that the reference does not have (all keyword-only, defaults keep reference
 behaviour): ``support`` ('full' | 'adaptive'), ``prefilter`` ('bilateral' |
 'domain_transform' -- which edge-aware filter ``prefiltering=True`` uses; the reference's
-live code path is the bilateral one, deblurring.py:107-108), ``return_info``.
+live code path is the bilateral one, deblurring.py:107-108), ``return_info``, ``temporaries``
+('fp32' | 'fp16': float16 tensors only -- store the two Horner temporaries as fp16).
 """
 from __future__ import annotations
 
@@ -55,11 +56,13 @@ def _is_torch_tensor(x) -> bool:
 
 def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles, n_interpolated_angles,
                    remove_halo, edgetaping, prefiltering, discard_saturation, multichannel_kernel, method, support,
-                   prefilter, force_theta_deg=-1.0):
+                   prefilter, force_theta_deg=-1.0, temporaries="fp32"):
     if method == "direct_separable" and edgetaping:
         raise NotImplementedError("edgetaping is not defined for method='direct_separable'")
     if method not in _METHODS:
         raise ValueError("%s not implemented" % method)          # reference: deblurring.py:119 (never raised there)
+    if temporaries not in ("fp32", "fp16"):
+        raise ValueError("temporaries must be 'fp32' or 'fp16'")
     if support not in _SUPPORT:
         raise ValueError("support must be 'full' or 'adaptive'")
     if prefilter not in _PREFILTER:
@@ -82,7 +85,7 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
                                prefilter=_PREFILTER[prefilter] if prefiltering else capi.PB_PREFILTER_NONE,
                                discard_saturation=discard_saturation, boundary=_METHODS[method],
                                support=_SUPPORT[support], force_theta_deg=force_theta_deg, ker_size=ker_size,
-                               separable_approx=(method == "direct_separable"))
+                               separable_approx=(method == "direct_separable"), half_temporaries=(temporaries == "fp16"))
 
 
 def _info_to_dicts(info, n_angles, n_interp):
@@ -115,7 +118,7 @@ def _print_stage_times(prof, wall):
 def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_r=0.8, sigma_s=2.0, ker_size=25, q=0.0,
                         n_angles=6, n_interpolated_angles=30, remove_halo=False, edgetaping=False, prefiltering=False,
                         discard_saturation=False, multichannel_kernel=False, method='fft', verbose=False, *,
-                        support='full', prefilter='bilateral', return_info=False, device=None):
+                        support='full', prefilter='bilateral', return_info=False, device=None, temporaries='fp32'):
     """Blind deblurring of ``img`` -- see the module docstring; reference deblurring.py:23-96."""
     start = time()
     if isinstance(img, np.ndarray):
@@ -153,9 +156,11 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
     if img.dtype not in (torch.float32, torch.float16):
         raise TypeError("tensor dtype must be float32 or float16 (the reference is float32-only)")
     _check_image_size(*img.shape[-2:])
+    if temporaries == "fp16" and img.dtype != torch.float16:
+        raise ValueError("temporaries='fp16' applies to float16 images only")
     opts = _build_options(img.shape[1], n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, n_angles,
                           n_interpolated_angles, remove_halo, edgetaping, prefiltering, discard_saturation,
-                          multichannel_kernel, method, support, prefilter)
+                          multichannel_kernel, method, support, prefilter, temporaries=temporaries)
     dtype = capi.PB_F32 if img.dtype == torch.float32 else capi.PB_F16
     if img.is_cuda:
         dev = img.device.index if img.device.index is not None else torch.cuda.current_device()

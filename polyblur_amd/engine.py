@@ -102,7 +102,7 @@ class Engine:
     def make_options(n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_r=0.8, sigma_s=2.0, q=0.0, n_angles=6,
                      n_interpolated_angles=30, remove_halo=False, edgetaping=False, prefilter=capi.PB_PREFILTER_NONE,
                      discard_saturation=False, boundary=capi.PB_WRAP, support=capi.PB_SUPPORT_FULL,
-                     force_theta_deg=-1.0, ker_size=capi.PB_KSIZE, separable_approx=False) -> capi.pb_options:
+                     force_theta_deg=-1.0, ker_size=capi.PB_KSIZE, separable_approx=False, half_temporaries=False) -> capi.pb_options:
         o = capi.pb_options()
         o.n_iter = int(n_iter); o.c = float(c); o.b = float(b); o.alpha = float(alpha); o.beta = float(beta)
         o.sigma_s = float(sigma_s); o.sigma_r = float(sigma_r); o.q = float(q); o.n_angles = int(n_angles)
@@ -112,6 +112,7 @@ class Engine:
         o.force_theta_deg = float(force_theta_deg)
         o.ker_size = int(ker_size)
         o.separable_approx = int(bool(separable_approx))
+        o.half_temporaries = int(bool(half_temporaries))
         return o
 
     # ---- raw-pointer entry points (device pointers as ints) --------------------------------

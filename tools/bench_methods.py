@@ -17,3 +17,21 @@ for name, extra in (("fft full", {}), ("fft adaptive", dict(support="adaptive"))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 100
     print("%-28s %.3f ms  %8.0f MP/s" % (name, ms, H * W / 1e3 / ms))
+if "--f16" in sys.argv:
+    for B, Hh, Ww, it in ((1, 4320, 7680, 5), (16, 1080, 1920, 3)):
+        nd = min(B, 4)
+        xs = synthetic_blurry_batch(nd, 3, Hh, Ww, seed0=DEFAULT_SEED)[0]
+        xh = torch.from_numpy(np.concatenate([xs] * (B // nd))).cuda().half()
+        kk = dict(kw, n_iter=it)
+        outs = {}
+        for th_name, th in (("oblique as estimated", {}),):
+            for tmp in ("fp32", "fp16"):
+                for sup in ("full", "adaptive"):
+                    for _ in range(2): o = polyblur_deblurring(xh, temporaries=tmp, support=sup, **kk)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(5): o = polyblur_deblurring(xh, temporaries=tmp, support=sup, **kk)
+                    torch.cuda.synchronize()
+                    ms = (time.perf_counter() - t0) * 200
+                    outs[(tmp, sup)] = o
+                    print("B=%d %dx%d n_iter=%d fp16 I/O, temporaries=%s support=%s: %.3f ms  %8.0f MP/s" % (B, Ww, Hh, it, tmp, sup, ms, B * Hh * Ww / 1e3 / ms))
+        print("   max |fp16 temporaries - fp32 temporaries| =", float((outs[("fp16", "full")].float() - outs[("fp32", "full")].float()).abs().max()))
