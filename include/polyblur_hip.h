@@ -128,6 +128,14 @@ typedef struct pb_blur_info {
                                            row 25 is all zeros (the taps of the list's filler phases) */
     float gtaps_odd[(PB_KSIZE + 1) * 32]; /* the same rows shifted by one tap (gtaps_odd[y][n] = gtaps[y][n+1]): the second
                                            alignment of adjacent tap pairs for the packed-FMA stencil */
+    /* x-t separable approximation (pb_options.separable_approx; filled in the SECOND record of a pair by
+     * pb_make_separable_kernels): xt_first = 1 when the 1-D pass runs along x and the oblique pass walks rows, 0 for the
+     * transposed arrangement; xt_g1 = the 1-D pass's taps; per offset i = -12..12 along the oblique pass's axis, the line
+     * sits xt_m[i] + f samples across it and the two neighbours get the weights xt_wa[i] = g2 (1-f), xt_wb[i] = g2 f.   */
+    int32_t xt_first;
+    float xt_g1[PB_KSIZE];
+    int32_t xt_m[PB_KSIZE];
+    float xt_wa[PB_KSIZE], xt_wb[PB_KSIZE];
     int32_t nphase[3];                  /* general (non rank-1) stencil: number of (kernel row, 4-tap segment) phases of
                                            kind 0 (inner chunk of a window row), 1 (first chunk), 2 (last chunk); each
                                            count is even (an all-zero filler phase pads an odd one)                  */

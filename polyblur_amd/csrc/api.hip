@@ -243,20 +243,32 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
                    int dst_dtype, int clamp01) {
     const float a3 = alpha / 2 - beta + 2, a2 = 3 * beta - alpha - 6, a1 = 5 - 3 * beta + alpha / 2;
     if (g.sep1) {
-        // K ~= K2 after K1 (estimate.hip: sep_records_kernel): u = K1 * t, then t' = scale (K2 * u) + coef x
-        ConvPass p1 = base_pass(g, g.sep1, boundary), p2 = base_pass(g, g.sep2, boundary);
-        set_x_virtual(p1, g, xsrc, x_dtype); set_out_padded(p1, g, g.sep_u);          // coef = 0: x is not used
-        set_in_padded(p2, g, g.sep_u); set_x_virtual(p2, g, xsrc, x_dtype);
+        // K ~= K2 after K1 (estimate.hip: sep_records_kernel).  One launch per step keeps u = K1 * t in LDS (conv_xt.hip);
+        // dtype combinations it is not built for (8-bit images) -- or PB_XT=2 -- take two launches through the sparse
+        // phase lists of the general body: u = K1 * t, then t' = scale (K2 * u) + coef x
+        static const bool two_launch = [] { const char *e = getenv("PB_XT"); return e && e[0] == '2'; }();
         const float scale[3] = {a3, 1.f, 1.f}, coef[3] = {a2, a1, beta};
         float *tmp[2] = {t1, t2};
+        ConvPass p1 = base_pass(g, g.sep1, boundary), p2 = base_pass(g, g.sep2, boundary);
+        set_x_virtual(p1, g, xsrc, x_dtype); set_out_padded(p1, g, g.sep_u);          // coef = 0: x is not used
+        set_x_virtual(p2, g, xsrc, x_dtype);
         for (int step = 0; step < 3; ++step) {
-            if (step == 0) set_in_virtual(p1, g, xsrc, x_dtype); else set_in_padded(p1, g, tmp[step - 1]);
-            int rc = pb_launch_conv(ctx, p1);
-            if (rc) return rc;
             if (step < 2) set_out_padded(p2, g, tmp[step]); else set_out_interior(p2, g, dst, dst_dtype);
             p2.scale = scale[step]; p2.coef = coef[step]; p2.clamp01 = step == 2 ? clamp01 : 0;
-            rc = pb_launch_conv(ctx, p2);
-            if (rc) return rc;
+            int rc = PB_ERR_UNSUPPORTED;
+            if (!two_launch) {
+                if (step == 0) set_in_virtual(p2, g, xsrc, x_dtype); else set_in_padded(p2, g, tmp[step - 1]);
+                rc = pb_launch_conv_xt(ctx, p2);
+                if (rc != PB_OK && rc != PB_ERR_UNSUPPORTED) return rc;
+            }
+            if (rc == PB_ERR_UNSUPPORTED) {
+                if (step == 0) set_in_virtual(p1, g, xsrc, x_dtype); else set_in_padded(p1, g, tmp[step - 1]);
+                rc = pb_launch_conv(ctx, p1);
+                if (rc) return rc;
+                set_in_padded(p2, g, g.sep_u);
+                rc = pb_launch_conv(ctx, p2);
+                if (rc) return rc;
+            }
         }
         return PB_OK;
     }

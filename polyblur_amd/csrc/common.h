@@ -123,7 +123,8 @@ struct ConvPass {
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
-int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // conv_fused.hip
+int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // conv_fused.hip (experimental build only)
+int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // conv_xt.hip
 
 // ------------------------------------------------------------------------------------
 // estimation (estimate.hip)

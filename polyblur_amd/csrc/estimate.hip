@@ -897,6 +897,11 @@ __global__ __launch_bounds__(NT) void sep_records_kernel(const pb_blur_info *inf
         const int m = (int)fl;
         if (x_first) r1->kernel[PB_KRAD * PB_KSIZE + tid] = w1; else r1->kernel[tid * PB_KSIZE + PB_KRAD] = w1;
         const float wa = w2 * (1.f - f), wb = w2 * f;
+        // the same numbers for the one-launch x-t body (conv_xt.hip), which applies them without forming the 2-D kernels
+        r2->xt_g1[tid] = w1;
+        r2->xt_m[tid] = m;
+        r2->xt_wa[tid] = (abs(m) <= rad) ? wa : 0.f;
+        r2->xt_wb[tid] = (abs(m + 1) <= rad) ? wb : 0.f;
         if (abs(m) <= rad && wa != 0.f) {
             if (x_first) r2->kernel[tid * PB_KSIZE + PB_KRAD + m] = wa; else r2->kernel[(PB_KRAD + m) * PB_KSIZE + tid] = wa;
         }
@@ -904,7 +909,9 @@ __global__ __launch_bounds__(NT) void sep_records_kernel(const pb_blur_info *inf
             if (x_first) r2->kernel[tid * PB_KSIZE + PB_KRAD + m + 1] = wb; else r2->kernel[(PB_KRAD + m + 1) * PB_KSIZE + tid] = wb;
         }
     }
+    if (tid < PB_KSIZE && abs(tid - PB_KRAD) > rad) { r2->xt_g1[tid] = 0.f; r2->xt_m[tid] = 0; r2->xt_wa[tid] = 0.f; r2->xt_wb[tid] = 0.f; }
     if (tid == 0) {
+        r2->xt_first = x_first ? 1 : 0;
         r1->theta = r2->theta = src->theta; r1->sigma = r2->sigma = src->sigma; r1->rho = r2->rho = src->rho;
         r1->i_min = r2->i_min = src->i_min; r1->gray_min = r2->gray_min = src->gray_min; r1->gray_max = r2->gray_max = src->gray_max;
     }

@@ -835,3 +835,23 @@ def test_half_temporaries_option():
         assert maxabs(b.float().cpu().numpy(), want) < 8e-3
     with pytest.raises(ValueError):
         polyblur_deblurring(xt.float(), temporaries="fp16", **KW)
+
+
+def test_direct_separable_fp16_and_kernel_size():
+    """the one-launch x-t pass with fp16 images (fp16 window / operand loads, fp16 store) and with a 13 x 13 kernel
+    (replicate pad 6: the patch of the intermediate image is cleared outside a smaller padded domain)"""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    x = synthetic_blurry_batch(2, 3, 120, 150, seed0=14)[0]
+    x16 = x.astype(np.float16)
+    out = polyblur_deblurring(torch.from_numpy(x16).cuda(), n_iter=3, method="direct_separable", **KW)
+    want = ref.polyblur_deblurring(x16.astype(np.float32), n_iter=3, method="direct_separable", **KW)
+    assert out.dtype == torch.float16 and maxabs(out.float().cpu().numpy(), want) < 1e-3
+    out = polyblur_deblurring(torch.from_numpy(x).cuda(), n_iter=2, method="direct_separable", ker_size=13, **KW)
+    want = ref.polyblur_deblurring(x, n_iter=2, method="direct_separable", ker_size=13, **KW)
+    assert maxabs(out.cpu().numpy(), want) < 3e-5
+    # tiny image: every tile is a border tile
+    xs = synthetic_blurry_batch(1, 1, 20, 30, seed0=15)[0]
+    out = polyblur_deblurring(torch.from_numpy(xs).cuda(), n_iter=2, method="direct_separable", **KW)
+    want = ref.polyblur_deblurring(xs, n_iter=2, method="direct_separable", **KW)
+    assert maxabs(out.cpu().numpy(), want) < 3e-5
