@@ -133,6 +133,7 @@ typedef struct pb_blur_info {
      * transposed arrangement; xt_g1 = the 1-D pass's taps; per offset i = -12..12 along the oblique pass's axis, the line
      * sits xt_m[i] + f samples across it and the two neighbours get the weights xt_wa[i] = g2 (1-f), xt_wb[i] = g2 f.   */
     int32_t xt_first;
+    int32_t xt_exact_rank1;             /* the image's EXACT kernel is rank-1: it takes the exact separable body instead */
     float xt_g1[PB_KSIZE];
     int32_t xt_m[PB_KSIZE];
     float xt_wa[PB_KSIZE], xt_wb[PB_KSIZE];

@@ -55,7 +55,7 @@ class pb_blur_info(C.Structure):
         ("kernel", C.c_float * (PB_KSIZE * PB_KSIZE)), ("kx", C.c_float * PB_KSIZE), ("ky", C.c_float * PB_KSIZE),
         ("acorr_y", C.c_float * PB_KSIZE), ("acorr_x", C.c_float * PB_KSIZE),
         ("gtaps", C.c_float * ((PB_KSIZE + 1) * 32)), ("gtaps_odd", C.c_float * ((PB_KSIZE + 1) * 32)),
-        ("xt_first", C.c_int32), ("xt_g1", C.c_float * PB_KSIZE), ("xt_m", C.c_int32 * PB_KSIZE),
+        ("xt_first", C.c_int32), ("xt_exact_rank1", C.c_int32), ("xt_g1", C.c_float * PB_KSIZE), ("xt_m", C.c_int32 * PB_KSIZE),
         ("xt_wa", C.c_float * PB_KSIZE), ("xt_wb", C.c_float * PB_KSIZE),
         ("nphase", C.c_int32 * 3), ("phase", C.c_int32 * (PB_MAX_PHASES + 9)),
     ]
@@ -66,7 +66,7 @@ INFO_DTYPE = np.dtype([
     ("i_min", "<i4"), ("theta", "<f4"), ("sigma", "<f4"), ("rho", "<f4"), ("separable", "<i4"), ("radius", "<i4"),
     ("kernel", "<f4", (PB_KSIZE, PB_KSIZE)), ("kx", "<f4", (PB_KSIZE,)), ("ky", "<f4", (PB_KSIZE,)),
     ("acorr_y", "<f4", (PB_KSIZE,)), ("acorr_x", "<f4", (PB_KSIZE,)), ("gtaps", "<f4", (PB_KSIZE + 1, 32)),
-    ("gtaps_odd", "<f4", (PB_KSIZE + 1, 32)), ("xt_first", "<i4"), ("xt_g1", "<f4", (PB_KSIZE,)),
+    ("gtaps_odd", "<f4", (PB_KSIZE + 1, 32)), ("xt_first", "<i4"), ("xt_exact_rank1", "<i4"), ("xt_g1", "<f4", (PB_KSIZE,)),
     ("xt_m", "<i4", (PB_KSIZE,)), ("xt_wa", "<f4", (PB_KSIZE,)), ("xt_wb", "<f4", (PB_KSIZE,)), ("nphase", "<i4", (3,)), ("phase", "<i4", (PB_MAX_PHASES + 9,)),
 ])
 assert INFO_DTYPE.itemsize == C.sizeof(pb_blur_info)

@@ -260,6 +260,13 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
                 if (step == 0) set_in_virtual(p2, g, xsrc, x_dtype); else set_in_padded(p2, g, tmp[step - 1]);
                 rc = pb_launch_conv_xt(ctx, p2);
                 if (rc != PB_OK && rc != PB_ERR_UNSUPPORTED) return rc;
+                if (rc == PB_OK) {
+                    // images whose exact kernel is rank-1 were skipped there: the exact separable body does them
+                    ConvPass pe = p2;
+                    pe.info = info; pe.skip_general = 1;
+                    rc = pb_launch_conv(ctx, pe);
+                    if (rc) return rc;
+                }
             }
             if (rc == PB_ERR_UNSUPPORTED) {
                 if (step == 0) set_in_virtual(p1, g, xsrc, x_dtype); else set_in_padded(p1, g, tmp[step - 1]);

@@ -119,7 +119,8 @@ struct ConvPass {
     int boundary;
     int epilogue;
     int clamp01;
-    int skip_sep;        // rank-1 images were handled by the fused two-step launch: their tiles exit at once
+    int skip_sep;        // rank-1 images are handled by another launch of this step: their tiles exit at once
+    int skip_general;    // non-rank-1 images are handled by another launch of this step (conv_xt.hip)
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int 
     const pb_blur_info *info = a.info + __builtin_amdgcn_readfirstlane(plane / a.C);
     const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
     const bool sep = cinfo->separable != 0;
-    if (sep && a.skip_sep) return;                                 // done by the fused two-step launch (conv_fused.hip)
+    if (sep ? a.skip_sep : a.skip_general) return;                 // another launch of this step does this image
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;

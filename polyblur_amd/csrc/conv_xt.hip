@@ -151,27 +151,33 @@ __device__ __forceinline__ void body_xt_rows(const ConvPass &a, const pb_blur_in
         xt_fma(acc[r][0], wa, A0); xt_fma(acc[r][1], wa, A1); xt_fma(acc[r][2], wa, A2); xt_fma(acc[r][3], wa, A3); \
         xt_fma(acc[r][0], wb, A1); xt_fma(acc[r][1], wb, A2); xt_fma(acc[r][2], wb, A3); xt_fma(acc[r][3], wb, A4); \
     }
-#pragma unroll 1
-    for (int i = 0; i < PB_KSIZE; ++i) {
-        const float wa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wav), i));
-        const float wb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wbv), i));
-        const int s = cb & 3;
-        const int inext = min(i + 1, PB_KSIZE - 1);
-        cb = XR + __builtin_amdgcn_readlane(mv, inext);
-        {
-            const float *p = base + inext * LP + (cb & ~3);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { nlo[r] = *reinterpret_cast<const xf4 *>(p + r * LP); nhi[r] = *reinterpret_cast<const xf4 *>(p + r * LP + 4); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s == 0) { PB_XT_ROW(lo[r].x, lo[r].y, lo[r].z, lo[r].w, hi[r].x) }
-        else if (s == 1) { PB_XT_ROW(lo[r].y, lo[r].z, lo[r].w, hi[r].x, hi[r].y) }
-        else if (s == 2) { PB_XT_ROW(lo[r].z, lo[r].w, hi[r].x, hi[r].y, hi[r].z) }
-        else { PB_XT_ROW(lo[r].w, hi[r].x, hi[r].y, hi[r].z, hi[r].w) }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { lo[r] = nlo[r]; hi[r] = nhi[r]; }
+    // two offsets per trip, the chunk registers ping-ponging (a copy per offset would cost as many moves as FMAs)
+#define PB_XT_OFFSET(I, LO, HI, NLO, NHI)                                                       \
+    {                                                                                          \
+        const float wa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wav), (I)));  \
+        const float wb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wbv), (I)));  \
+        const int s = cb & 3;                                                                  \
+        const int inext = min((I) + 1, PB_KSIZE - 1);                                          \
+        cb = XR + __builtin_amdgcn_readlane(mv, inext);                                        \
+        {                                                                                      \
+            const float *p = base + inext * LP + (cb & ~3);                                    \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                    \
+                NLO[r] = *reinterpret_cast<const xf4 *>(p + r * LP); NHI[r] = *reinterpret_cast<const xf4 *>(p + r * LP + 4); } \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (s == 0) { PB_XT_ROW(LO[r].x, LO[r].y, LO[r].z, LO[r].w, HI[r].x) }                 \
+        else if (s == 1) { PB_XT_ROW(LO[r].y, LO[r].z, LO[r].w, HI[r].x, HI[r].y) }            \
+        else if (s == 2) { PB_XT_ROW(LO[r].z, LO[r].w, HI[r].x, HI[r].y, HI[r].z) }            \
+        else { PB_XT_ROW(LO[r].w, HI[r].x, HI[r].y, HI[r].z, HI[r].w) }                        \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
     }
+#pragma unroll 1
+    for (int i = 0; i < PB_KSIZE - 1; i += 2) {
+        PB_XT_OFFSET(i, lo, hi, nlo, nhi)
+        PB_XT_OFFSET(i + 1, nlo, nhi, lo, hi)
+    }
+    PB_XT_OFFSET(PB_KSIZE - 1, lo, hi, nlo, nhi)
+#undef PB_XT_OFFSET
 #undef PB_XT_ROW
     float4 out[4];
 #pragma unroll
@@ -291,6 +297,7 @@ __global__ __launch_bounds__(NT, 4) void conv_xt_kernel(const ConvPass a, int ti
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
+    if (as_constant(info)->xt_exact_rank1) return;              // exact and cheaper in the rank-1 body (conv.hip, same step)
     if (as_constant(info)->xt_first) body_xt_rows<TIn, TX, TOut>(a, info, ipl, xpl, opl, local, tiles_x, smem);
     else body_xt_cols<TIn, TX, TOut>(a, info, ipl, xpl, opl, local, tiles_x, smem);
 }

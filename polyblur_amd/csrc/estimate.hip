@@ -912,6 +912,7 @@ __global__ __launch_bounds__(NT) void sep_records_kernel(const pb_blur_info *inf
     if (tid < PB_KSIZE && abs(tid - PB_KRAD) > rad) { r2->xt_g1[tid] = 0.f; r2->xt_m[tid] = 0; r2->xt_wa[tid] = 0.f; r2->xt_wb[tid] = 0.f; }
     if (tid == 0) {
         r2->xt_first = x_first ? 1 : 0;
+        r2->xt_exact_rank1 = src->separable;
         r1->theta = r2->theta = src->theta; r1->sigma = r2->sigma = src->sigma; r1->rho = r2->rho = src->rho;
         r1->i_min = r2->i_min = src->i_min; r1->gray_min = r2->gray_min = src->gray_min; r1->gray_max = r2->gray_max = src->gray_max;
     }

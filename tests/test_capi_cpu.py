@@ -40,7 +40,7 @@ def test_struct_layout_matches_header(lib):
     assert abs(o.sigma_r - 0.8) < 1e-7 and o.sigma_s == 2.0 and o.q == 0 and o.force_theta_deg == -1.0
     assert (o.remove_halo, o.edgetaping, o.prefilter, o.discard_saturation, o.boundary, o.support) == (0,) * 6
     assert o.ker_size == 25
-    assert ctypes.sizeof(capi.pb_blur_info) == capi.INFO_DTYPE.itemsize == 4 * (2 + 13 + 64 + 4 + 2 + 625 + 100 + 832 + 832 + 1 + 100 + 3 + 184)
+    assert ctypes.sizeof(capi.pb_blur_info) == capi.INFO_DTYPE.itemsize == 4 * (2 + 13 + 64 + 4 + 2 + 625 + 100 + 832 + 832 + 2 + 100 + 3 + 184)
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -12,6 +12,9 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 rm -rf "$OUT"; mkdir -p "$OUT"
 CMD=(python tools/bench_inner.py --only "$NAME")
+# a method name instead of an inner-loop flavour profiles whole calls: bash tools/pmc_inner.sh method:direct_separable out conv_xt
+case "$NAME" in method:*) CMD=(python tools/run_method.py "${NAME#method:}");; esac
+PAT=${4:-conv_}
 SETS=${3:-sq1 sq2 grbm tcc1 tcc2 tcc3 tcp1}
 run() { tag=$1; shift; case " $SETS " in *" $tag "*) timeout 150 rocprofv3 --pmc "$@" -d "$OUT/$tag" -o pmc -- "${CMD[@]}" > "$OUT/$tag.log" 2>&1;; esac; }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
@@ -21,5 +24,5 @@ run tcc1 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
 run tcc2 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run tcc3 TCC_WRITE_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_sum
 run tcp1 TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
-python tools/pmc_report.py "$OUT" conv_ 20 > "$OUT/report.txt" 2>&1
+python tools/pmc_report.py "$OUT" "$PAT" 20 > "$OUT/report.txt" 2>&1
 cat "$OUT/report.txt"
