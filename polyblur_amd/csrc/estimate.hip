@@ -415,11 +415,46 @@ __global__ __launch_bounds__(NT) void quant_scan_kernel(const unsigned *__restri
 // ------------------------------------------------------------------------------------
 // spectral derivative along rows: one workgroup = two rows packed as one complex line
 // ------------------------------------------------------------------------------------
-// NORMALIZE: lines are range-normalised on load with the per-image (lo, hi) in mm
+// normalize: lines are range-normalised on load with the per-image (lo, hi) in mm
 // (blur_estimation.py:92-93); planes_per_image maps a plane to its image's min/max.
-template <bool NORMALIZE>
-__global__ __launch_bounds__(NT) void grad_rows_kernel(const float *__restrict__ planes, float *__restrict__ gx,
-                                                       int H, int W, const unsigned *__restrict__ mm,
+// (x - lo) / scale clipped to [0, 1] (blur_estimation.py:92-93) with the quotient in three instructions instead of
+// the dozen of an IEEE division: q = a * r, then one correction step with the exact residual, r = RN(1 / scale)
+// computed once per workgroup (Markstein: the corrected quotient is the correctly rounded one, but for a scale whose
+// significand is all ones).  A constant image (scale == 0) gives NaN -> 0 either way.
+__device__ __forceinline__ float norm01(float x, float lo, float scale, float inv) {
+    const float a = x - lo;
+    float q = a * inv;
+    q = fmaf(fmaf(-q, scale, a), inv, q);
+    return fminf(fmaxf(q, 0.f), 1.f);
+}
+
+// how the fused transform (fft.h, spectral_derivative_fused) reaches the two rows of a workgroup
+struct RowsIO {
+    struct Pre {};
+    const float *row0, *row1;
+    float *o0;
+    int W;
+    bool has1, normalize;
+    float lo, scale, inv;
+    __device__ __forceinline__ float2 load(int p, int) const {
+        float a = row0[p], b = has1 ? row1[p] : 0.f;
+        if (normalize) {
+            a = norm01(a, lo, scale, inv);
+            b = has1 ? norm01(b, lo, scale, inv) : 0.f;
+        }
+        return make_float2(a, b);
+    }
+    __device__ __forceinline__ Pre prefetch(int, int) const { return Pre(); }
+    __device__ __forceinline__ void store(int p, int, float2 v, Pre) const {
+        o0[p] = v.x;
+        if (has1) o0[W + p] = -v.y;
+    }
+};
+
+// NTH == 128: the fused transform (direct plans of two or more stages); NTH == 256: the general one (Bluestein, one stage)
+template <int NTH>
+__global__ __launch_bounds__(NTH) void grad_rows_kernel(const float *__restrict__ planes, float *__restrict__ gx,
+                                                       int H, int W, int normalize, const unsigned *__restrict__ mm,
                                                        int planes_per_image, pbfft::DevPlan plan) {
     extern __shared__ __attribute__((aligned(16))) float2 sfft[];
     const int pairs = (H + 1) / 2;
@@ -429,34 +464,40 @@ __global__ __launch_bounds__(NT) void grad_rows_kernel(const float *__restrict__
     const float *row0 = planes + ((long)plane * H + r0) * W;
     const float *row1 = row0 + W;
     float lo = 0.f, scale = 1.f;
-    if (NORMALIZE) {
+    if (normalize) {
         const int img = plane / planes_per_image;
         lo = pb_ord2f(mm[2 * img]);
         scale = pb_ord2f(mm[2 * img + 1]) - lo;
+    }
+    const float inv = 1.f / scale;
+    if constexpr (NTH == 128) {
+        RowsIO io{row0, row1, gx + ((long)plane * H + r0) * W, W, has1, normalize != 0, lo, scale, inv};
+        pbfft::spectral_derivative_fused(sfft, plan, 0, io);
+        return;
     }
     const bool vec = (W & 3) == 0;                 // rows are 16-byte aligned: whole-row float4 traffic
     if (vec) {
         const int W4 = W >> 2;
         const float4 *r0 = reinterpret_cast<const float4 *>(row0), *r1 = reinterpret_cast<const float4 *>(row1);
-        for (int base = 0; base < W4; base += 4 * NT) {
+        for (int base = 0; base < W4; base += 4 * NTH) {
             float4 a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                      // all loads of the batch in flight together
-                const int i = base + u * NT + threadIdx.x;
+                const int i = base + u * NTH + threadIdx.x;
                 a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 b[u] = a[u];
                 if (i < W4) { a[u] = r0[i]; if (has1) b[u] = r1[i]; }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = base + u * NT + threadIdx.x;
+                const int i = base + u * NTH + threadIdx.x;
                 if (i < W4) {
                     float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (NORMALIZE) {
-                            av[e] = fminf(fmaxf((av[e] - lo) / scale, 0.f), 1.f);
-                            bv[e] = has1 ? fminf(fmaxf((bv[e] - lo) / scale, 0.f), 1.f) : 0.f;
+                        if (normalize) {
+                            av[e] = norm01(av[e], lo, scale, inv);
+                            bv[e] = has1 ? norm01(bv[e], lo, scale, inv) : 0.f;
                         }
                         sfft[4 * i + e] = make_float2(av[e], bv[e]);
                     }
@@ -464,11 +505,11 @@ __global__ __launch_bounds__(NT) void grad_rows_kernel(const float *__restrict__
             }
         }
     } else {
-        for (int n = threadIdx.x; n < W; n += NT) {
+        for (int n = threadIdx.x; n < W; n += NTH) {
             float a = row0[n], b = has1 ? row1[n] : 0.f;
-            if (NORMALIZE) {
-                a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
-                b = has1 ? fminf(fmaxf((b - lo) / scale, 0.f), 1.f) : 0.f;
+            if (normalize) {
+                a = norm01(a, lo, scale, inv);
+                b = has1 ? norm01(b, lo, scale, inv) : 0.f;
             }
             sfft[n] = make_float2(a, b);
         }
@@ -478,13 +519,13 @@ __global__ __launch_bounds__(NT) void grad_rows_kernel(const float *__restrict__
     float *o0 = gx + ((long)plane * H + r0) * W;
     if (vec) {
         const int W4 = W >> 2;
-        for (int i = threadIdx.x; i < W4; i += NT) {
+        for (int i = threadIdx.x; i < W4; i += NTH) {
             const float2 v0 = sfft[4 * i], v1 = sfft[4 * i + 1], v2 = sfft[4 * i + 2], v3 = sfft[4 * i + 3];
             reinterpret_cast<float4 *>(o0)[i] = make_float4(v0.x, v1.x, v2.x, v3.x);
             if (has1) reinterpret_cast<float4 *>(o0 + W)[i] = make_float4(-v0.y, -v1.y, -v2.y, -v3.y);
         }
     } else {
-        for (int n = threadIdx.x; n < W; n += NT) {
+        for (int n = threadIdx.x; n < W; n += NTH) {
             const float2 v = sfft[n];
             o0[n] = v.x;
             if (has1) o0[W + n] = -v.y;
@@ -496,12 +537,99 @@ __global__ __launch_bounds__(NT) void grad_rows_kernel(const float *__restrict__
 // spectral derivative along columns: one workgroup = 2*NB adjacent columns (NB complex lines)
 // MODE 0: write gy.  MODE 1: fuse the directional maxima (needs gx of the same plane).
 // ------------------------------------------------------------------------------------
-template <int MODE, bool NORMALIZE>
-__global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__ planes, const float *__restrict__ gx,
-                                                       float *__restrict__ gy, int H, int W, int lognb,
+// workgroup maximum of every direction -> one partial row per column tile; blur_params_kernel folds them
+// (no contended atomics).  red: NT/64 * PB_MAX_ANGLES floats of LDS nobody else is using.
+template <int NTH>
+__device__ __forceinline__ void reduce_maxima(const float (&best)[PB_MAX_ANGLES], float *red, unsigned *__restrict__ mags,
+                                              int tile_id, int n_angles) {
+#pragma unroll
+    for (int k = 0; k < PB_MAX_ANGLES; ++k) {
+        float m = best[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * PB_MAX_ANGLES + k] = m;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= n_angles) {
+        float m = red[threadIdx.x];
+        for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w * PB_MAX_ANGLES + threadIdx.x]);
+        mags[(long)tile_id * PB_MAX_ANGLES + threadIdx.x] = __float_as_uint(m);   // m >= 0
+    }
+}
+
+// cos / sin of the n_angles + 1 directions k pi / n_angles (blur_estimation.py:129-131), evaluated once on the host
+struct AngleTable {
+    float cs[PB_MAX_ANGLES], sn[PB_MAX_ANGLES];
+};
+
+// how the fused transform reaches the 2*nb columns of a workgroup.  MODE 0 writes gy; MODE 1 folds every output
+// sample, with the gx of the same position, into the directional maxima (NA > 0: n_angles + 1 at compile time).
+template <int MODE, int NA> struct ColsIO {
+    struct Pre { float2 dx, g; };
+    const float *src, *gxp;
+    float *dst;
+    int W, c0, na;
+    bool vec2, discard_sat, normalize;
+    float lo, scale, inv, sat_threshold;
+    AngleTable ang;
+    float best[PB_MAX_ANGLES];
+    __device__ __forceinline__ float2 load(int p, int j) const {
+        const int c = c0 + 2 * j;
+        float2 v = make_float2(0.f, 0.f);
+        if (vec2) v = *reinterpret_cast<const float2 *>(src + (long)p * W + c);
+        else {
+            if (c < W) v.x = src[(long)p * W + c];
+            if (c + 1 < W) v.y = src[(long)p * W + c + 1];
+        }
+        if (normalize) {
+            v.x = norm01(v.x, lo, scale, inv);
+            v.y = norm01(v.y, lo, scale, inv);
+        }
+        return v;
+    }
+    __device__ __forceinline__ Pre prefetch(int p, int j) const {
+        Pre r;
+        r.dx = make_float2(0.f, 0.f);
+        r.g = make_float2(0.f, 0.f);
+        if (MODE == 1) {
+            const int c = c0 + 2 * j;
+            const long idx = (long)p * W + c;
+            if (vec2) {
+                r.dx = *reinterpret_cast<const float2 *>(gxp + idx);
+                if (discard_sat) r.g = *reinterpret_cast<const float2 *>(src + idx);
+            } else {
+                if (c < W) { r.dx.x = gxp[idx]; if (discard_sat) r.g.x = src[idx]; }
+                if (c + 1 < W) { r.dx.y = gxp[idx + 1]; if (discard_sat) r.g.y = src[idx + 1]; }
+            }
+        }
+        return r;
+    }
+    __device__ __forceinline__ void fold(float dx, float dy) {
+        // m_k = max |cos(t_k) gx - sin(t_k) gy|  (blur_estimation.py:129-133)
+#pragma unroll
+        for (int k = 0; k < (NA ? NA : PB_MAX_ANGLES); ++k)
+            if (NA || k < na) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
+    }
+    __device__ __forceinline__ void store(int p, int j, float2 v, const Pre &pre) {
+        const int c = c0 + 2 * j;
+        if (MODE == 0) {
+            if (c < W) dst[(long)p * W + c] = v.x;
+            if (c + 1 < W) dst[(long)p * W + c + 1] = -v.y;
+        } else {
+            // gradients are zeroed under the saturation mask (blur_estimation.py:117-118): they cannot raise a maximum
+            if (c < W && !(discard_sat && pre.g.x > sat_threshold)) fold(pre.dx.x, v.x);
+            if (c + 1 < W && !(discard_sat && pre.g.y > sat_threshold)) fold(pre.dx.y, -v.y);
+        }
+    }
+};
+
+template <int MODE, int NA, int NTH>
+__global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict__ planes, const float *__restrict__ gx,
+                                                       float *__restrict__ gy, int H, int W, int lognb, int normalize,
                                                        const unsigned *__restrict__ mm, int planes_per_image,
                                                        unsigned *__restrict__ mags, int n_angles, int discard_sat,
-                                                       float sat_threshold, int total_tiles, pbfft::DevPlan plan) {
+                                                       float sat_threshold, int total_tiles, pbfft::DevPlan plan,
+                                                       AngleTable ang) {
     extern __shared__ __attribute__((aligned(16))) float2 sfft[];
     const int nb = 1 << lognb;
     const int tc = 2 * nb;
@@ -515,18 +643,33 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
     const int c0 = (tile_id - plane * tiles) * tc;
     const float *src = planes + (long)plane * H * W;
     float lo = 0.f, scale = 1.f;
-    if (NORMALIZE) {
+    if (normalize) {
         const int img = plane / planes_per_image;
         lo = pb_ord2f(mm[2 * img]);
         scale = pb_ord2f(mm[2 * img + 1]) - lo;
     }
+    const float inv = 1.f / scale;
     // element e = p*nb + j  <->  row p, columns c0+2j, c0+2j+1
     const bool vec2 = (W & 1) == 0 && c0 + tc <= W;          // every pair is an aligned, in-range float2
-    for (int base = 0; base < (H << lognb); base += 8 * NT) {
+    if (pbfft::fused_plan(plan)) {
+        ColsIO<MODE, NA> io;
+        io.src = src; io.gxp = gx + (long)plane * H * W; io.dst = gy + (long)plane * H * W;
+        io.W = W; io.c0 = c0; io.na = n_angles + 1; io.vec2 = vec2; io.discard_sat = discard_sat != 0; io.normalize = normalize != 0;
+        io.lo = lo; io.scale = scale; io.inv = inv; io.sat_threshold = sat_threshold; io.ang = ang;
+#pragma unroll
+        for (int k = 0; k < PB_MAX_ANGLES; ++k) io.best[k] = 0.f;
+        pbfft::spectral_derivative_fused(sfft, plan, lognb, io);
+        if (MODE == 1) {
+            __syncthreads();
+            reduce_maxima<NTH>(io.best, reinterpret_cast<float *>(sfft), mags, tile_id, n_angles);
+        }
+        return;
+    }
+    for (int base = 0; base < (H << lognb); base += 8 * NTH) {
         float2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {                          // 8 independent loads in flight per thread
-            const int e = base + u * NT + threadIdx.x;
+            const int e = base + u * NTH + threadIdx.x;
             v[u] = make_float2(0.f, 0.f);
             if (e < (H << lognb)) {
                 const int p = e >> lognb, j = e & (nb - 1);
@@ -540,12 +683,12 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = base + u * NT + threadIdx.x;
+            const int e = base + u * NTH + threadIdx.x;
             if (e < (H << lognb)) {
                 float a = v[u].x, b = v[u].y;
-                if (NORMALIZE) {
-                    a = fminf(fmaxf((a - lo) / scale, 0.f), 1.f);
-                    b = fminf(fmaxf((b - lo) / scale, 0.f), 1.f);
+                if (normalize) {
+                    a = norm01(a, lo, scale, inv);
+                    b = norm01(b, lo, scale, inv);
                 }
                 sfft[e] = make_float2(a, b);
             }
@@ -555,7 +698,7 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
     pbfft::spectral_derivative(sfft, plan, lognb);
     if (MODE == 0) {
         float *dst = gy + (long)plane * H * W;
-        for (int e = threadIdx.x; e < (H << lognb); e += NT) {
+        for (int e = threadIdx.x; e < (H << lognb); e += NTH) {
             const int p = e >> lognb, j = e & (nb - 1);
             const int c = c0 + 2 * j;
             const float2 v = sfft[e];
@@ -564,18 +707,15 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
         }
     } else {
         // m_k = max |cos(t_k) gx - sin(t_k) gy|, t_k = k pi / n_angles  (blur_estimation.py:129-133)
-        float cs[PB_MAX_ANGLES], sn[PB_MAX_ANGLES], best[PB_MAX_ANGLES];
+        float best[PB_MAX_ANGLES];
 #pragma unroll
-        for (int k = 0; k < PB_MAX_ANGLES; ++k) {
-            const float t = 3.14159265358979323846f * (float)k / (float)n_angles;
-            cs[k] = cosf(t); sn[k] = sinf(t); best[k] = 0.f;
-        }
+        for (int k = 0; k < PB_MAX_ANGLES; ++k) best[k] = 0.f;
         const float *gxp = gx + (long)plane * H * W;
-        for (int base = 0; base < (H << lognb); base += 8 * NT) {
+        for (int base = 0; base < (H << lognb); base += 8 * NTH) {
             float2 dxv[8], gv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = base + u * NT + threadIdx.x;
+                const int e = base + u * NTH + threadIdx.x;
                 dxv[u] = make_float2(0.f, 0.f);
                 gv[u] = make_float2(0.f, 0.f);
                 if (e < (H << lognb)) {
@@ -592,7 +732,7 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = base + u * NT + threadIdx.x;
+                const int e = base + u * NTH + threadIdx.x;
                 if (e >= (H << lognb)) continue;
                 const int j = e & (nb - 1);
                 const int c = c0 + 2 * j;
@@ -605,26 +745,12 @@ __global__ __launch_bounds__(NT) void grad_cols_kernel(const float *__restrict__
                     const float dy = h ? -vv.y : vv.x;
 #pragma unroll
                     for (int k = 0; k < PB_MAX_ANGLES; ++k)
-                        if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(cs[k] * dx - sn[k] * dy));
+                        if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
                 }
             }
         }
         __syncthreads();
-        float *red = reinterpret_cast<float *>(sfft);
-#pragma unroll
-        for (int k = 0; k < PB_MAX_ANGLES; ++k) {
-            float m = best[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * PB_MAX_ANGLES + k] = m;
-        }
-        __syncthreads();
-        if ((int)threadIdx.x <= n_angles) {
-            float m = red[threadIdx.x];
-            for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, red[w * PB_MAX_ANGLES + threadIdx.x]);
-            // one partial row per column tile; blur_params_kernel folds them (no contended atomics)
-            mags[(long)tile_id * PB_MAX_ANGLES + threadIdx.x] = __float_as_uint(m);   // m >= 0
-        }
+        reduce_maxima<NTH>(best, reinterpret_cast<float *>(sfft), mags, tile_id, n_angles);
     }
 }
 
@@ -950,6 +1076,8 @@ int pick_lognb(const FftPlan *pl, int W) {
     return lognb;
 }
 
+// Rows: a workgroup's transform is a chain of dependent stages and 30 KB of LDS per two 3840-sample rows fit five
+// workgroups per CU, which the registers of 256-thread workgroups did not (three): the fused transform runs with 128.
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
                 const unsigned *mm, int planes_per_image) {
     const FftPlan *pl = pb_get_plan(ctx, W);
@@ -958,14 +1086,17 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     if (lds > kMaxLds) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image width %d too large for the in-LDS FFT", W);
     const long blocks = (long)P * ((H + 1) / 2);
     const pbfft::DevPlan dp = dev_plan(pl);
+    const bool fused = !pl->bluestein_m && pl->nstage >= 2;          // as pbfft::fused_plan
     ProfScope prof(ctx, PB_PROF_GRAD_ROWS);
-    if (normalize) {
-        int rc = allow_lds(ctx, grad_rows_kernel<true>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(grad_rows_kernel<true>, dim3((unsigned)blocks), dim3(NT), lds, ctx->stream, planes, gx, H, W, mm, planes_per_image, dp);
-    } else {
-        int rc = allow_lds(ctx, grad_rows_kernel<false>, lds); if (rc) return rc;
-        hipLaunchKernelGGL(grad_rows_kernel<false>, dim3((unsigned)blocks), dim3(NT), lds, ctx->stream, planes, gx, H, W, mm, planes_per_image, dp);
-    }
+#define PB_ROWS(NTH)                                                                                             \
+    do {                                                                                                         \
+        int rc = allow_lds(ctx, grad_rows_kernel<NTH>, lds);                                                     \
+        if (rc) return rc;                                                                                       \
+        hipLaunchKernelGGL((grad_rows_kernel<NTH>), dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream,         \
+                           planes, gx, H, W, normalize ? 1 : 0, mm, planes_per_image, dp);                       \
+    } while (0)
+    if (fused) PB_ROWS(128); else PB_ROWS(256);
+#undef PB_ROWS
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
@@ -983,16 +1114,23 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     const pbfft::DevPlan dp = dev_plan(pl);
     const float thr = 0.99f;
     ProfScope prof(ctx, PB_PROF_GRAD_COLS);
-#define PB_COLS(MODE, NORM)                                                                                      \
+    AngleTable ang;
+    for (int k = 0; k < PB_MAX_ANGLES; ++k) {
+        const float t = n_angles > 0 ? 3.14159265358979323846f * (float)k / (float)n_angles : 0.f;
+        ang.cs[k] = std::cos(t);
+        ang.sn[k] = std::sin(t);
+    }
+#define PB_COLS(MODE, NA)                                                                                        \
     do {                                                                                                         \
-        int rc = allow_lds(ctx, grad_cols_kernel<MODE, NORM>, lds);                                              \
+        int rc = allow_lds(ctx, grad_cols_kernel<MODE, NA, NT>, lds);                                            \
         if (rc) return rc;                                                                                       \
-        hipLaunchKernelGGL((grad_cols_kernel<MODE, NORM>), dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(NT), lds,  \
-                           ctx->stream, planes, gx, gy, H, W, lognb, mm, planes_per_image, mags, n_angles,        \
-                           discard_sat, thr, (int)blocks, dp);                                                    \
+        hipLaunchKernelGGL((grad_cols_kernel<MODE, NA, NT>), dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(NT),   \
+                           lds, ctx->stream, planes, gx, gy, H, W, lognb, normalize ? 1 : 0, mm,                 \
+                           planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);            \
     } while (0)
-    if (mode == 0) { if (normalize) PB_COLS(0, true); else PB_COLS(0, false); }
-    else { if (normalize) PB_COLS(1, true); else PB_COLS(1, false); }
+    if (mode == 0) PB_COLS(0, 0);
+    else if (n_angles == 6) PB_COLS(1, 7);          // the default grid of directions, unrolled
+    else PB_COLS(1, 0);
 #undef PB_COLS
     PB_LAUNCH_CHECK();
     return PB_OK;

@@ -14,6 +14,10 @@
 // barrier per stage); NB interleaved lines are transformed together (element (p, j) lives at
 // s[p*NB + j]) so that consecutive lanes touch consecutive LDS words.
 //
+// Direct plans of two or more stages run the fused form (spectral_derivative_fused): the first stage reads global memory,
+// the innermost DIF stage + multiplier + innermost DIT stage run in registers, the last stage feeds the caller's epilogue
+// -- four LDS round trips and barriers for a 3840-point line instead of eight.
+//
 // Lengths whose prime factors are all <= 7 use radices up to 16 (composites 16/15/12/10/9/8/6 are evaluated
 // in registers as two-level Cooley-Tukey, so a 3840-point line needs 3 LDS passes, not 6); any other length
 // goes through Bluestein's chirp-z with a power-of-two inner length (plan.bluestein_m).
@@ -22,7 +26,6 @@
 
 namespace pbfft {
 
-constexpr int NT = 256;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -78,8 +81,31 @@ template <int R> __device__ __forceinline__ void dft_odd(float2 (&v)[R], const f
 #pragma unroll
     for (int k = 0; k < R; ++k) v[k] = o[k];
 }
-template <> __device__ __forceinline__ void dft_small<3>(float2 (&v)[3]) { dft_odd<3>(v, kCos3, kSin3); }
-template <> __device__ __forceinline__ void dft_small<5>(float2 (&v)[5]) { dft_odd<5>(v, kCos5, kSin5); }
+// 3 and 5 points in the Rader/Winograd form (sums and differences of the mirrored pairs first): 7 and 21 complex
+// operations instead of the 12 and 40 of the matrix form above -- radices 3, 5, 6, 9, 10, 12, 15 are built on them
+template <> __device__ __forceinline__ void dft_small<3>(float2 (&v)[3]) {
+    const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    const float s = 0.86602540378443864676f;
+    v[0] = cadd(v[0], t);
+    v[1] = make_float2(m.x + s * d.y, m.y - s * d.x);       // m - i s d
+    v[2] = make_float2(m.x - s * d.y, m.y + s * d.x);
+}
+template <> __device__ __forceinline__ void dft_small<5>(float2 (&v)[5]) {
+    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const float2 t5 = cadd(t1, t2);
+    const float c = 0.55901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const float2 m1 = make_float2(v[0].x - 0.25f * t5.x, v[0].y - 0.25f * t5.y);
+    const float2 m2 = make_float2(c * (t1.x - t2.x), c * (t1.y - t2.y));
+    const float2 a1 = cadd(m1, m2), a2 = csub(m1, m2);
+    const float2 b1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    const float2 b2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    v[0] = cadd(v[0], t5);
+    v[1] = make_float2(a1.x + b1.y, a1.y - b1.x);           // a1 - i b1
+    v[4] = make_float2(a1.x - b1.y, a1.y + b1.x);
+    v[2] = make_float2(a2.x + b2.y, a2.y - b2.x);
+    v[3] = make_float2(a2.x - b2.y, a2.y + b2.x);
+}
 template <> __device__ __forceinline__ void dft_small<7>(float2 (&v)[7]) { dft_odd<7>(v, kCos7, kSin7); }
 
 
@@ -139,6 +165,24 @@ __device__ __forceinline__ void divmod(int t, int m, float inv_m, int &q, int &r
     else if (r >= m) { r -= m; ++q; }
 }
 
+// The R - 1 twiddles W^q of one butterfly, W = tw[m]: the powers 1, 2, 4, 8 come from the table (exact), the others
+// are products of two of them or of an earlier product (at most three roundings) -- four gathers instead of fifteen,
+// and no integer multiply per gather.
+template <int R>
+__device__ __forceinline__ void twiddle_powers(float2 (&w)[R], const float2 *__restrict__ tw, int m) {
+#pragma unroll
+    for (int q = 1; q < R; ++q) {
+        if ((q & (q - 1)) == 0) w[q] = tw[m * q];
+    }
+#pragma unroll
+    for (int q = 3; q < R; ++q) {
+        if ((q & (q - 1)) != 0) {
+            const int hi = q >= 8 ? 8 : (q >= 4 ? 4 : 2);
+            w[q] = cmul(w[hi], w[q - hi]);
+        }
+    }
+}
+
 // One in-place stage on all NB interleaved lines.  L = current block length (a multiple of R).
 // DIT == false:  butterfly, then twiddle W_L^{n' k}          (decimation in frequency)
 // DIT == true :  twiddle W_L^{n' k}, then butterfly           (its transpose)
@@ -150,7 +194,7 @@ __device__ __forceinline__ void stage(float2 *s, int N, int lognb, int L, const 
     const int tw_step = N / L;
     const int nb = 1 << lognb;
     const int work = (N / R) << lognb;
-    for (int w = threadIdx.x; w < work; w += NT) {
+    for (int w = threadIdx.x; w < work; w += (int)blockDim.x) {
         const int j = w & (nb - 1);
         const int t = w >> lognb;
         int blk, np;
@@ -163,15 +207,19 @@ __device__ __forceinline__ void stage(float2 *s, int N, int lognb, int L, const 
         // M == 1 (the innermost stage): np == 0, every twiddle is 1 -- nothing to fetch or multiply
         if (DIT) {
             if (M > 1) {
+                float2 wq[R];
+                twiddle_powers<R>(wq, tw, np * tw_step);
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[np * q * tw_step]);
+                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
             }
             dft_small<R>(v);
         } else {
             dft_small<R>(v);
             if (M > 1) {
+                float2 wq[R];
+                twiddle_powers<R>(wq, tw, np * tw_step);
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[np * q * tw_step]);
+                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
             }
         }
 #pragma unroll
@@ -229,15 +277,133 @@ __device__ __forceinline__ void forward_dit(float2 *s, const DevPlan &p, int log
     }
 }
 
+// ---- the same transform with three of its LDS round trips removed ----------------------------------------------------
+// The first DIF stage takes its inputs from `io.load` (global memory) instead of LDS; the last DIF stage, the derivative
+// multiplier and the first DIT stage touch the same R points and run back to back in registers; the last DIT stage hands
+// its outputs to `io.store` instead of writing them to LDS.  Needs a direct plan with at least two stages.
+//   io.load(p, j)            -> the two real samples (line 2j, line 2j+1) at position p, as one complex value
+//   io.prefetch(p, j)        -> whatever io.store wants fetched before the butterfly (its loads overlap the arithmetic)
+//   io.store(p, j, v, pre)   -> v = conj(d line_2j/dn + i d line_2j+1/dn) at position p
+template <int R, class IO>
+__device__ __forceinline__ void first_stage(float2 *s, int N, int lognb, const float2 *__restrict__ tw, IO &io) {
+    const int M = N / R;
+    const int nb = 1 << lognb;
+    const int stride = M << lognb;
+    for (int w = threadIdx.x; w < stride; w += (int)blockDim.x) {
+        const int j = w & (nb - 1), np = w >> lognb;
+        float2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = io.load(np + q * M, j);
+        dft_small<R>(v);
+        float2 wq[R];
+        twiddle_powers<R>(wq, tw, np);
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
+        float2 *base = s + w;
+#pragma unroll
+        for (int q = 0; q < R; ++q) base[q * stride] = v[q];
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void centre_stage(float2 *s, int N, int lognb, const float *__restrict__ drev) {
+    const int nb = 1 << lognb;
+    const int work = (N / R) << lognb;
+    for (int w = threadIdx.x; w < work; w += (int)blockDim.x) {
+        const int j = w & (nb - 1), t = w >> lognb;
+        float2 *base = s + ((t * R) << lognb) + j;
+        float2 v[R];
+        float d[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { v[q] = base[q << lognb]; d[q] = drev[t * R + q]; }
+        dft_small<R>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = make_float2(-d[q] * v[q].y, -d[q] * v[q].x);      // conj(i d z)
+        dft_small<R>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) base[q << lognb] = v[q];
+    }
+}
+
+template <int R, class IO>
+__device__ __forceinline__ void last_stage(const float2 *s, int N, int lognb, const float2 *__restrict__ tw, IO &io) {
+    const int M = N / R;
+    const int nb = 1 << lognb;
+    const int stride = M << lognb;
+    for (int w = threadIdx.x; w < stride; w += (int)blockDim.x) {
+        const int j = w & (nb - 1), np = w >> lognb;
+        typename IO::Pre pre[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) pre[q] = io.prefetch(np + q * M, j);
+        float2 v[R];
+        const float2 *base = s + w;
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = base[q * stride];
+        float2 wq[R];
+        twiddle_powers<R>(wq, tw, np);
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
+        dft_small<R>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) io.store(np + q * M, j, v[q], pre[q]);
+    }
+}
+
+#define PB_FFT_RADIX_SWITCH(radix, CALL)                                                                       \
+    switch (radix) {                                                                                           \
+        case 16: CALL(16); break;                                                                              \
+        case 15: CALL(15); break;                                                                              \
+        case 12: CALL(12); break;                                                                              \
+        case 10: CALL(10); break;                                                                              \
+        case 9: CALL(9); break;                                                                                \
+        case 8: CALL(8); break;                                                                                \
+        case 6: CALL(6); break;                                                                                \
+        case 4: CALL(4); break;                                                                                \
+        case 2: CALL(2); break;                                                                                \
+        case 3: CALL(3); break;                                                                                \
+        case 5: CALL(5); break;                                                                                \
+        default: CALL(7); break;                                                                               \
+    }
+
+__device__ __forceinline__ bool fused_plan(const DevPlan &p) { return p.line_n == p.n && p.nstage >= 2; }
+
+// Must be called by all threads of the workgroup; s needs no initialisation and holds nothing of interest afterwards.
+template <class IO>
+__device__ __forceinline__ void spectral_derivative_fused(float2 *s, const DevPlan &p, int lognb, IO &io) {
+    const int last = p.nstage - 1;
+#define PB_FIRST(R) first_stage<R>(s, p.n, lognb, p.tw, io)
+    PB_FFT_RADIX_SWITCH(p.radix[0], PB_FIRST)
+#undef PB_FIRST
+    __syncthreads();
+    int L = p.n / p.radix[0];
+    for (int i = 1; i < last; ++i) {
+        stage_any<false>(s, p.n, lognb, L, p.radix[i], p.tw);
+        L /= p.radix[i];
+        __syncthreads();
+    }
+#define PB_CENTRE(R) centre_stage<R>(s, p.n, lognb, p.drev)
+    PB_FFT_RADIX_SWITCH(p.radix[last], PB_CENTRE)
+#undef PB_CENTRE
+    __syncthreads();
+    for (int i = last - 1; i >= 1; --i) {
+        L *= p.radix[i];
+        stage_any<true>(s, p.n, lognb, L, p.radix[i], p.tw);
+        __syncthreads();
+    }
+#define PB_LAST(R) last_stage<R>(s, p.n, lognb, p.tw, io)
+    PB_FFT_RADIX_SWITCH(p.radix[0], PB_LAST)
+#undef PB_LAST
+}
+
 // s holds NB interleaved complex lines of length plan.line_n in natural order (for bluestein
 // plans the buffer must have room for plan.n entries per line).  On return s[p] = conj of the
 // complex line (da/dn + i db/dn): the derivative of the real part is s.x, of the imaginary
-// part is -s.y.  Must be called by all NT threads; ends with a barrier.
+// part is -s.y.  Must be called by all threads of the workgroup; ends with a barrier.
 __device__ __forceinline__ void spectral_derivative(float2 *s, const DevPlan &p, int lognb) {
     const int nb = 1 << lognb;
     if (p.line_n == p.n) {
         forward_dif(s, p, lognb);
-        for (int e = threadIdx.x; e < (p.n << lognb); e += NT) {
+        for (int e = threadIdx.x; e < (p.n << lognb); e += (int)blockDim.x) {
             const float d = p.drev[e >> lognb];
             const float2 z = s[e];
             s[e] = make_float2(-d * z.y, -d * z.x);        // conj(i d z)
@@ -250,7 +416,7 @@ __device__ __forceinline__ void spectral_derivative(float2 *s, const DevPlan &p,
     const int N = p.line_n, M = p.n;
     for (int pass = 0; pass < 2; ++pass) {
         // a[n] = x[n] * conj(w[n]), zero padded to M
-        for (int e = threadIdx.x; e < (M << lognb); e += NT) {
+        for (int e = threadIdx.x; e < (M << lognb); e += (int)blockDim.x) {
             const int n = e >> lognb;
             float2 v = make_float2(0.f, 0.f);
             if (n < N) {
@@ -262,14 +428,14 @@ __device__ __forceinline__ void spectral_derivative(float2 *s, const DevPlan &p,
         __syncthreads();
         forward_dif(s, p, lognb);
         // multiply by the filter spectrum (already / M), conj for the inverse transform
-        for (int e = threadIdx.x; e < (M << lognb); e += NT) {
+        for (int e = threadIdx.x; e < (M << lognb); e += (int)blockDim.x) {
             const float2 v = cmul(s[e], p.bfilt_rev[e >> lognb]);
             s[e] = make_float2(v.x, -v.y);
         }
         __syncthreads();
         forward_dit(s, p, lognb);
         // c[k] = conj(s[k]);  X[k] = conj(w[k]) c[k]
-        for (int e = threadIdx.x; e < (M << lognb); e += NT) {
+        for (int e = threadIdx.x; e < (M << lognb); e += (int)blockDim.x) {
             const int k = e >> lognb;
             if (k < N) {
                 const float2 w = p.chirp[k];
