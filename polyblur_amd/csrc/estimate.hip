@@ -537,11 +537,12 @@ __global__ __launch_bounds__(NTH) void grad_rows_kernel(const float *__restrict_
 // spectral derivative along columns: one workgroup = 2*NB adjacent columns (NB complex lines)
 // MODE 0: write gy.  MODE 1: fuse the directional maxima (needs gx of the same plane).
 // ------------------------------------------------------------------------------------
-// workgroup maximum of every direction -> one partial row per column tile; blur_params_kernel folds them
-// (no contended atomics).  red: NT/64 * PB_MAX_ANGLES floats of LDS nobody else is using.
+// workgroup maximum of every direction -> one partial per column tile, stored direction-major (row k of an image holds
+// the tiles' maxima of direction k, so that blur_params_kernel folds a row with contiguous 16-byte loads; no contended
+// atomics).  red: NTH/64 * PB_MAX_ANGLES floats of LDS nobody else is using; mags_tile = &row 0 [this tile].
 template <int NTH>
-__device__ __forceinline__ void reduce_maxima(const float (&best)[PB_MAX_ANGLES], float *red, unsigned *__restrict__ mags,
-                                              int tile_id, int n_angles) {
+__device__ __forceinline__ void reduce_maxima(const float (&best)[PB_MAX_ANGLES], float *red, unsigned *__restrict__ mags_tile,
+                                              int tiles_pad, int n_angles) {
 #pragma unroll
     for (int k = 0; k < PB_MAX_ANGLES; ++k) {
         float m = best[k];
@@ -553,7 +554,7 @@ __device__ __forceinline__ void reduce_maxima(const float (&best)[PB_MAX_ANGLES]
     if ((int)threadIdx.x <= n_angles) {
         float m = red[threadIdx.x];
         for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w * PB_MAX_ANGLES + threadIdx.x]);
-        mags[(long)tile_id * PB_MAX_ANGLES + threadIdx.x] = __float_as_uint(m);   // m >= 0
+        mags_tile[(long)threadIdx.x * tiles_pad] = __float_as_uint(m);   // m >= 0
     }
 }
 
@@ -641,6 +642,8 @@ __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict_
     if (tile_id >= total_tiles) return;
     const int plane = tile_id / tiles;
     const int c0 = (tile_id - plane * tiles) * tc;
+    const int tiles_pad = (tiles + 3) & ~3;
+    unsigned *mags_tile = mags + (long)plane * PB_MAX_ANGLES * tiles_pad + (tile_id - plane * tiles);
     const float *src = planes + (long)plane * H * W;
     float lo = 0.f, scale = 1.f;
     if (normalize) {
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict_
         pbfft::spectral_derivative_fused(sfft, plan, lognb, io);
         if (MODE == 1) {
             __syncthreads();
-            reduce_maxima<NTH>(io.best, reinterpret_cast<float *>(sfft), mags, tile_id, n_angles);
+            reduce_maxima<NTH>(io.best, reinterpret_cast<float *>(sfft), mags_tile, tiles_pad, n_angles);
         }
         return;
     }
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict_
             }
         }
         __syncthreads();
-        reduce_maxima<NTH>(best, reinterpret_cast<float *>(sfft), mags, tile_id, n_angles);
+        reduce_maxima<NTH>(best, reinterpret_cast<float *>(sfft), mags_tile, tiles_pad, n_angles);
     }
 }
 
@@ -770,7 +773,8 @@ __device__ float block_sum(float v, float *red) {
 
 // Fills kernel (unless from_taps), marginals, autocorrelations, separability and radius of one
 // record.  Called by all NT threads of a block.
-__device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red, int ksize) {
+__device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red, int ksize,
+                              const float *par = nullptr) {
     // Everything is derived in LDS from the taps; the record in global memory is only written (a dependent chain of
     // global round trips made this single-workgroup kernel the longest latency of small calls).
     __shared__ float sk[PB_KSIZE * PB_KSIZE], skx[PB_KSIZE], sky[PB_KSIZE];
@@ -779,9 +783,11 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     __syncthreads();                                    // (a previous call's readers of the shared arrays are done)
     if (!from_taps) {
         // blur_estimation.py:189-232
-        const float th = -info->theta;
+        // par (LDS): theta, sigma, rho as the caller has just computed them -- no round trip through the global record
+        const float th = -(par ? par[0] : info->theta);
+        const float sg = par ? par[1] : info->sigma, rh = par ? par[2] : info->rho;
         const float c = cosf(th), s = sinf(th);
-        const float i1 = 1.f / (info->sigma * info->sigma), i2 = 1.f / (info->rho * info->rho);
+        const float i1 = 1.f / (sg * sg), i2 = 1.f / (rh * rh);
         const float a00 = c * c * i1 + s * s * i2;
         const float a01 = s * c * (i1 - i2);
         const float a11 = c * c * i2 + s * s * i1;
@@ -813,7 +819,8 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     float sx = 0.f, sy = 0.f;
     if (tid < PB_KSIZE) {
         int any = 0;
-        for (int i = 0; i < PB_KSIZE; ++i) {
+#pragma unroll
+        for (int i = 0; i < PB_KSIZE; ++i) {                 // unrolled: the LDS reads are in flight together
             const float cv = sk[i * PB_KSIZE + tid], rv = sk[tid * PB_KSIZE + i];
             sx += cv;                                   // column sum -> kx[tid]
             sy += rv;                                   // row sum    -> ky[tid]
@@ -836,9 +843,12 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     __syncthreads();
     if (tid < PB_KSIZE) {
         float ax = 0.f, ay = 0.f;
-        for (int n = 0; n + tid < PB_KSIZE; ++n) {
-            ax += skx[n] * skx[n + tid];
-            ay += sky[n] * sky[n + tid];
+#pragma unroll
+        for (int n = 0; n < PB_KSIZE; ++n) {
+            if (n + tid < PB_KSIZE) {
+                ax += skx[n] * skx[n + tid];
+                ay += sky[n] * sky[n + tid];
+            }
         }
         info->acorr_x[tid] = ax;
         info->acorr_y[tid] = ay;
@@ -854,17 +864,19 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT)
         res += fabsf(sk[idx] - sky[idx / PB_KSIZE] * skx[idx % PB_KSIZE]);
     const float resid = block_sum(res, red);
+    // FULL: every tap that is not exactly 0.0f is evaluated (rows / columns whose taps all underflowed to
+    // zero -- sigma below ~0.9 -- are skipped: bit-identical to evaluating them).  ADAPTIVE: the smallest
+    // radius outside which both marginals carry < 1e-8 of the mass.
+    const float thr = (support & 15) == PB_SUPPORT_ADAPTIVE ? 1e-8f : 0.f;
+    bool live_t = false;
+    if (tid < PB_KSIZE) live_t = thr > 0.f ? (fabsf(skx[tid]) >= thr || fabsf(sky[tid]) >= thr) : (nz[tid] != 0);
+    const unsigned long long live_mask = __ballot(live_t);          // thread 0 reads wave 0's: lanes 0..24
     if (tid == 0) {
         info->separable = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL)) ? 1 : 0;
-        // FULL: every tap that is not exactly 0.0f is evaluated (rows / columns whose taps all underflowed to
-        // zero -- sigma below ~0.9 -- are skipped: bit-identical to evaluating them).  ADAPTIVE: the smallest
-        // radius outside which both marginals carry < 1e-8 of the mass.
-        const float thr = (support & 15) == PB_SUPPORT_ADAPTIVE ? 1e-8f : 0.f;
         int rad = 0;
-        for (int t = 0; t < PB_KSIZE; ++t) {
-            const int d = t > PB_KRAD ? t - PB_KRAD : PB_KRAD - t;
-            const bool live = thr > 0.f ? (fabsf(skx[t]) >= thr || fabsf(sky[t]) >= thr) : (nz[t] != 0);
-            if (live && d > rad) rad = d;
+        if (live_mask) {
+            const int lo = __ffsll((long long)live_mask) - 1, hi = 63 - __clzll((long long)live_mask);
+            rad = max(PB_KRAD - lo, hi - PB_KRAD);
         }
         s_radius = rad <= 4 ? 4 : (rad <= 6 ? 6 : (rad <= 8 ? 8 : (rad <= 10 ? 10 : PB_KRAD)));
         info->radius = s_radius;
@@ -927,19 +939,37 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     pb_blur_info *info = infos + blockIdx.x;
     const int na = n_angles + 1;
     {
-        // fold the per-tile partial maxima of this image: thread t handles angle t % 16, tiles t/16, t/16+16, ...
+        // fold the per-tile partial maxima of this image: 16 lanes per direction, every lane's loads in flight together
         __shared__ float s_part[NT];
-        const int k = threadIdx.x & 15, lane_t = threadIdx.x >> 4;
+        const int k = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+        const int tiles_pad = (tiles_per_image + 3) & ~3, n4 = tiles_pad >> 2;
         float m = 0.f;
-        if (k < na)
-            for (int t = lane_t; t < tiles_per_image; t += NT / 16)
-                m = fmaxf(m, __uint_as_float(mags_u[((long)blockIdx.x * tiles_per_image + t) * PB_MAX_ANGLES + k]));
+        if (k < na) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(mags_u + ((long)blockIdx.x * PB_MAX_ANGLES + k) * tiles_pad);
+            for (int base = 0; base < n4; base += 16 * 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + u * 16 + l16;
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < n4) v[u] = row[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = 4 * (base + u * 16 + l16);          // entries past the last tile were never written
+                    if (e < tiles_per_image) m = fmaxf(m, __uint_as_float(v[u].x));
+                    if (e + 1 < tiles_per_image) m = fmaxf(m, __uint_as_float(v[u].y));
+                    if (e + 2 < tiles_per_image) m = fmaxf(m, __uint_as_float(v[u].z));
+                    if (e + 3 < tiles_per_image) m = fmaxf(m, __uint_as_float(v[u].w));
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         s_part[threadIdx.x] = m;
         __syncthreads();
         if (threadIdx.x < PB_MAX_ANGLES) {
-            float v = 0.f;
-            if ((int)threadIdx.x < na)
-                for (int j = 0; j < NT / 16; ++j) v = fmaxf(v, s_part[j * 16 + threadIdx.x]);
+            const float v = (int)threadIdx.x < na ? s_part[threadIdx.x * 16] : 0.f;
             s_mags[threadIdx.x] = v;
             info->mags[threadIdx.x] = v;
         }
@@ -954,31 +984,44 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
         info->interp[threadIdx.x] = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        info->gray_min = pb_ord2f(mm[2 * blockIdx.x]);
-        info->gray_max = pb_ord2f(mm[2 * blockIdx.x + 1]);
-        int i_min = 0;                                           // argmin, first minimum (:160)
+    __shared__ float s_par[3];
+    if (threadIdx.x < 64) {
+        // argmin, first minimum (:160), over the lanes of one wave: (value, index) pairs, NaN never selected
+        const int lane = threadIdx.x;
         float vmin = INFINITY;
-        for (int i = 0; i < n_interp; ++i)
-            if (s_interp[i] < vmin) { vmin = s_interp[i]; i_min = i; }
-        const float step = 180.0f / (float)n_interp;
-        int theta_deg = (int)((float)i_min * step);            // interpolated_thetas.long()
-        if (force_theta_deg >= 0.f) {
-            theta_deg = (int)force_theta_deg;
-            i_min = (int)((float)theta_deg / step);
-            vmin = s_interp[i_min];
+        if (lane < n_interp) { const float x = s_interp[lane]; if (x < INFINITY) vmin = x; }
+        int i_min = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(vmin, o);
+            const int oi = __shfl_xor(i_min, o);
+            if (ov < vmin || (ov == vmin && oi < i_min)) { vmin = ov; i_min = oi; }
         }
-        const int ortho_deg = (theta_deg + 90) % 180;
-        const int i_ortho = (int)((float)ortho_deg / step);
-        const float m_n = vmin, m_o = s_interp[i_ortho];
-        const float cc = c * c, bb = b * b;
-        info->sigma = sqrtf(fminf(fmaxf(cc / (m_n * m_n + 1e-8f) - bb, 0.09f), 16.0f));
-        info->rho = sqrtf(fminf(fmaxf(cc / (m_o * m_o + 1e-8f) - bb, 0.09f), 16.0f));
-        info->theta = (float)theta_deg * 3.14159274101257324f / 180.0f;
-        info->i_min = i_min;
+        if (lane == 0) {
+            const float step = 180.0f / (float)n_interp;
+            int theta_deg = (int)((float)i_min * step);            // interpolated_thetas.long()
+            if (force_theta_deg >= 0.f) {
+                theta_deg = (int)force_theta_deg;
+                i_min = (int)((float)theta_deg / step);
+                vmin = s_interp[i_min];
+            }
+            const int ortho_deg = (theta_deg + 90) % 180;
+            const int i_ortho = (int)((float)ortho_deg / step);
+            const float m_n = vmin, m_o = s_interp[i_ortho];
+            const float cc = c * c, bb = b * b;
+            s_par[1] = sqrtf(fminf(fmaxf(cc / (m_n * m_n + 1e-8f) - bb, 0.09f), 16.0f));
+            s_par[2] = sqrtf(fminf(fmaxf(cc / (m_o * m_o + 1e-8f) - bb, 0.09f), 16.0f));
+            s_par[0] = (float)theta_deg * 3.14159274101257324f / 180.0f;
+            info->theta = s_par[0];
+            info->sigma = s_par[1];
+            info->rho = s_par[2];
+            info->i_min = i_min;
+            info->gray_min = pb_ord2f(mm[2 * blockIdx.x]);
+            info->gray_max = pb_ord2f(mm[2 * blockIdx.x + 1]);
+        }
     }
     __syncthreads();
-    finish_record(info, support, false, red, ksize);
+    finish_record(info, support, false, red, ksize, s_par);
 }
 
 // method='direct_separable': the two correlation kernels of the x-t separable approximation of the image's Gaussian
@@ -1160,7 +1203,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     float *gray = static_cast<float *>(pb_scratch(ctx, "est.gray", sizeof(float) * B * HW));
     float *gx = static_cast<float *>(pb_scratch(ctx, "est.gx", sizeof(float) * B * HW));
     unsigned *mm = static_cast<unsigned *>(pb_scratch(ctx, "est.mm", sizeof(unsigned) * 2 * B));
-    unsigned *mags = static_cast<unsigned *>(pb_scratch(ctx, "est.mags", sizeof(unsigned) * (size_t)B * col_tiles * PB_MAX_ANGLES));
+    unsigned *mags = static_cast<unsigned *>(pb_scratch(ctx, "est.mags", sizeof(unsigned) * (size_t)B * ((col_tiles + 3) & ~3) * PB_MAX_ANGLES));
     if (!gray || !gx || !mm || !mags) return PB_ERR_NOMEM;
     const float *wts = pb_get_interp_weights(ctx, opt->n_angles, opt->n_interpolated_angles);
     if (!wts) return PB_ERR_NOMEM;
