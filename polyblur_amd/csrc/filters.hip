@@ -256,6 +256,172 @@ __global__ __launch_bounds__(NT) void dt_cols_kernel(float *__restrict__ F, cons
     }
 }
 
+// ---- the same filter without the domain planes (C == 1 or 3) -----------------------------------------------------------
+// dom is a function of two neighbouring samples of the joint image, which both passes have in hand or one cache line
+// away: recomputing it where it is used removes dt_domain_kernel, its two fp32 planes per image (written once, read
+// twice per pass) and the fp32 copy of the input -- 53 B per sample become 32 for fp32 images (44 -> 28 for fp16).
+// Same expressions in the same order as the kernels above, so the results are bit-identical to them.
+template <typename TJ, typename TIN, int C>
+__global__ __launch_bounds__(NT) void dt_rows_fused_kernel(const TJ *J, const TIN *in, float *F, int H, int W, float ratio,
+                                                           float log_a, long rows_total) {
+    const int lane = threadIdx.x & 63;
+    const long row_id = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);   // over B*H: one wave = one row, all channels
+    if (row_id >= rows_total) return;
+    const long b = row_id / H;
+    const int r = (int)(row_id - b * H);
+    const long HW = (long)H * W, off = (b * C * H + r) * (long)W;
+    const TJ *j = J + off;
+    const TIN *x0 = in + off;
+    float *f = F + off;
+    // ---- left -> right
+    float carry[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) carry[c] = 0.f;
+    for (int base = 0; base < W; base += 64) {
+        const int i = base + lane;
+        float dx = 0.f, x[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            x[c] = 0.f;
+            if (i < W) {
+                x[c] = pb_ld(x0 + c * HW + i);
+                if (i > 0) dx += fabsf(pb_ld(j + c * HW + i) - pb_ld(j + c * HW + i - 1));
+            }
+        }
+        float v = 1.f;
+        if (i < W) v = expf((1.f + ratio * dx) * log_a);
+        float ma = (i == 0 || i >= W) ? 0.f : v, mb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) mb[c] = (i == 0 || i >= W) ? x[c] : (1.f - v) * x[c];
+        if (i >= W) {
+            ma = 1.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) mb[c] = 0.f;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float pa = __shfl_up(ma, o);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float pb = __shfl_up(mb[c], o);
+                if (lane >= o) mb[c] = fmaf(ma, pb, mb[c]);
+            }
+            if (lane >= o) ma = ma * pa;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float y = fmaf(ma, carry[c], mb[c]);
+            if (i < W) f[c * HW + i] = y;
+            carry[c] = __shfl(y, 63);
+            if (base + 63 >= W) carry[c] = __shfl(y, (W - 1) - base);
+        }
+    }
+    __threadfence_block();                               // the right-to-left pass reads what other lanes have just written
+    // ---- right -> left
+    const int last_base = ((W - 1) / 64) * 64;
+#pragma unroll
+    for (int c = 0; c < C; ++c) carry[c] = 0.f;
+    for (int base = last_base; base >= 0; base -= 64) {
+        const int i = base + (63 - lane);                // lane 0 handles the right-most element of the chunk
+        float dx = 0.f, x[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            x[c] = 0.f;
+            if (i < W) x[c] = f[c * HW + i];
+            if (i + 1 < W) dx += fabsf(pb_ld(j + c * HW + i + 1) - pb_ld(j + c * HW + i));
+        }
+        float v = 1.f;
+        if (i + 1 < W) v = expf((1.f + ratio * dx) * log_a);
+        float ma = (i >= W - 1) ? 0.f : v, mb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) mb[c] = (i >= W - 1) ? x[c] : (1.f - v) * x[c];
+        if (i >= W) {
+            ma = 1.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) mb[c] = 0.f;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float pa = __shfl_up(ma, o);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float pb = __shfl_up(mb[c], o);
+                if (lane >= o) mb[c] = fmaf(ma, pb, mb[c]);
+            }
+            if (lane >= o) ma = ma * pa;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float y = fmaf(ma, carry[c], mb[c]);
+            if (i < W) f[c * HW + i] = y;
+            carry[c] = __shfl(y, 63);                    // element `base`, the left-most of this chunk
+        }
+    }
+}
+
+constexpr int DT_UF = 8;
+template <typename TJ, int C>
+__global__ __launch_bounds__(NT) void dt_cols_fused_kernel(const TJ *__restrict__ J, float *__restrict__ F, int H, int W,
+                                                           float ratio, float log_a, long cols_total) {
+    const long id = (long)blockIdx.x * NT + threadIdx.x;   // over B*W: one thread = one column, all channels
+    if (id >= cols_total) return;
+    const long b = id / W;
+    const int col = (int)(id - b * W);
+    const long HW = (long)H * W;
+    float *f = F + b * C * HW + col;
+    const TJ *j = J + b * C * HW + col;
+    float prev[C], pj[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { prev[c] = f[c * HW]; pj[c] = pb_ld(j + c * HW); }
+    for (int r0 = 1; r0 < H; r0 += DT_UF) {
+        float xs[DT_UF][C], js[DT_UF][C];
+#pragma unroll
+        for (int u = 0; u < DT_UF; ++u) {
+            const int r = min(r0 + u, H - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { xs[u][c] = f[c * HW + (long)r * W]; js[u][c] = pb_ld(j + c * HW + (long)r * W); }
+        }
+#pragma unroll
+        for (int u = 0; u < DT_UF; ++u) {
+            if (r0 + u < H) {
+                float dy = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { dy += fabsf(js[u][c] - pj[c]); pj[c] = js[u][c]; }
+                const float v = expf((1.f + ratio * dy) * log_a);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    prev[c] = xs[u][c] + v * (prev[c] - xs[u][c]);
+                    f[c * HW + (long)(r0 + u) * W] = prev[c];
+                }
+            }
+        }
+    }
+    // pj = J[H-1], prev = F[H-1]
+    for (int r0 = H - 2; r0 >= 0; r0 -= DT_UF) {
+        float xs[DT_UF][C], js[DT_UF][C];
+#pragma unroll
+        for (int u = 0; u < DT_UF; ++u) {
+            const int r = max(r0 - u, 0);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { xs[u][c] = f[c * HW + (long)r * W]; js[u][c] = pb_ld(j + c * HW + (long)r * W); }
+        }
+#pragma unroll
+        for (int u = 0; u < DT_UF; ++u) {
+            if (r0 - u >= 0) {
+                float dy = 0.f;                                      // dom of row r+1: |J[r+1] - J[r]|
+#pragma unroll
+                for (int c = 0; c < C; ++c) { dy += fabsf(pj[c] - js[u][c]); pj[c] = js[u][c]; }
+                const float v = expf((1.f + ratio * dy) * log_a);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    prev[c] = xs[u][c] + v * (prev[c] - xs[u][c]);
+                    f[c * HW + (long)(r0 - u) * W] = prev[c];
+                }
+            }
+        }
+    }
+}
+
 template <typename T> __global__ void to_float_kernel(const T *__restrict__ in, float *__restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = pb_ld(in + i);
 }
@@ -335,16 +501,46 @@ int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int
     return PB_OK;
 }
 
+template <typename T, int C>
+static int dt_filter_fused(pb_ctx *ctx, const T *in, const T *J, float *out, int B, int H, int W, float ratio, int N, float sigma_s) {
+    const long rows_total = (long)B * H, cols_total = (long)B * W;
+    for (int i = 0; i < N; ++i) {
+        // domain_transform.py:50,53
+        const double sigma_i = (double)sigma_s * std::sqrt(3.0) * std::pow(2.0, N - (i + 1)) / std::sqrt(std::pow(4.0, N) - 1.0);
+        const float a = (float)std::exp(-std::sqrt(2.0) / sigma_i);
+        const float log_a = std::log(a);
+        const dim3 rgrid((unsigned)((rows_total + 3) / 4)), cgrid((unsigned)((cols_total + NT - 1) / NT));
+        if (i == 0)
+            hipLaunchKernelGGL((dt_rows_fused_kernel<T, T, C>), rgrid, dim3(NT), 0, ctx->stream, J, in, out, H, W, ratio, log_a, rows_total);
+        else
+            hipLaunchKernelGGL((dt_rows_fused_kernel<T, float, C>), rgrid, dim3(NT), 0, ctx->stream, J, out, out, H, W, ratio, log_a, rows_total);
+        hipLaunchKernelGGL((dt_cols_fused_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, H, W, ratio, log_a, cols_total);
+        PB_LAUNCH_CHECK();
+    }
+    return PB_OK;
+}
+
 // out (float32, B*C*H*W) = recursive_filter(in, joint)
 int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype, float *out, int B, int C, int H, int W,
                       float sigma_s, float sigma_r, int num_iterations) {
     const long HW = (long)H * W, n = (long)B * C * HW;
     ProfScope prof(ctx, PB_PROF_PREFILTER);
+    const void *J = joint ? joint : in;
+    const float ratio = sigma_s / sigma_r;
+    const int N = num_iterations;
+    if (C == 1 || C == 3) {                       // gray and colour images: no domain planes (see dt_rows_fused_kernel)
+        if (dtype == PB_F32) {
+            const float *i32 = static_cast<const float *>(in), *j32 = static_cast<const float *>(J);
+            return C == 3 ? dt_filter_fused<float, 3>(ctx, i32, j32, out, B, H, W, ratio, N, sigma_s)
+                          : dt_filter_fused<float, 1>(ctx, i32, j32, out, B, H, W, ratio, N, sigma_s);
+        }
+        const __half *i16 = static_cast<const __half *>(in), *j16 = static_cast<const __half *>(J);
+        return C == 3 ? dt_filter_fused<__half, 3>(ctx, i16, j16, out, B, H, W, ratio, N, sigma_s)
+                      : dt_filter_fused<__half, 1>(ctx, i16, j16, out, B, H, W, ratio, N, sigma_s);
+    }
     float *domx = static_cast<float *>(pb_scratch(ctx, "dt.domx", sizeof(float) * B * HW));
     float *domy = static_cast<float *>(pb_scratch(ctx, "dt.domy", sizeof(float) * B * HW));
     if (!domx || !domy) return PB_ERR_NOMEM;
-    const void *J = joint ? joint : in;
-    const float ratio = sigma_s / sigma_r;
     dim3 dgrid(grid_for(HW, NT, 2048), B);
     if (dtype == PB_F32) {
         hipLaunchKernelGGL(dt_domain_kernel<float>, dgrid, dim3(NT), 0, ctx->stream, static_cast<const float *>(J), domx, domy, C, H, W, ratio);
@@ -354,7 +550,6 @@ int pb_dt_filter_impl(pb_ctx *ctx, const void *in, const void *joint, int dtype,
         hipLaunchKernelGGL(to_float_kernel<__half>, dim3(grid_for(n)), dim3(NT), 0, ctx->stream, static_cast<const __half *>(in), out, n);
     }
     PB_LAUNCH_CHECK();
-    const int N = num_iterations;
     const long rows_total = (long)B * C * H, cols_total = (long)B * C * W;
     for (int i = 0; i < N; ++i) {
         // domain_transform.py:50,53
