@@ -10,7 +10,7 @@
 int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int P, long HW);
 int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
                   const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
-                  int clamp01);
+                  int clamp01, const void *recomb_cur = nullptr, int recomb_cur_dtype = 0, const float *recomb_smooth = nullptr);
 int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, int cur_dtype, const float *smooth, void *out, int out_dtype,
                  long n);
 int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int out_dtype, int P, int H, int W);
@@ -322,7 +322,9 @@ struct InverseScratch {
 // src: what gets deconvolved (cur, or the smooth component).  dst: (B,C,H,W) of dst_dtype.
 int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype, void *dst, int dst_dtype,
                    const pb_blur_info *info, float alpha, float beta, int boundary, int edgetaping, int remove_halo,
-                   const float *g0x, const float *g0y, const float *nM, int final_clamp) {
+                   const float *g0x, const float *g0y, const float *nM, int final_clamp,
+                   const void *recomb_cur = nullptr, int recomb_cur_dtype = 0, const float *recomb_smooth = nullptr) {
+    // recomb_cur (only with remove_halo): the halo kernel also adds back the detail layer cur - recomb_smooth
     float *t1 = nullptr, *t2 = nullptr;
     if (!g.t1h) {
         t1 = static_cast<float *>(pb_scratch(ctx, "inv.t1", sizeof(float) * g.P * g.pplane));
@@ -350,8 +352,9 @@ int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtyp
     if (rc) return rc;
     if (xpadded)
         return pb_halo_apply(ctx, xpadded + (long)g.pad * g.pp + g.pad, PB_F32, g.pp, g.pplane, y, g0x, g0y, ox, nM, dst,
-                             dst_dtype, g.P, g.H, g.W, final_clamp);
-    return pb_halo_apply(ctx, src, src_dtype, g.W, g.HW, y, g0x, g0y, ox, nM, dst, dst_dtype, g.P, g.H, g.W, final_clamp);
+                             dst_dtype, g.P, g.H, g.W, final_clamp, recomb_cur, recomb_cur_dtype, recomb_smooth);
+    return pb_halo_apply(ctx, src, src_dtype, g.W, g.HW, y, g0x, g0y, ox, nM, dst, dst_dtype, g.P, g.H, g.W, final_clamp,
+                         recomb_cur, recomb_cur_dtype, recomb_smooth);
 }
 
 int check_shape(pb_ctx *ctx, int dtype, int B, int C, int H, int W, int allow_u8 = 0) {
@@ -636,11 +639,17 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
             else
                 rc = pb_dt_filter_impl(ctx, cur, nullptr, cur_dtype, smooth, B, C, H, W, opt->sigma_s, opt->sigma_r, 1);
             if (rc) return rc;
-            rc = inverse_filter(ctx, g, smooth, PB_F32, ybuf, PB_F32, info, opt->alpha, opt->beta, opt->boundary,
-                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1);
-            if (rc) return rc;
-            rc = pb_recombine(ctx, ybuf, cur, cur_dtype, smooth, dst, dst_dtype, n);
-            if (rc) return rc;
+            if (opt->remove_halo) {                 // the halo kernel recombines as it stores: no ybuf round trip
+                rc = inverse_filter(ctx, g, smooth, PB_F32, dst, dst_dtype, info, opt->alpha, opt->beta, opt->boundary,
+                                    opt->edgetaping, 1, g0x, g0y, nM, 1, cur, cur_dtype, smooth);
+                if (rc) return rc;
+            } else {
+                rc = inverse_filter(ctx, g, smooth, PB_F32, ybuf, PB_F32, info, opt->alpha, opt->beta, opt->boundary,
+                                    opt->edgetaping, 0, g0x, g0y, nM, 1);
+                if (rc) return rc;
+                rc = pb_recombine(ctx, ybuf, cur, cur_dtype, smooth, dst, dst_dtype, n);
+                if (rc) return rc;
+            }
         }
         cur = dst;
     }

@@ -46,12 +46,15 @@ __global__ __launch_bounds__(64) void grad_energy_fold_kernel(const float *__res
 
 // M = -gx*ox - gy*gy  (sic: deblurring.py:174 multiplies grad_y by itself, not by gout_y)
 // z = max(M / (nM + M), 0);  out = y + z (x - y)   [+ clamp to [0,1], deblurring.py:239]
+// With a prefilter the masked result is recombined on the spot (cur != nullptr; recombine_kernel's arithmetic):
+// out = clip(clip(out, 0, 1) + (cur - smooth), 0, 1) -- one pass over the batch instead of a store, a load and a pass.
 template <typename TX, typename TOut>
 __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int x_pitch, long x_plane,
                                                   const float *__restrict__ y, const float *__restrict__ gx,
                                                   const float *__restrict__ gy, const float *__restrict__ ox,
                                                   const float *__restrict__ nM, TOut *__restrict__ out, int P, int H, int W,
-                                                  int clamp01) {
+                                                  int clamp01, const void *__restrict__ cur, int cur_is_half,
+                                                  const float *smooth) {
     const long HW = (long)H * W;
     for (int plane = blockIdx.y; plane < P; plane += gridDim.y) {      // (grid.y is capped at 65535)
     const float nm = nM[plane];
@@ -65,6 +68,12 @@ __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int 
         const float yv = y[k];
         float v = yv + z * (xv - yv);
         if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        if (cur) {
+            const float cv = cur_is_half ? pb_ld(static_cast<const __half *>(cur) + k) : static_cast<const float *>(cur)[k];
+            const float d = cv - smooth[k];
+            v = fminf(fmaxf(v, 0.f), 1.f) + d;
+            v = fminf(fmaxf(v, 0.f), 1.f);
+        }
         pb_st(out + k, v);
     }
     }
@@ -454,12 +463,16 @@ int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int
 
 int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
                   const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
-                  int clamp01) {
+                  int clamp01, const void *recomb_cur, int recomb_cur_dtype, const float *recomb_smooth) {
     dim3 grid(grid_for((long)H * W, NT, 2048), P < 65535 ? P : 65535);
     ProfScope prof(ctx, PB_PROF_HALO);
+    if (recomb_cur && recomb_cur_dtype != PB_F32 && recomb_cur_dtype != PB_F16)
+        return pb_fail(ctx, PB_ERR_BADARG, "halo: the recombined image must be fp32 or fp16");
+    const int cur_is_half = recomb_cur_dtype == PB_F16;
 #define PB_HALO(TX, TO)                                                                                           \
     hipLaunchKernelGGL((halo_kernel<TX, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
-                       x_plane, y, gx, gy, ox, nM, static_cast<TO *>(out), P, H, W, clamp01)
+                       x_plane, y, gx, gy, ox, nM, static_cast<TO *>(out), P, H, W, clamp01, recomb_cur, cur_is_half, \
+                       recomb_smooth)
     if (x_dtype == PB_F32 && out_dtype == PB_F32) PB_HALO(float, float);
     else if (x_dtype == PB_F32 && out_dtype == PB_F16) PB_HALO(float, __half);
     else if (x_dtype == PB_F16 && out_dtype == PB_F32) PB_HALO(__half, float);
