@@ -233,6 +233,20 @@ def test_dt_filter_joint_and_wide(eng):
     assert maxabs(eng.dt_recursive_filter(x, 8.0, 0.5, 2, joint=j), ref.recursive_filter(x, 8.0, 0.5, 2, j)) < 5e-6
 
 
+@pytest.mark.parametrize("shape,n", [((1, 1, 33, 70), 1), ((2, 1, 65, 129), 3), ((1, 2, 40, 130), 2), ((1, 4, 21, 64), 1),
+                                     ((3, 3, 2, 90), 1), ((1, 3, 90, 2), 2)])
+def test_dt_filter_channel_counts(eng, shape, n):
+    """1 and 3 channels take the kernels that recompute the domain weights in place, any other count the ones that
+    read them from domain planes; two-row / two-column images; fp16 input"""
+    rng = np.random.default_rng(17)
+    x = rng.random(shape, dtype=np.float32)
+    assert maxabs(eng.dt_recursive_filter(x, 6.0, 0.4, n), ref.recursive_filter(x, 6.0, 0.4, n)) < 5e-6
+    xh = x.astype(np.float16)
+    got = eng.dt_recursive_filter(xh, 6.0, 0.4, n)
+    assert got.dtype == np.float16
+    assert maxabs(got, ref.recursive_filter(xh.astype(np.float32), 6.0, 0.4, n)) < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------
 # rank-1 (separable) kernels and support policy
 # ---------------------------------------------------------------------------------------------
