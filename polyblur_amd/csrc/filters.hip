@@ -269,7 +269,28 @@ __global__ __launch_bounds__(NT) void dt_cols_kernel(float *__restrict__ F, cons
 // dom is a function of two neighbouring samples of the joint image, which both passes have in hand or one cache line
 // away: recomputing it where it is used removes dt_domain_kernel, its two fp32 planes per image (written once, read
 // twice per pass) and the fp32 copy of the input -- 53 B per sample become 32 for fp32 images (44 -> 28 for fp16).
-// Same expressions in the same order as the kernels above, so the results are bit-identical to them.
+// Same expressions as the kernels above (the wave scan associates its products differently: last-bit differences).
+// Wave-level inclusive scan of affine maps (shared slope ma, one intercept per channel) with DPP moves instead of LDS
+// permutes: four row_shr steps inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into
+// rows 2 and 3.  Lanes without a source take the identity map (1, 0), under which compose() returns its argument exactly.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_take(float identity, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK, int C> __device__ __forceinline__ void scan_step(float &ma, float (&mb)[C]) {
+    const float pa = dpp_take<CTRL, ROW_MASK>(1.f, ma);
+#pragma unroll
+    for (int c = 0; c < C; ++c) mb[c] = fmaf(ma, dpp_take<CTRL, ROW_MASK>(0.f, mb[c]), mb[c]);
+    ma = ma * pa;
+}
+template <int C> __device__ __forceinline__ void scan_affine(float &ma, float (&mb)[C]) {
+    scan_step<0x111, 0xf>(ma, mb);      // row_shr:1
+    scan_step<0x112, 0xf>(ma, mb);      // row_shr:2
+    scan_step<0x114, 0xf>(ma, mb);      // row_shr:4
+    scan_step<0x118, 0xf>(ma, mb);      // row_shr:8
+    scan_step<0x142, 0xa>(ma, mb);      // row_bcast:15 -> rows 1, 3
+    scan_step<0x143, 0xc>(ma, mb);      // row_bcast:31 -> rows 2, 3
+}
+
 template <typename TJ, typename TIN, int C>
 __global__ __launch_bounds__(NT) void dt_rows_fused_kernel(const TJ *J, const TIN *in, float *F, int H, int W, float ratio,
                                                            float log_a, long rows_total) {
@@ -307,22 +328,12 @@ __global__ __launch_bounds__(NT) void dt_rows_fused_kernel(const TJ *J, const TI
 #pragma unroll
             for (int c = 0; c < C; ++c) mb[c] = 0.f;
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float pa = __shfl_up(ma, o);
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float pb = __shfl_up(mb[c], o);
-                if (lane >= o) mb[c] = fmaf(ma, pb, mb[c]);
-            }
-            if (lane >= o) ma = ma * pa;
-        }
+        scan_affine<C>(ma, mb);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float y = fmaf(ma, carry[c], mb[c]);
             if (i < W) f[c * HW + i] = y;
-            carry[c] = __shfl(y, 63);
-            if (base + 63 >= W) carry[c] = __shfl(y, (W - 1) - base);
+            carry[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), base + 63 >= W ? (W - 1) - base : 63));
         }
     }
     __threadfence_block();                               // the right-to-left pass reads what other lanes have just written
@@ -349,21 +360,12 @@ __global__ __launch_bounds__(NT) void dt_rows_fused_kernel(const TJ *J, const TI
 #pragma unroll
             for (int c = 0; c < C; ++c) mb[c] = 0.f;
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float pa = __shfl_up(ma, o);
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float pb = __shfl_up(mb[c], o);
-                if (lane >= o) mb[c] = fmaf(ma, pb, mb[c]);
-            }
-            if (lane >= o) ma = ma * pa;
-        }
+        scan_affine<C>(ma, mb);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float y = fmaf(ma, carry[c], mb[c]);
             if (i < W) f[c * HW + i] = y;
-            carry[c] = __shfl(y, 63);                    // element `base`, the left-most of this chunk
+            carry[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63));  // element `base`, the left-most of this chunk
         }
     }
 }
