@@ -232,12 +232,15 @@ def main():
         xr = torch.cat([x] * world) if rank == 0 else None
         fr_shape = (B * world, 3, H, W)
         fr = lambda: deblur_from_root(xr, fr_shape, tdt, device=dev, **kw)
-        fr()
-        n_fr = max(2, min(args.steps, 5))
-        dt_fr, _ = timed(n_fr, fr)
-        ms_fr = 1e3 * dt_fr / n_fr
-        side["from_root_scatter_compute_gather"] = dict(ms_per_step=round(ms_fr, 4), mp_per_s=round(mp_per_step / (ms_fr * 1e-3), 1),
-                                                        note="whole batch on rank 0 before and after; grouped RCCL send/recv per image")
+        try:                                     # a side measurement: its failure must not take the headline with it
+            fr()
+            n_fr = max(2, min(args.steps, 5))
+            dt_fr, _ = timed(n_fr, fr)
+            ms_fr = 1e3 * dt_fr / n_fr
+            side["from_root_scatter_compute_gather"] = dict(ms_per_step=round(ms_fr, 4), mp_per_s=round(mp_per_step / (ms_fr * 1e-3), 1),
+                                                            note="whole batch on rank 0 before and after; grouped RCCL send/recv per image")
+        except Exception as e:                   # noqa: BLE001 -- reported in the line, not raised
+            side["from_root_scatter_compute_gather"] = dict(error="%s: %s" % (type(e).__name__, str(e)[:200]))
         del xr
 
     if rank != 0:
