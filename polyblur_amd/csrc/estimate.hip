@@ -451,8 +451,9 @@ struct RowsIO {
     }
 };
 
-// NTH == 128: the fused transform (direct plans of two or more stages); NTH == 256: the general one (Bluestein, one stage)
-template <int NTH>
+// FUSED: the fused transform (direct plans of two or more stages), with 128 threads for lines of up to 4096 samples;
+// otherwise the general one (Bluestein, one stage)
+template <int NTH, bool FUSED>
 __global__ __launch_bounds__(NTH) void grad_rows_kernel(const float *__restrict__ planes, float *__restrict__ gx,
                                                        int H, int W, int normalize, const unsigned *__restrict__ mm,
                                                        int planes_per_image, pbfft::DevPlan plan) {
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(NTH) void grad_rows_kernel(const float *__restrict_
         scale = pb_ord2f(mm[2 * img + 1]) - lo;
     }
     const float inv = 1.f / scale;
-    if constexpr (NTH == 128) {
+    if constexpr (FUSED) {
         RowsIO io{row0, row1, gx + ((long)plane * H + r0) * W, W, has1, normalize != 0, lo, scale, inv};
         pbfft::spectral_derivative_fused(sfft, plan, 0, io);
         return;
@@ -1119,8 +1120,10 @@ int pick_lognb(const FftPlan *pl, int W) {
     return lognb;
 }
 
-// Rows: a workgroup's transform is a chain of dependent stages and 30 KB of LDS per two 3840-sample rows fit five
-// workgroups per CU, which the registers of 256-thread workgroups did not (three): the fused transform runs with 128.
+// Rows: a workgroup's transform is a chain of dependent stages, so the kernel is as fast as the number of chains in
+// flight.  Lines of up to 4096 samples (32 KB of LDS per two rows) fit five workgroups per CU, which the registers of
+// 256-thread workgroups do not allow (three): those run with 128 threads.  Longer lines are limited by LDS to two or
+// three workgroups per CU and keep 256 threads (measured at 7680: 241 us per 8K image against 339 us with 128).
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
                 const unsigned *mm, int planes_per_image) {
     const FftPlan *pl = pb_get_plan(ctx, W);
@@ -1131,14 +1134,16 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     const pbfft::DevPlan dp = dev_plan(pl);
     const bool fused = !pl->bluestein_m && pl->nstage >= 2;          // as pbfft::fused_plan
     ProfScope prof(ctx, PB_PROF_GRAD_ROWS);
-#define PB_ROWS(NTH)                                                                                             \
+#define PB_ROWS(NTH, FUSED)                                                                                      \
     do {                                                                                                         \
-        int rc = allow_lds(ctx, grad_rows_kernel<NTH>, lds);                                                     \
+        int rc = allow_lds(ctx, grad_rows_kernel<NTH, FUSED>, lds);                                              \
         if (rc) return rc;                                                                                       \
-        hipLaunchKernelGGL((grad_rows_kernel<NTH>), dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream,         \
+        hipLaunchKernelGGL((grad_rows_kernel<NTH, FUSED>), dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream,  \
                            planes, gx, H, W, normalize ? 1 : 0, mm, planes_per_image, dp);                       \
     } while (0)
-    if (fused) PB_ROWS(128); else PB_ROWS(256);
+    if (!fused) PB_ROWS(256, false);
+    else if (lds <= 32 * 1024) PB_ROWS(128, true);
+    else PB_ROWS(256, true);
 #undef PB_ROWS
     PB_LAUNCH_CHECK();
     return PB_OK;
