@@ -219,11 +219,12 @@ def test_pipeline_with_normalized_convolution_prefilter():
     got = polyblur_deblurring(torch.from_numpy(x), prefilter="normalized_convolution", **kw).numpy()
     want = ref.polyblur_deblurring(x, prefilter="normalized_convolution", **kw)
     # the NC filter is discontinuous in its input (box limits are comparisons): from the second iteration on,
-    # rounding-level differences of the first move a limit by one sample here and there
-    assert np.mean(np.abs(got - want) > 2e-5) < 2e-2 and maxabs(got, want) < 5e-2
+    # rounding-level differences of the first move a limit by one sample here and there -- measured: 26 of 80 640
+    # samples beyond 2e-5, the largest 9.1e-5
+    assert np.mean(np.abs(got - want) > 2e-5) < 1e-3 and maxabs(got, want) < 5e-4
     one = polyblur_deblurring(torch.from_numpy(x), prefilter="normalized_convolution", **dict(kw, n_iter=1)).numpy()
     want1 = ref.polyblur_deblurring(x, prefilter="normalized_convolution", **dict(kw, n_iter=1))
-    assert np.mean(np.abs(one - want1) > 2e-5) < 1e-4
+    assert maxabs(one, want1) < 2e-5            # one iteration: no amplified limit decisions yet (measured 2.4e-6)
 
 
 def test_dt_filter_joint_and_wide(eng):
@@ -586,12 +587,13 @@ def test_many_small_images_and_many_iterations():
     assert np.array_equal(out[:4], out[296:])
     # each iteration is polyblur applied to the previous result: 6 at once == 4 followed by 2, bit for bit
     xs = torch.from_numpy(x[:1]).cuda()
-    six = polyblur_deblurring(xs, n_iter=6, **KW)
+    six, infos = polyblur_deblurring(xs, n_iter=6, return_info=True, **KW)
     assert torch.equal(six, polyblur_deblurring(polyblur_deblurring(xs, n_iter=4, **KW), n_iter=2, **KW))
-    want6 = ref.polyblur_deblurring(x[:1], n_iter=6, **KW)
-    got6 = six.cpu().numpy()
-    # after six sharpening passes rounding differences have been amplified; the bulk still agrees closely
-    assert np.mean(np.abs(got6 - want6) > 1e-4) < 1e-2
+    want6, winfos = ref.polyblur_deblurring(x[:1], n_iter=6, return_info=True, **KW)
+    # six sharpening passes (17 % of the samples end up clipped): the same six directions, and the fp32 tolerance
+    # still holds (measured 4.4e-6; 5e-7 after one pass)
+    assert [float(i["theta"][0]) for i in infos] == [float(i["theta"][0]) for i in winfos]
+    assert maxabs(six.cpu().numpy(), want6) < 2e-5
 
 
 def test_mixed_batch_rank1_and_general(eng):
