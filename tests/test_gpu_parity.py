@@ -38,9 +38,10 @@ def test_fourier_gradients(eng, golden, name):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 64, 64), (1, 2, 50, 70), (2, 1, 121, 77), (1, 1, 97, 101), (1, 1, 360, 480),
-                                   (1, 1, 2, 3), (1, 1, 1080, 1920)])
+                                   (1, 1, 2, 3), (1, 1, 1080, 1920), (1, 1, 45, 75), (2, 1, 135, 63), (1, 1, 16, 15)])
 def test_fourier_gradients_sizes(eng, shape):
-    """mixed radix (2,3,4,5,7), Bluestein (prime factors > 7, e.g. 97, 101, 121=11^2) and tiny sizes"""
+    """mixed radix (2,3,4,5,7), Bluestein (prime factors > 7, e.g. 97, 101, 121=11^2), tiny sizes, one-stage plans
+    (16, 15), and odd lengths on the multi-stage (fused) plans: an unpaired last row / last column"""
     rng = np.random.default_rng(7)
     x = rng.random(shape, dtype=np.float32)
     gx, gy = eng.fourier_gradients(x)
@@ -526,7 +527,8 @@ def test_8k_fp16_properties(eng):
 # ---------------------------------------------------------------------------------------------
 # edge cases: ragged / tiny sizes, mixed batches, degenerate inputs
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1, 3, 8, 8), (1, 1, 16, 20), (2, 3, 33, 130), (1, 3, 65, 63), (1, 2, 40, 44)])
+@pytest.mark.parametrize("shape", [(1, 3, 8, 8), (1, 1, 16, 20), (2, 3, 33, 130), (1, 3, 65, 63), (1, 2, 40, 44),
+                                   (1, 3, 45, 75)])
 @pytest.mark.parametrize("method", ["fft", "direct"])
 def test_small_and_ragged_sizes(shape, method):
     """images smaller than the 25x25 support (the wrap boundary wraps more than once), widths that are
