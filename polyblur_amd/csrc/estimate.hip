@@ -657,7 +657,9 @@ __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict_
     const bool vec2 = (W & 1) == 0 && c0 + tc <= W;          // every pair is an aligned, in-range float2
     if (pbfft::fused_plan(plan)) {
         ColsIO<MODE, NA> io;
-        io.src = src; io.gxp = gx + (long)plane * H * W; io.dst = gy + (long)plane * H * W;
+        io.src = src;
+        io.gxp = MODE == 1 ? gx + (long)plane * H * W : nullptr;
+        io.dst = MODE == 0 ? gy + (long)plane * H * W : nullptr;
         io.W = W; io.c0 = c0; io.na = n_angles + 1; io.vec2 = vec2; io.discard_sat = discard_sat != 0; io.normalize = normalize != 0;
         io.lo = lo; io.scale = scale; io.inv = inv; io.sat_threshold = sat_threshold; io.ang = ang;
 #pragma unroll
