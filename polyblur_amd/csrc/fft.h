@@ -27,20 +27,58 @@
 namespace pbfft {
 
 
+// (float2 helpers: the Bluestein path and the callers' I/O)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// multiply by -i (forward quarter turn)
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
 
-static __device__ const float kCos3[3] = {1.f, -0.5f, -0.5f};
-static __device__ const float kSin3[3] = {0.f, 0.86602540378443864676f, -0.86602540378443864676f};
-static __device__ const float kCos5[5] = {1.f, 0.30901699437494742410f, -0.80901699437494742410f,
-                                          -0.80901699437494742410f, 0.30901699437494742410f};
-static __device__ const float kSin5[5] = {0.f, 0.95105651629515357212f, 0.58778525229247312917f,
-                                          -0.58778525229247312917f, -0.95105651629515357212f};
+// ---- butterfly arithmetic on complex values held as one aligned register pair ------------------------------------------
+// A complex add is one v_pk_add_f32, a complex product two packed instructions (op_sel picks the halves, neg_lo / neg_hi
+// the signs), a multiplication by -i is folded into the add that consumes it.  Written out because the compiler, given
+// the same formulas on scalars, packs them after the fact and pays one register move for every two packed operations
+// (343 vector instructions per radix-16 butterfly with its 15 twiddles; ~190 this way).
+typedef float cf __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf to_cf(float2 v) { return (cf){v.x, v.y}; }
+__device__ __forceinline__ float2 to_f2(cf v) { return make_float2(v.x, v.y); }
+
+// a * w
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                      // (a.x w.x, a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;                                                                                                    // (.. - a.y w.y, .. + a.y w.x)
+}
+// a * w for a compile-time constant w (kept in a scalar register pair)
+__device__ __forceinline__ cf cmulc(cf a, cf w) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+// a + (-i) b  and  a - (-i) b          ((-i) b = (b.y, -b.x))
+__device__ __forceinline__ cf cadd_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf csub_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// m + k (-i) d  and  m - k (-i) d  for a real constant k (both halves of kk hold it)
+__device__ __forceinline__ cf cfma_mi(cf m, cf kk, cf d) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(d), "s"(kk), "v"(m));
+    return r;
+}
+__device__ __forceinline__ cf cfms_mi(cf m, cf kk, cf d) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(d), "s"(kk), "v"(m));
+    return r;
+}
+
 static __device__ const float kCos7[7] = {1.f, 0.62348980185873353053f, -0.22252093395631440429f,
                                           -0.90096886790241912624f, -0.90096886790241912624f,
                                           -0.22252093395631440429f, 0.62348980185873353053f};
@@ -49,65 +87,63 @@ static __device__ const float kSin7[7] = {0.f, 0.78183148246802980871f, 0.974927
                                           -0.97492791218182360702f, -0.78183148246802980871f};
 
 // forward DFT of R points held in registers: v[k] <- sum_q v[q] exp(-2 pi i q k / R)
-template <int R> __device__ __forceinline__ void dft_small(float2 (&v)[R]);
+template <int R> __device__ __forceinline__ void dft_small(cf (&v)[R]);
 
-template <> __device__ __forceinline__ void dft_small<2>(float2 (&v)[2]) {
-    const float2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
+template <> __device__ __forceinline__ void dft_small<2>(cf (&v)[2]) {
+    const cf a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
 }
-template <> __device__ __forceinline__ void dft_small<4>(float2 (&v)[4]) {
-    const float2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
-    const float2 s13 = cadd(v[1], v[3]), d13 = mul_mi(csub(v[1], v[3]));
-    v[0] = cadd(s02, s13);
-    v[1] = cadd(d02, d13);
-    v[2] = csub(s02, s13);
-    v[3] = csub(d02, d13);
+template <> __device__ __forceinline__ void dft_small<4>(cf (&v)[4]) {
+    const cf s02 = v[0] + v[2], d02 = v[0] - v[2];
+    const cf s13 = v[1] + v[3], d13 = v[1] - v[3];
+    v[0] = s02 + s13;
+    v[1] = cadd_mi(d02, d13);
+    v[2] = s02 - s13;
+    v[3] = csub_mi(d02, d13);
 }
-template <int R> __device__ __forceinline__ void dft_odd(float2 (&v)[R], const float *cs, const float *sn) {
-    float2 o[R];
+// 3 and 5 points in the Rader/Winograd form (sums and differences of the mirrored pairs first): 6 and 19 packed
+// operations -- radices 3, 5, 6, 9, 10, 12, 15 are built on them
+template <> __device__ __forceinline__ void dft_small<3>(cf (&v)[3]) {
+    const cf t = v[1] + v[2], d = v[1] - v[2];
+    const cf m = v[0] - 0.5f * t;
+    const float s = 0.86602540378443864676f;
+    v[0] = v[0] + t;
+    v[1] = cfma_mi(m, (cf){s, s}, d);                        // m - i s d
+    v[2] = cfms_mi(m, (cf){s, s}, d);
+}
+template <> __device__ __forceinline__ void dft_small<5>(cf (&v)[5]) {
+    const cf t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
+    const cf t5 = t1 + t2;
+    const float c = 0.55901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const cf m1 = v[0] - 0.25f * t5;
+    const cf m2 = c * (t1 - t2);
+    const cf a1 = m1 + m2, a2 = m1 - m2;
+    const cf b1 = s1 * t3 + s2 * t4;
+    const cf b2 = s2 * t3 - s1 * t4;
+    v[0] = v[0] + t5;
+    v[1] = cadd_mi(a1, b1);                                  // a1 - i b1
+    v[4] = csub_mi(a1, b1);
+    v[2] = cadd_mi(a2, b2);
+    v[3] = csub_mi(a2, b2);
+}
+template <> __device__ __forceinline__ void dft_small<7>(cf (&v)[7]) {        // matrix form (rare)
+    cf o[7];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        float2 acc = v[0];
+    for (int k = 0; k < 7; ++k) {
+        cf acc = v[0];
 #pragma unroll
-        for (int q = 1; q < R; ++q) {
-            const int m = (q * k) % R;
-            const float c = cs[m], s = -sn[m];      // exp(-i phi)
+        for (int q = 1; q < 7; ++q) {
+            const int m = (q * k) % 7;
+            const float c = kCos7[m], s = -kSin7[m];         // exp(-i phi)
             acc.x += v[q].x * c - v[q].y * s;
             acc.y += v[q].x * s + v[q].y * c;
         }
         o[k] = acc;
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) v[k] = o[k];
+    for (int k = 0; k < 7; ++k) v[k] = o[k];
 }
-// 3 and 5 points in the Rader/Winograd form (sums and differences of the mirrored pairs first): 7 and 21 complex
-// operations instead of the 12 and 40 of the matrix form above -- radices 3, 5, 6, 9, 10, 12, 15 are built on them
-template <> __device__ __forceinline__ void dft_small<3>(float2 (&v)[3]) {
-    const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-    const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
-    const float s = 0.86602540378443864676f;
-    v[0] = cadd(v[0], t);
-    v[1] = make_float2(m.x + s * d.y, m.y - s * d.x);       // m - i s d
-    v[2] = make_float2(m.x - s * d.y, m.y + s * d.x);
-}
-template <> __device__ __forceinline__ void dft_small<5>(float2 (&v)[5]) {
-    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    const float2 t5 = cadd(t1, t2);
-    const float c = 0.55901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-    const float2 m1 = make_float2(v[0].x - 0.25f * t5.x, v[0].y - 0.25f * t5.y);
-    const float2 m2 = make_float2(c * (t1.x - t2.x), c * (t1.y - t2.y));
-    const float2 a1 = cadd(m1, m2), a2 = csub(m1, m2);
-    const float2 b1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
-    const float2 b2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
-    v[0] = cadd(v[0], t5);
-    v[1] = make_float2(a1.x + b1.y, a1.y - b1.x);           // a1 - i b1
-    v[4] = make_float2(a1.x - b1.y, a1.y + b1.x);
-    v[2] = make_float2(a2.x + b2.y, a2.y - b2.x);
-    v[3] = make_float2(a2.x - b2.y, a2.y + b2.x);
-}
-template <> __device__ __forceinline__ void dft_small<7>(float2 (&v)[7]) { dft_odd<7>(v, kCos7, kSin7); }
-
 
 // ---- composite radices, evaluated in registers as A x B Cooley-Tukey with constant twiddles -------------
 // X[k1 + A k2] = sum_{n2} W_N^{n2 k1} ( sum_{n1} x[n1 B + n2] W_A^{n1 k1} ) W_B^{n2 k2},  N = A B
@@ -125,23 +161,23 @@ static __device__ const float kCos15[15] = {1.0f, 0.9135454576426009f, 0.6691306
 static __device__ const float kSin15[15] = {0.0f, 0.40673664307580015f, 0.7431448254773941f, 0.9510565162951535f, 0.9945218953682734f, 0.8660254037844387f, 0.5877852522924732f, 0.20791169081775931f, -0.20791169081775907f, -0.587785252292473f, -0.8660254037844384f, -0.9945218953682733f, -0.9510565162951536f, -0.743144825477394f, -0.40673664307580015f};
 static __device__ const float kCos16[16] = {1.0f, 0.9238795325112867f, 0.7071067811865476f, 0.38268343236508984f, 0.0f, -0.3826834323650897f, -0.7071067811865475f, -0.9238795325112867f, -1.0f, -0.9238795325112868f, -0.7071067811865477f, -0.38268343236509034f, 0.0f, 0.38268343236509f, 0.7071067811865474f, 0.9238795325112865f};
 static __device__ const float kSin16[16] = {0.0f, 0.3826834323650898f, 0.7071067811865475f, 0.9238795325112867f, 1.0f, 0.9238795325112867f, 0.7071067811865476f, 0.3826834323650899f, 0.0f, -0.38268343236508967f, -0.7071067811865475f, -0.9238795325112865f, -1.0f, -0.9238795325112866f, -0.7071067811865477f, -0.3826834323650904f};
-template <int A, int B> __device__ __forceinline__ void dft_ct(float2 (&v)[A * B], const float *cs, const float *sn) {
-    float2 y[A * B];
+template <int A, int B> __device__ __forceinline__ void dft_ct(cf (&v)[A * B], const float *cs, const float *sn) {
+    cf y[A * B];
 #pragma unroll
     for (int n2 = 0; n2 < B; ++n2) {
-        float2 col[A];
+        cf col[A];
 #pragma unroll
         for (int n1 = 0; n1 < A; ++n1) col[n1] = v[n1 * B + n2];
         dft_small<A>(col);
 #pragma unroll
         for (int k1 = 0; k1 < A; ++k1) {
             const int m = (n2 * k1) % (A * B);
-            y[k1 * B + n2] = (m == 0) ? col[k1] : cmul(col[k1], make_float2(cs[m], -sn[m]));
+            y[k1 * B + n2] = (m == 0) ? col[k1] : cmulc(col[k1], (cf){cs[m], -sn[m]});
         }
     }
 #pragma unroll
     for (int k1 = 0; k1 < A; ++k1) {
-        float2 row[B];
+        cf row[B];
 #pragma unroll
         for (int n2 = 0; n2 < B; ++n2) row[n2] = y[k1 * B + n2];
         dft_small<B>(row);
@@ -149,13 +185,13 @@ template <int A, int B> __device__ __forceinline__ void dft_ct(float2 (&v)[A * B
         for (int k2 = 0; k2 < B; ++k2) v[k1 + A * k2] = row[k2];
     }
 }
-template <> __device__ __forceinline__ void dft_small<6>(float2 (&v)[6]) { dft_ct<2, 3>(v, kCos6, kSin6); }
-template <> __device__ __forceinline__ void dft_small<8>(float2 (&v)[8]) { dft_ct<4, 2>(v, kCos8, kSin8); }
-template <> __device__ __forceinline__ void dft_small<9>(float2 (&v)[9]) { dft_ct<3, 3>(v, kCos9, kSin9); }
-template <> __device__ __forceinline__ void dft_small<10>(float2 (&v)[10]) { dft_ct<2, 5>(v, kCos10, kSin10); }
-template <> __device__ __forceinline__ void dft_small<12>(float2 (&v)[12]) { dft_ct<4, 3>(v, kCos12, kSin12); }
-template <> __device__ __forceinline__ void dft_small<15>(float2 (&v)[15]) { dft_ct<3, 5>(v, kCos15, kSin15); }
-template <> __device__ __forceinline__ void dft_small<16>(float2 (&v)[16]) { dft_ct<4, 4>(v, kCos16, kSin16); }
+template <> __device__ __forceinline__ void dft_small<6>(cf (&v)[6]) { dft_ct<2, 3>(v, kCos6, kSin6); }
+template <> __device__ __forceinline__ void dft_small<8>(cf (&v)[8]) { dft_ct<4, 2>(v, kCos8, kSin8); }
+template <> __device__ __forceinline__ void dft_small<9>(cf (&v)[9]) { dft_ct<3, 3>(v, kCos9, kSin9); }
+template <> __device__ __forceinline__ void dft_small<10>(cf (&v)[10]) { dft_ct<2, 5>(v, kCos10, kSin10); }
+template <> __device__ __forceinline__ void dft_small<12>(cf (&v)[12]) { dft_ct<4, 3>(v, kCos12, kSin12); }
+template <> __device__ __forceinline__ void dft_small<15>(cf (&v)[15]) { dft_ct<3, 5>(v, kCos15, kSin15); }
+template <> __device__ __forceinline__ void dft_small<16>(cf (&v)[16]) { dft_ct<4, 4>(v, kCos16, kSin16); }
 
 // t / m and t % m for 0 <= t < 2^23 with a float reciprocal and a one-step fix-up
 __device__ __forceinline__ void divmod(int t, int m, float inv_m, int &q, int &r) {
@@ -169,10 +205,10 @@ __device__ __forceinline__ void divmod(int t, int m, float inv_m, int &q, int &r
 // are products of two of them or of an earlier product (at most three roundings) -- four gathers instead of fifteen,
 // and no integer multiply per gather.
 template <int R>
-__device__ __forceinline__ void twiddle_powers(float2 (&w)[R], const float2 *__restrict__ tw, int m) {
+__device__ __forceinline__ void twiddle_powers(cf (&w)[R], const float2 *__restrict__ tw, int m) {
 #pragma unroll
     for (int q = 1; q < R; ++q) {
-        if ((q & (q - 1)) == 0) w[q] = tw[m * q];
+        if ((q & (q - 1)) == 0) w[q] = reinterpret_cast<const cf *>(tw)[m * q];
     }
 #pragma unroll
     for (int q = 3; q < R; ++q) {
@@ -199,15 +235,15 @@ __device__ __forceinline__ void stage(float2 *s, int N, int lognb, int L, const 
         const int t = w >> lognb;
         int blk, np;
         divmod(t, M, inv_m, blk, np);
-        float2 *base = s + (((long)blk * L + np) << lognb) + j;
+        cf *base = reinterpret_cast<cf *>(s) + (((long)blk * L + np) << lognb) + j;
         const int stride = M << lognb;
-        float2 v[R];
+        cf v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = base[q * stride];
         // M == 1 (the innermost stage): np == 0, every twiddle is 1 -- nothing to fetch or multiply
         if (DIT) {
             if (M > 1) {
-                float2 wq[R];
+                cf wq[R];
                 twiddle_powers<R>(wq, tw, np * tw_step);
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
@@ -216,7 +252,7 @@ __device__ __forceinline__ void stage(float2 *s, int N, int lognb, int L, const 
         } else {
             dft_small<R>(v);
             if (M > 1) {
-                float2 wq[R];
+                cf wq[R];
                 twiddle_powers<R>(wq, tw, np * tw_step);
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
@@ -291,15 +327,15 @@ __device__ __forceinline__ void first_stage(float2 *s, int N, int lognb, const f
     const int stride = M << lognb;
     for (int w = threadIdx.x; w < stride; w += (int)blockDim.x) {
         const int j = w & (nb - 1), np = w >> lognb;
-        float2 v[R];
+        cf v[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = io.load(np + q * M, j);
+        for (int q = 0; q < R; ++q) v[q] = to_cf(io.load(np + q * M, j));
         dft_small<R>(v);
-        float2 wq[R];
+        cf wq[R];
         twiddle_powers<R>(wq, tw, np);
 #pragma unroll
         for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
-        float2 *base = s + w;
+        cf *base = reinterpret_cast<cf *>(s) + w;
 #pragma unroll
         for (int q = 0; q < R; ++q) base[q * stride] = v[q];
     }
@@ -311,14 +347,14 @@ __device__ __forceinline__ void centre_stage(float2 *s, int N, int lognb, const 
     const int work = (N / R) << lognb;
     for (int w = threadIdx.x; w < work; w += (int)blockDim.x) {
         const int j = w & (nb - 1), t = w >> lognb;
-        float2 *base = s + ((t * R) << lognb) + j;
-        float2 v[R];
+        cf *base = reinterpret_cast<cf *>(s) + ((t * R) << lognb) + j;
+        cf v[R];
         float d[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) { v[q] = base[q << lognb]; d[q] = drev[t * R + q]; }
         dft_small<R>(v);
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = make_float2(-d[q] * v[q].y, -d[q] * v[q].x);      // conj(i d z)
+        for (int q = 0; q < R; ++q) v[q] = (cf){-d[q] * v[q].y, -d[q] * v[q].x};                // conj(i d z)
         dft_small<R>(v);
 #pragma unroll
         for (int q = 0; q < R; ++q) base[q << lognb] = v[q];
@@ -335,17 +371,17 @@ __device__ __forceinline__ void last_stage(const float2 *s, int N, int lognb, co
         typename IO::Pre pre[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) pre[q] = io.prefetch(np + q * M, j);
-        float2 v[R];
-        const float2 *base = s + w;
+        cf v[R];
+        const cf *base = reinterpret_cast<const cf *>(s) + w;
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = base[q * stride];
-        float2 wq[R];
+        cf wq[R];
         twiddle_powers<R>(wq, tw, np);
 #pragma unroll
         for (int q = 1; q < R; ++q) v[q] = cmul(v[q], wq[q]);
         dft_small<R>(v);
 #pragma unroll
-        for (int q = 0; q < R; ++q) io.store(np + q * M, j, v[q], pre[q]);
+        for (int q = 0; q < R; ++q) io.store(np + q * M, j, to_f2(v[q]), pre[q]);
     }
 }
 
