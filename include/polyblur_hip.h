@@ -155,6 +155,14 @@ int pb_set_stream(pb_ctx *ctx, void *stream);
 int pb_synchronize(pb_ctx *ctx);
 const char *pb_last_error_string(pb_ctx *ctx);
 void pb_default_options(pb_options *opt);        /* the functional API's defaults, deblurring.py:23-25 */
+/* How dense (non rank-1) kernels are evaluated by the reblurring pass.  PB_DENSE_STENCIL: always by the 2-D stencil
+ * body (up to 625 multiply-adds per sample, fp32-vector-bound).  PB_DENSE_AUTO (default, min_phases = 36): images whose
+ * stencil would run at least `min_phases` live (kernel row, 4-tap segment) phases are evaluated per 64 x 64 window in
+ * the frequency domain inside LDS (overlap-save; same taps, same boundary models, results agree to fp32 rounding);
+ * the others, rank-1 kernels and 8-bit images keep the stencil bodies.  Replaces nothing in the reference: both are
+ * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>. */
+typedef enum pb_dense_eval { PB_DENSE_STENCIL = 0, PB_DENSE_AUTO = 1 } pb_dense_eval;
+int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases);
 /* bytes of scratch the context currently holds (for the HBM-footprint report) */
 size_t pb_workspace_bytes(pb_ctx *ctx);
 
@@ -265,7 +273,7 @@ int pb_time_inner_loop(pb_ctx *ctx, const void *in, void *out, int dtype, int B,
 /* Per-kernel-class device timing with hipEvents on the context's stream.  Between begin and
  * end every launch is bracketed by two events; end synchronises and returns, per tag, the
  * summed milliseconds and the launch count (arrays of PB_PROF_NTAGS).                        */
-#define PB_PROF_NTAGS 9
+#define PB_PROF_NTAGS 10
 typedef enum pb_prof_tag {
     PB_PROF_CONV = 0,        /* stencil pass (one Horner step / taper blend) */
     PB_PROF_GRAY = 1,        /* gray + min/max */
@@ -275,7 +283,8 @@ typedef enum pb_prof_tag {
     PB_PROF_HALO = 5,        /* halo masking + its reductions */
     PB_PROF_PREFILTER = 6,   /* bilateral / domain transform / recombination */
     PB_PROF_OTHER = 7,
-    PB_PROF_CONV_FUSED = 8   /* Horner steps 2 + 3 in one launch (rank-1 kernels) */
+    PB_PROF_CONV_FUSED = 8,  /* Horner steps 2 + 3 in one launch (rank-1 kernels) */
+    PB_PROF_CONV_FFT = 9     /* the same pass for dense kernels: tile-spectrum body (conv_fft.hip) */
 } pb_prof_tag;
 int pb_profile_begin(pb_ctx *ctx);
 int pb_profile_end(pb_ctx *ctx, float *host_ms, int *host_count);

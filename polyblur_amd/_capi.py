@@ -21,6 +21,8 @@ PB_F32, PB_F16, PB_U8 = 0, 1, 2
 PB_WRAP, PB_ZERO = 0, 1
 PB_PREFILTER_NONE, PB_PREFILTER_BILATERAL, PB_PREFILTER_DOMAIN_TRANSFORM, PB_PREFILTER_NORMALIZED_CONVOLUTION = 0, 1, 2, 3
 PB_SUPPORT_FULL, PB_SUPPORT_ADAPTIVE = 0, 1
+PB_DENSE_STENCIL, PB_DENSE_AUTO = 0, 1
+PB_DENSE_MIN_PHASES = 36
 
 STATUS = {0: "PB_OK", -1: "PB_ERR_BADARG", -2: "PB_ERR_UNSUPPORTED", -3: "PB_ERR_HIP", -4: "PB_ERR_NOMEM"}
 
@@ -32,9 +34,9 @@ SYMBOLS = [
     "pb_inverse_filter", "pb_convolve2d", "pb_edgetaper", "pb_halo_mask", "pb_dt_recursive_filter",
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
     "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
-    "pb_fft_length_supported", "pb_make_separable_kernels",
+    "pb_fft_length_supported", "pb_make_separable_kernels", "pb_set_dense_eval",
 ]
-PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused"]
+PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused", "conv_fft"]
 
 
 class pb_options(C.Structure):
@@ -110,6 +112,7 @@ def load_library():
             "pb_last_error_string": (C.c_char_p, [vp]),
             "pb_default_options": (None, [C.POINTER(pb_options)]),
             "pb_workspace_bytes": (sz, [vp]),
+            "pb_set_dense_eval": (ci, [vp, ci, ci]),
             "pb_malloc": (ci, [vp, C.POINTER(vp), sz]),
             "pb_free": (ci, [vp, vp]),
             "pb_memcpy_h2d": (ci, [vp, vp, vp, sz]),

@@ -81,9 +81,20 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     pb_ctx *ctx = new pb_ctx();
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(stream);
+    if (const char *e = getenv("PB_DENSE_EVAL")) {              // "stencil": never the tile-spectrum body; a number: its phase threshold
+        if (e[0] == 's') ctx->fft_min_phases = -1;
+        else if (e[0] >= '0' && e[0] <= '9') ctx->fft_min_phases = atoi(e);
+    }
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     *out = ctx;
+    return PB_OK;
+}
+
+int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases) {
+    if (!ctx || (mode != PB_DENSE_STENCIL && mode != PB_DENSE_AUTO) || min_phases < 0 || min_phases > PB_MAX_PHASES + 1)
+        return PB_ERR_BADARG;
+    ctx->fft_min_phases = mode == PB_DENSE_STENCIL ? -1 : min_phases;
     return PB_OK;
 }
 
@@ -304,9 +315,9 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
         else if (rc != PB_ERR_UNSUPPORTED) return rc;
     }
 #endif
-    // t2 = K * t1 + a1 x
+    // t2 = K * t1 + a1 x   (the kernels' spectra, where the tile-spectrum body is used, were built by the first pass)
     set_in_padded(p, g, T1, tdt); set_out_padded(p, g, T2, tdt);
-    p.scale = 1.f; p.coef = a1;
+    p.scale = 1.f; p.coef = a1; p.khat_ready = 1;
     rc = pb_launch_conv(ctx, p);
     if (rc) return rc;
     // y = K * t2 + beta x   (only the crop is needed)

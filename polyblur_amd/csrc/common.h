@@ -51,6 +51,9 @@ struct pb_ctx {
     int interp_na = 0, interp_ni = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_switch = nullptr;
     size_t est_done_bytes = 0;     // size of the zero-initialised arrival counters
+    // dense (non rank-1) kernels with at least this many live stencil phases are evaluated per tile in the frequency
+    // domain (conv_fft.hip) instead of by the stencil body; < 0: never (pb_set_dense_eval, env PB_DENSE_EVAL)
+    int fft_min_phases = 36;
 };
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);
@@ -106,6 +109,9 @@ enum { OUT_INTERIOR = 0,  // write the H x W crop into an un-padded plane
 enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
        EPI_TAPER = 1 };   // out = a * x + (1-a) * (K*in),  a = v1[py] * v2[px]
 
+// per image: which body evaluates a dense kernel (written on the device by khat_kernel, conv_fft.hip)
+struct pb_fft_sel { int use_fft; int rf; };       // rf = window halo of the tile-spectrum body: 4, 8 or 12
+
 struct ConvPass {
     const void *in;  int in_kind;  int in_dtype;  int in_pitch;  long in_plane;
     const void *x;   int x_kind;   int x_dtype;   int x_pitch;   long x_plane;
@@ -121,11 +127,19 @@ struct ConvPass {
     int clamp01;
     int skip_sep;        // rank-1 images are handled by another launch of this step: their tiles exit at once
     int skip_general;    // non-rank-1 images are handled by another launch of this step (conv_xt.hip)
+    // tile-spectrum body (conv_fft.hip): per-image selection and kernel spectra (context scratch), filled in by
+    // pb_launch_conv; the caller sets khat_ready when an earlier pass on the same stream built them from the same records
+    const pb_fft_sel *fsel;
+    const float2 *khat;
+    int khat_ready;
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // conv_fused.hip (experimental build only)
 int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // conv_xt.hip
+bool pb_conv_fft_supports(const ConvPass &p);                                // conv_fft.hip
+int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float2 **khat, pb_fft_sel **sel, bool launch);
+int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 
 // ------------------------------------------------------------------------------------
 // estimation (estimate.hip)

@@ -82,6 +82,12 @@ class Engine:
     def synchronize(self):
         self._check(self.lib.pb_synchronize(self.ctx))
 
+    def set_dense_eval(self, mode: str = "auto", min_phases: int = 36):
+        """How dense (non rank-1) kernels are evaluated: 'stencil' = always the 2-D stencil body; 'auto' = kernels with
+        at least `min_phases` live stencil phases take the tile-spectrum body (pb_set_dense_eval)."""
+        m = {"stencil": capi.PB_DENSE_STENCIL, "auto": capi.PB_DENSE_AUTO}[mode]
+        self._check(self.lib.pb_set_dense_eval(self.ctx, m, int(min_phases)))
+
     def workspace_bytes(self) -> int:
         return int(self.lib.pb_workspace_bytes(self.ctx))
 

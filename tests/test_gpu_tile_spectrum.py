@@ -1,0 +1,96 @@
+"""GPU parity of the tile-spectrum body (csrc/conv_fft.hip): dense kernels evaluated per 64 x 64 window in the frequency
+domain.  It must agree with the oracle's spatial convolution and with the 2-D stencil body it stands in for, under both
+boundary models, every window halo class, every dtype it is built for, and on images smaller than one window."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import polyblur_ref as ref                      # the checker (tests only)
+from polyblur_amd import _capi as capi
+from polyblur_amd.synthetic import synthetic_blurry_batch
+
+
+@pytest.fixture()
+def eng():
+    from polyblur_amd.engine import get_engine
+    e = get_engine(0)
+    yield e
+    e.set_dense_eval("auto", capi.PB_DENSE_MIN_PHASES)
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def both_ways(eng, fn):
+    eng.set_dense_eval("auto", 0)                            # every dense kernel through the tile-spectrum body
+    a = fn()
+    eng.set_dense_eval("stencil")
+    b = fn()
+    return a, b
+
+
+@pytest.mark.parametrize("sigma,rho,deg", [(3.0, 2.0, 66.0), (4.0, 0.3, 42.0), (1.3, 0.8, 60.0), (0.6, 0.4, 24.0), (2.0, 1.0, 12.0)])
+@pytest.mark.parametrize("boundary,method", [(capi.PB_WRAP, "fft"), (capi.PB_ZERO, "direct")])
+@pytest.mark.parametrize("support", [capi.PB_SUPPORT_FULL, capi.PB_SUPPORT_ADAPTIVE])
+def test_inverse_filter_matches_oracle_and_stencil(eng, sigma, rho, deg, boundary, method, support):
+    x, _ = synthetic_blurry_batch(1, 3, 150, 210, seed0=11)
+    th = np.float32(deg) * np.float32(np.pi) / np.float32(180)
+    k = ref.gaussian_kernel_2d([th], [sigma], [rho])
+    buf = eng.make_kernels([sigma], [rho], [th], support=support)
+    assert eng.read_info(buf, 1)["separable"][0] == 0
+    a, b = both_ways(eng, lambda: eng.inverse_filter(x, buf, 6.0, 1.0, boundary))
+    want = ref.inverse_filtering_rank3(x, k[:, None], 6.0, 1.0, method=method)
+    assert maxabs(a, want) < 1e-5
+    assert maxabs(a, b) < 5e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 8, 9), (1, 3, 33, 130), (2, 3, 65, 63), (1, 2, 40, 44), (1, 1, 200, 37), (3, 1, 97, 161)])
+@pytest.mark.parametrize("boundary", [capi.PB_WRAP, capi.PB_ZERO])
+def test_convolve2d_small_and_ragged(eng, shape, boundary):
+    rng = np.random.default_rng(5)
+    B, C, H, W = shape
+    xp = rng.random((B, C, H + 24, W + 24), dtype=np.float32)
+    th = np.deg2rad(np.float32([30.0, 75.0, 110.0][:B]))
+    buf = eng.make_kernels([2.5, 1.2, 3.5][:B], [1.0, 0.7, 3.0][:B], th)
+    a, b = both_ways(eng, lambda: eng.convolve2d(xp, buf, boundary))
+    assert maxabs(a, b) < 2e-6
+
+
+def test_arbitrary_asymmetric_taps(eng):
+    # pb_set_kernels: any 25 x 25 taps, not only point-symmetric Gaussians (the spectrum is complex)
+    rng = np.random.default_rng(9)
+    k = rng.random((1, 25, 25), dtype=np.float32)
+    k /= k.sum()
+    xp = rng.random((1, 2, 120 + 24, 90 + 24), dtype=np.float32)
+    buf = eng.set_kernels(k)
+    a, b = both_ways(eng, lambda: eng.convolve2d(xp, buf, capi.PB_ZERO))
+    assert maxabs(a, b) < 2e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float16, 1e-3)])
+@pytest.mark.parametrize("extra", [dict(), dict(edgetaping=True), dict(method="direct", remove_halo=True)])
+def test_pipeline_both_ways(eng, dtype, tol, extra):
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    x, _ = synthetic_blurry_batch(2, 3, 240, 328, seed0=3)
+    xt = torch.from_numpy(x.astype(dtype)).cuda()
+    kw = dict(n_iter=3, c=0.362, b=0.468, alpha=6, beta=1, **extra)
+    a, b = both_ways(eng, lambda: polyblur_deblurring(xt, **kw).float().cpu().numpy())
+    want = ref.polyblur_deblurring(xt.float().cpu().numpy(), **kw)
+    assert maxabs(a, want) < tol
+    assert maxabs(a, b) < tol
+
+
+def test_mixed_batch(eng):
+    # one rank-1, one dense-small (below the threshold) and one dense-large kernel in the same launch
+    x, _ = synthetic_blurry_batch(3, 3, 130, 170, seed0=2)
+    th = np.deg2rad(np.float32([0.0, 24.0, 66.0]))
+    sig, rho = [2.0, 0.6, 3.0], [1.0, 0.4, 2.0]
+    buf = eng.make_kernels(sig, rho, th, support=capi.PB_SUPPORT_ADAPTIVE)
+    eng.set_dense_eval("auto", capi.PB_DENSE_MIN_PHASES)
+    out = eng.inverse_filter(x, buf, 6.0, 1.0, capi.PB_WRAP)
+    k = ref.gaussian_kernel_2d(th, sig, rho)
+    want = ref.inverse_filtering_rank3(x, k[:, None], 6.0, 1.0, method="fft")
+    assert maxabs(out, want) < 1e-5
