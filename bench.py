@@ -305,11 +305,23 @@ def main():
             return 4 * int(nph[0]) + 3 * (int(nph[1]) + int(nph[2]))
         macs = [sum(issued(int(r), int(sp), nph) for r, sp, nph in zip(i["radius"], i["separable"], i["nphase"])) / B
                 for i in infos]                                   # per sample, per pass
-        tflops = 2.0 * samples * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12 if conv_n else 0.0
-        roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
-                                frac=round(tflops / VALU_PEAK_TFLOPS, 4),
-                                note="dense (non-rank-1) kernels estimated for this input: the pass is VALU-bound; "
-                                     "context.inner_loop_rank1_* is the HBM-bound separable case")
+        # which body evaluated the dense kernels (pb_set_dense_eval: the default threshold on live stencil phases)
+        spectrum = [bool(not sp and int(sum(nph)) >= capi.PB_DENSE_MIN_PHASES)
+                    for i in infos for sp, nph in zip(i["separable"], i["nphase"])]
+        if any(spectrum):
+            roofline["kernel"] = ("conv_tile_kernel (one Horner step per launch; taps as estimated, full 25x25 support; dense "
+                                  "kernels evaluated per 64x64 window in the frequency domain inside LDS)")
+            roofline["body"] = dict(tile_spectrum_images=sum(spectrum), of=len(spectrum),
+                                    stencil_multiply_adds_per_sample_it_replaces=round(sum(macs) / len(macs), 1),
+                                    note="dense (non-rank-1) kernels estimated for this input; the pass is bound by LDS traffic and "
+                                         "the butterflies' vector instructions, not by HBM; context.end_to_end_dense_stencil_body is "
+                                         "the same call through the 2-D stencil body; context.inner_loop_rank1_* the separable case")
+        else:
+            tflops = 2.0 * samples * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12 if conv_n else 0.0
+            roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                                    frac=round(tflops / VALU_PEAK_TFLOPS, 4),
+                                    note="stencil bodies: multiply-adds issued / launch time; "
+                                         "context.inner_loop_rank1_* is the HBM-bound separable case")
 
     def inner_loop(theta_deg, sigma, rho, support, reps=20):
         buf = eng.make_kernels([sigma] * B, [rho] * B, [np.deg2rad(np.float32(theta_deg))] * B, support=support,
@@ -336,6 +348,16 @@ def main():
         dt_ad, _ = timed(args.steps, lambda: step("adaptive"))
         ms_ad = 1e3 * dt_ad / args.steps
         side["end_to_end_adaptive_support"] = dict(ms_per_step=round(ms_ad, 4), mp_per_s=round(B * H * W / 1e6 / (ms_ad * 1e-3), 1))
+        # the same call with every dense kernel through the 2-D stencil body (pb_set_dense_eval: PB_DENSE_STENCIL)
+        eng.set_dense_eval("stencil")
+        try:
+            for _ in range(2):
+                step()
+            dt_st, _ = timed(args.steps, step)
+        finally:
+            eng.set_dense_eval("auto", capi.PB_DENSE_MIN_PHASES)
+        ms_st = 1e3 * dt_st / args.steps
+        side["end_to_end_dense_stencil_body"] = dict(ms_per_step=round(ms_st, 4), mp_per_s=round(B * H * W / 1e6 / (ms_st * 1e-3), 1))
         # the opt-in x-t separable APPROXIMATION of the oblique kernels (method='direct_separable', zero boundary):
         # its speed, and its distance to the exact zero-boundary result on this image
         sep_kw = dict(kw, method="direct_separable")

@@ -130,15 +130,14 @@ struct ConvPass {
     // tile-spectrum body (conv_fft.hip): per-image selection and kernel spectra (context scratch), filled in by
     // pb_launch_conv; the caller sets khat_ready when an earlier pass on the same stream built them from the same records
     const pb_fft_sel *fsel;
-    const float2 *khat;
+    const float *khat;
     int khat_ready;
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // conv_fused.hip (experimental build only)
 int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // conv_xt.hip
-bool pb_conv_fft_supports(const ConvPass &p);                                // conv_fft.hip
-int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float2 **khat, pb_fft_sel **sel, bool launch);
+int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch);
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 
 // ------------------------------------------------------------------------------------

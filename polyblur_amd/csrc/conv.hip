@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int 
     const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
     const bool sep = cinfo->separable != 0;
     if (sep ? a.skip_sep : a.skip_general) return;                 // another launch of this step does this image
-    if (!sep && a.fsel && a.fsel[plane / a.C].use_fft) return;     // the tile-spectrum body (conv_fft.hip) does this image
+    if (!sep && a.fsel && as_constant(a.fsel + plane / a.C)->use_fft) return;     // the tile-spectrum body (conv_fft.hip) does this image
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
@@ -322,10 +322,10 @@ static int launch_stencil(pb_ctx *ctx, const ConvPass &p);
 // which -- as in the first -- every image's tiles exit at once unless the image's record selects that body.
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     ConvPass p = p0;
-    const bool fft = ctx->fft_min_phases >= 0 && !p.skip_general && pb_conv_fft_supports(p);
+    const bool fft = ctx->fft_min_phases >= 0 && !p.skip_general;
     if (!fft) { p.fsel = nullptr; p.khat = nullptr; }
     else {
-        float2 *k = nullptr; pb_fft_sel *s = nullptr;
+        float *k = nullptr; pb_fft_sel *s = nullptr;
         const int rc = pb_build_khat(ctx, p.info, p.P / p.C, &k, &s, !p.khat_ready);
         if (rc) return rc;
         p.khat = k; p.fsel = s;

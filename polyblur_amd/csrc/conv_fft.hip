@@ -22,6 +22,9 @@
 // * LDS rows are 65 complex values long: every row-direction access (stride 8 or contiguous 8 per lane) and every
 //   column-direction access is bank-conflict-free for ds_read_b64 / ds_write_b64.
 // * Each thread keeps ONE set of seven inter-stage twiddles W64^(n2 k) for the whole kernel (its n2 = 2 wave + half).
+// * Workgroups are persistent (four per CU) and walk the window pairs of their XCD: the 16 spectrum values a thread
+//   multiplies are the same for every window of an image and stay in registers, so the 32 KB spectrum is read once per
+//   workgroup and image, not once per window.
 //
 // The window keeps R = 4, 8 or 12 samples of halo (the record's radius class rounded up to a multiple of 4: 16-byte
 // aligned windows), i.e. 56, 48 or 40 outputs per side; every image picks its own on the device, like its body.
@@ -68,6 +71,18 @@ __device__ __forceinline__ cf cmul_conj(cf a, cf w) {
     return r;                                                                                                    // (.. + a.y w.y, a.y w.x - ..)
 }
 
+// a * h.x  and  a * h.y  for real h (two spectrum values share a register pair)
+__device__ __forceinline__ cf scale_lo(cf a, cf h) {
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(h));
+    return r;
+}
+__device__ __forceinline__ cf scale_hi(cf a, cf h) {
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(h));
+    return r;
+}
+
 // inverse 8-point DFT (unnormalised): the forward one with its outputs read in mirrored order
 __device__ __forceinline__ void idft8(cf (&v)[8]) {
     pbfft::dft_small<8>(v);
@@ -78,13 +93,16 @@ __device__ __forceinline__ void idft8(cf (&v)[8]) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// spectrum of every image's kernel (one workgroup per image)
+// spectrum of every image's kernel (eight workgroups per image)
 // ---------------------------------------------------------------------------------------------
-// khat[py][px] = (1/4096) sum_{u,v} k[u][v] exp(+2 pi i (fy (u-12) + fx (v-12)) / 64),  f = (p >> 3) + 8 (p & 7):
-// the conjugate spectrum (the pass is a correlation, like the stencil bodies), in the transforms' permuted order, with
-// both transforms' normalisation folded in.  Only the taps inside the record's support box count, exactly as in the
-// stencil body.  Accumulated in double (the spectrum is then the correctly rounded fp32 one).
-__global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, float2 *khat, pb_fft_sel *sel, int min_phases) {
+// khat[py][px] = (1/4096) sum_{u,v} k[u][v] cos(2 pi (fy (u-12) + fx (v-12)) / 64),  f = (p >> 3) + 8 (p & 7):
+// the spectrum of a point-symmetric real kernel -- every Gaussian the estimator builds is one, bit for bit
+// (k[12+u][12+v] == k[12-u][12-v]) -- is real, so correlation and convolution coincide and a thread's 16 spectrum
+// values fit 16 registers.  Laid out in the transforms' permuted order, both transforms' normalisation folded in.  Only
+// the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double (the spectrum
+// is then the correctly rounded fp32 one).  Caller-supplied taps that are not point-symmetric keep the stencil body.
+constexpr int KH_SLICES = 8;          // workgroups per image: each evaluates 512 of the 4096 values of the second sum
+__global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases) {
     __shared__ double2 G[PB_KSIZE * FT_N];
     __shared__ double cs[FT_N], sn[FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
@@ -92,14 +110,18 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
     const int tid = threadIdx.x;
     const int nph = info->nphase[0] + info->nphase[1] + info->nphase[2];
     const int R = info->radius;
-    const bool use = info->separable == 0 && nph >= min_phases && min_phases >= 0;
-    if (tid == 0) { sel[blockIdx.x].use_fft = use ? 1 : 0; sel[blockIdx.x].rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
-    if (!use) return;
-    if (tid < FT_N) { double s, c; sincospi((double)tid / 32.0, &s, &c); cs[tid] = c; sn[tid] = s; }
+    bool sym = true;
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += FT_NT) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
-        sk[i] = (abs(u) <= R && abs(v) <= R) ? info->kernel[i] : 0.f;
+        const bool in = abs(u) <= R && abs(v) <= R;
+        const float k = info->kernel[i];
+        sk[i] = in ? k : 0.f;
+        sym = sym && (!in || k == info->kernel[PB_KSIZE * PB_KSIZE - 1 - i]);
     }
+    const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases && min_phases >= 0;
+    if (tid == 0 && blockIdx.y == 0) { sel[blockIdx.x].use_fft = use ? 1 : 0; sel[blockIdx.x].rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
+    if (!use) return;
+    if (tid < FT_N) { double s, c; sincospi((double)tid / 32.0, &s, &c); cs[tid] = c; sn[tid] = s; }
     __syncthreads();
     for (int idx = tid; idx < PB_KSIZE * FT_N; idx += FT_NT) {
         const int u = idx >> 6, px = idx & 63, fx = (px >> 3) + 8 * (px & 7);
@@ -112,17 +134,16 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
         G[idx] = make_double2(ar, ai);
     }
     __syncthreads();
-    float2 *out = khat + (long)blockIdx.x * (FT_N * FT_N);
-    for (int idx = tid; idx < FT_N * FT_N; idx += FT_NT) {
+    float *out = khat + (long)blockIdx.x * (FT_N * FT_N);
+    for (int idx = blockIdx.y * (FT_N * FT_N / KH_SLICES) + tid; idx < (blockIdx.y + 1) * (FT_N * FT_N / KH_SLICES); idx += FT_NT) {
         const int py = idx >> 6, px = idx & 63, fy = (py >> 3) + 8 * (py & 7);
-        double ar = 0.0, ai = 0.0;
+        double ar = 0.0;
         for (int u = 0; u < PB_KSIZE; ++u) {
             const int m = (fy * (u - PB_KRAD)) & 63;
             const double2 g = G[u * FT_N + px];
             ar += g.x * cs[m] - g.y * sn[m];
-            ai += g.x * sn[m] + g.y * cs[m];
         }
-        out[idx] = make_float2((float)(ar * (1.0 / 4096.0)), (float)(ai * (1.0 / 4096.0)));
+        out[idx] = (float)(ar * (1.0 / 4096.0));
     }
 }
 
@@ -159,67 +180,120 @@ __device__ __forceinline__ void finish1(const ConvPass &a, const pb_blur_info *i
     pb_st(opl + (long)(py - oo) * a.out_pitch + (px - oo), v);
 }
 
-template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, int jobs_per_plane, int total_jobs) {
-    extern __shared__ __attribute__((aligned(16))) float2 Z[];
-    // XCD-aware order (see conv_tile_kernel): every XCD gets one contiguous run of window pairs
-    const int chunk = gridDim.x >> 3;
-    const int job = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (job >= total_jobs) return;
-    const int plane = __builtin_amdgcn_readfirstlane(job / jobs_per_plane);
-    const int local = job - plane * jobs_per_plane;
-    const int img = __builtin_amdgcn_readfirstlane(plane / a.C);
-    const pb_fft_sel sel = a.fsel[img];
-    if (!sel.use_fft) return;                                   // a stencil body of conv_tile_kernel does this image
-    const pb_blur_info *info = a.info + img;
-    const int R = sel.rf, T = FT_N - 2 * R;
+// Geometry of a pass for the three window halo classes (index R / 4 - 1), computed on the host: window pairs per row, pairs
+// per plane, pairs per plane and XCD; the reciprocals turn the kernel's divisions of small integers into one multiply.
+struct FftGeom {
+    int pairs_x[3], njobs[3], per[3];
+    float inv_pairs_x[3];
+    int slots;                    // per[2]: pairs per plane and XCD for the smallest tile (the job grid is sized for it)
+    float inv_slots;
+};
+__device__ __forceinline__ int div_small(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }   // n < 2^22, exact
+
+// Border windows: rows and columns are mapped through the boundary model once per window row / column of the thread
+// (12 maps for its 32 samples), then the samples are fetched one by one.
+template <typename TIn>
+__device__ __forceinline__ void stage1_mapped(const ConvPass &a, const TIn *ipl, int wy0, int wxA, int wxB, bool hasB, float2 *Z,
+                                              const cf (&tw)[8], int n2, int l) {
+    int iy[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) iy[n1] = map_axis(wy0 + 8 * n1 + n2, a.H, a.in_kind, a.boundary, a.pad);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        const int x = l + 32 * t;
+        const int ixa = map_axis(wxA + x, a.W, a.in_kind, a.boundary, a.pad);
+        const int ixb = hasB ? map_axis(wxB + x, a.W, a.in_kind, a.boundary, a.pad) : -1;
+        cf v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const TIn *row = ipl + (long)max(iy[n1], 0) * a.in_pitch;
+            v[n1] = (cf){(iy[n1] | ixa) >= 0 ? pb_ld(row + ixa) : 0.f, (iy[n1] | ixb) >= 0 ? pb_ld(row + ixb) : 0.f};
+        }
+        pbfft::dft_small<8>(v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Z[(8 * k + n2) * FT_P + x] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
+    }
+}
+// Border / taper epilogues, one output at a time.
+template <typename TX, typename TOut>
+__device__ __forceinline__ void epilogue_mapped(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl, int wy0,
+                                                int wxA, int R, bool hasB, const float2 *Z, const cf (&tw)[8], int n2, int l) {
     const OutRegion rg = out_region(a);
-    const int tiles_x = (rg.x_hi - rg.x_lo + T - 1) / T, pairs_x = (tiles_x + 1) >> 1, tiles_y = (rg.y_hi - rg.y_lo + T - 1) / T;
-    if (local >= pairs_x * tiles_y) return;                     // the grid is sized for the smallest tile
-    const int ty = __builtin_amdgcn_readfirstlane(local / pairs_x), pxi = local - ty * pairs_x;
-    const int wy0 = rg.y_lo + ty * T - R;                       // window origin, padded coordinates
-    const int wxA = rg.x_lo + 2 * pxi * T - R, wxB = wxA + T;
-    const bool hasB = wxB + R < rg.x_hi;
+    const int wxB = wxA + FT_N - 2 * R;
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        const int x = l + 32 * t;
+        const bool colA = x >= R && x < FT_N - R && wxA + x < rg.x_hi;
+        const bool colB = colA && hasB && wxB + x < rg.x_hi;
+        const float2 *p = Z + n2 * FT_P + x;
+        cf v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = pbfft::to_cf(p[8 * k * FT_P]); if (k) v[k] = cmul_conj(v[k], tw[k]); }
+        idft8(v);
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int i = 8 * n1 + n2, py = wy0 + i;
+            const bool rowok = i >= R && i < FT_N - R && py < rg.y_hi;
+            if (rowok && colA) finish1<TOut>(a, info, opl, py, wxA + x, v[n1].x, load_x1<TX>(a, xpl, py, wxA + x));
+            if (rowok && colB) finish1<TOut>(a, info, opl, py, wxB + x, v[n1].y, load_x1<TX>(a, xpl, py, wxB + x));
+        }
+    }
+}
+
+// One window pair.  Z: the workgroup's LDS tile; tw: the thread's inter-stage twiddles; kp: the image's spectrum.
+template <typename TIn, typename TX, typename TOut>
+__device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, int R, float2 *Z,
+                                            const cf (&tw)[8], const float *kp) {
+    const int T = FT_N - 2 * R;
+    const OutRegion rg = out_region(a);
+    const int wy0_ = rg.y_lo + ty * T - R;                      // window origin, padded coordinates
+    const int wxA_ = rg.x_lo + 2 * pxi * T - R;
+    const bool hasB = wxA_ + T + R < rg.x_hi;
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
+    const int tid0 = threadIdx.x;
+#define PB_STAGE_IDS const int tid = tid0, wave = tid >> 6, lane = tid & 63, l = lane & 31, n2 = 2 * wave + (lane >> 5); (void)l; (void)n2;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int l = lane & 31, n2 = 2 * wave + (lane >> 5);       // this thread's stage-1 column of the 8 x 8 index split
-    cf tw[8];
+    // the 16 spectrum values this thread multiplies in the centre stage: row (lane & 7) + 8 wave + 32 t, columns 8 (lane >> 3) ..
+    cf kh[2][4];
+    {
+        PB_STAGE_IDS
 #pragma unroll
-    for (int k = 1; k < 8; ++k) { const float2 w = kW64[(n2 * k) & 63]; tw[k] = (cf){w.x, w.y}; }
-
+        for (int t = 0; t < 2; ++t) {
+            const float4 *hp = reinterpret_cast<const float4 *>(kp + ((lane & 7) + 8 * wave + 32 * t) * FT_N + 8 * (lane >> 3));
+            const float4 h0 = hp[0], h1 = hp[1];
+            kh[t][0] = (cf){h0.x, h0.y}; kh[t][1] = (cf){h0.z, h0.w}; kh[t][2] = (cf){h1.x, h1.y}; kh[t][3] = (cf){h1.z, h1.w};
+        }
+    }
     // ---- columns, stage 1, straight from global memory: window rows 8 n1 + n2 of columns l, l + 32 ----
     {
+        PB_STAGE_IDS
+        const int wy0 = wy0_, wxA = wxA_, wxB = wxA_ + T;
         const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
         const bool inside = wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB;
+        if (inside) {
+            // interior pair: uniform plane pointer + 32-bit offsets
+            const unsigned step = 8u * (unsigned)a.in_pitch;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int x = l + 32 * t;
-            cf v[8];
-            if (inside) {
-                const TIn *p = ipl + (long)(wy0 - lo + n2) * a.in_pitch + (wxA - lo + x);
+            for (int t = 0; t < 2; ++t) {
+                const unsigned off = (unsigned)(wy0 - lo + n2) * (unsigned)a.in_pitch + (unsigned)(wxA - lo + l + 32 * t);
+                cf v[8];
 #pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) v[n1] = (cf){pb_ld(p + (long)(8 * n1) * a.in_pitch), pb_ld(p + (long)(8 * n1) * a.in_pitch + T)};
-            } else {
+                for (int n1 = 0; n1 < 8; ++n1) v[n1] = (cf){pb_ld(ipl + (off + n1 * step)), pb_ld(ipl + (off + n1 * step + (unsigned)T))};
+                pbfft::dft_small<8>(v);
 #pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) {
-                    const int py = wy0 + 8 * n1 + n2;
-                    v[n1] = (cf){load_elem<TIn>(a, ipl, py, wxA + x), hasB ? load_elem<TIn>(a, ipl, py, wxB + x) : 0.f};
-                }
+                for (int k = 0; k < 8; ++k) Z[(8 * k + n2) * FT_P + l + 32 * t] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
             }
-            pbfft::dft_small<8>(v);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const cf r = k ? pbfft::cmul(v[k], tw[k]) : v[0];
-                Z[(8 * k + n2) * FT_P + x] = make_float2(r.x, r.y);
-            }
+        } else {
+            stage1_mapped<TIn>(a, ipl, wy0, wxA, wxB, hasB, Z, tw, n2, l);
         }
     }
     __syncthreads();
     // ---- columns, stage 2: rows 8 k1 .. 8 k1 + 7 of column `lane` ----
+    {
+    PB_STAGE_IDS
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (8 * (2 * wave + t)) * FT_P + lane;
@@ -230,8 +304,11 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[j * FT_P] = pbfft::to_f2(v[j]);
     }
+    }
     __syncthreads();
     // ---- rows, stage 1: columns 8 n1 + n2 of rows l, l + 32 ----
+    {
+    PB_STAGE_IDS
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (l + 32 * t) * FT_P + n2;
@@ -242,34 +319,29 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, in
 #pragma unroll
         for (int k = 0; k < 8; ++k) p[8 * k] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
     }
+    }
     __syncthreads();
     // ---- rows, stage 2 -> x spectrum -> inverse stage 2: columns 8 k1 .. 8 k1 + 7 of one row ----
     {
-        const float2 *kh = a.khat + (long)img * (FT_N * FT_N);
+    PB_STAGE_IDS
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = (lane & 7) + 8 * wave + 32 * t, k1 = lane >> 3;
-            const float4 *hp = reinterpret_cast<const float4 *>(kh + row * FT_N + 8 * k1);
-            float4 h[4];
+    for (int t = 0; t < 2; ++t) {
+        float2 *p = Z + ((lane & 7) + 8 * wave + 32 * t) * FT_P + 8 * (lane >> 3);
+        cf v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[j] = hp[j];
-            float2 *p = Z + row * FT_P + 8 * k1;
-            cf v[8];
+        for (int j = 0; j < 8; ++j) v[j] = pbfft::to_cf(p[j]);
+        pbfft::dft_small<8>(v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pbfft::to_cf(p[j]);
-            pbfft::dft_small<8>(v);
+        for (int j = 0; j < 4; ++j) { v[2 * j] = scale_lo(v[2 * j], kh[t][j]); v[2 * j + 1] = scale_hi(v[2 * j + 1], kh[t][j]); }
+        idft8(v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[2 * j] = pbfft::cmul(v[2 * j], (cf){h[j].x, h[j].y});
-                v[2 * j + 1] = pbfft::cmul(v[2 * j + 1], (cf){h[j].z, h[j].w});
-            }
-            idft8(v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p[j] = pbfft::to_f2(v[j]);
-        }
+        for (int j = 0; j < 8; ++j) p[j] = pbfft::to_f2(v[j]);
+    }
     }
     __syncthreads();
     // ---- rows, inverse stage 1 ----
+    {
+    PB_STAGE_IDS
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (l + 32 * t) * FT_P + n2;
@@ -280,8 +352,11 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[8 * j] = pbfft::to_f2(v[j]);
     }
+    }
     __syncthreads();
     // ---- columns, inverse stage 2 ----
+    {
+    PB_STAGE_IDS
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (8 * (2 * wave + t)) * FT_P + lane;
@@ -292,21 +367,39 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[j * FT_P] = pbfft::to_f2(v[j]);
     }
+    }
     __syncthreads();
     // ---- columns, inverse stage 1, into the epilogue: window rows 8 n1 + n2 of columns l, l + 32 ----
+    // Fast form: both tiles complete, inside the output region, their x operand addressed without clamping, plain Horner
+    // epilogue -- uniform plane pointers + 32-bit offsets.
+    PB_STAGE_IDS
+#undef PB_STAGE_IDS
+    const int xo = a.x_kind == SRC_VIRTUAL ? a.pad : 0, oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
+    const int wy0 = wy0_, wxA = wxA_;
+    const int oy0 = wy0 + R, oxA = wxA + R;
+    const bool fast = a.epilogue == EPI_HORNER && hasB && oy0 + T <= rg.y_hi && oxA + 2 * T <= rg.x_hi && oy0 - xo >= 0 &&
+                      oxA - xo >= 0 && oy0 + T - xo <= (a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * a.pad) &&
+                      oxA + 2 * T - xo <= (a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * a.pad);
+    if (!fast) {
+        epilogue_mapped<TX, TOut>(a, info, xpl, opl, wy0, wxA, R, hasB, Z, tw, n2, l);
+        return;
+    }
+    const float sc = a.scale, cfx = a.coef;
+    const bool cl = a.clamp01 != 0;
+    const unsigned xstep = 8u * (unsigned)a.x_pitch, ostep = 8u * (unsigned)a.out_pitch;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int x = l + 32 * t;
-        const bool colA = x >= R && x < FT_N - R && wxA + x < rg.x_hi;
-        const bool colB = colA && hasB && wxB + x < rg.x_hi;
-        // (operands first: they arrive while the last butterflies run)
+        const bool colok = x >= R && x < FT_N - R;
+        const unsigned xoff = (unsigned)(wy0 + n2 - xo) * (unsigned)a.x_pitch + (unsigned)(wxA + x - xo);
+        const unsigned ooff = (unsigned)(wy0 + n2 - oo) * (unsigned)a.out_pitch + (unsigned)(wxA + x - oo);
         float xa[8], xb[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-            const int i = 8 * n1 + n2, py = wy0 + i;
-            const bool rowok = i >= R && i < FT_N - R && py < rg.y_hi;
-            xa[n1] = (rowok && colA) ? load_x1<TX>(a, xpl, py, wxA + x) : 0.f;
-            xb[n1] = (rowok && colB) ? load_x1<TX>(a, xpl, py, wxB + x) : 0.f;
+            const int i = 8 * n1 + n2;
+            const bool ok = colok && i >= R && i < FT_N - R;
+            xa[n1] = 0.f; xb[n1] = 0.f;
+            if (ok) { xa[n1] = pb_ld(xpl + (xoff + n1 * xstep)); xb[n1] = pb_ld(xpl + (xoff + n1 * xstep + (unsigned)T)); }
         }
         const float2 *p = Z + n2 * FT_P + x;
         cf v[8];
@@ -315,43 +408,72 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, in
         idft8(v);
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-            const int i = 8 * n1 + n2, py = wy0 + i;
-            const bool rowok = i >= R && i < FT_N - R && py < rg.y_hi;
-            if (rowok && colA) finish1<TOut>(a, info, opl, py, wxA + x, v[n1].x, xa[n1]);
-            if (rowok && colB) finish1<TOut>(a, info, opl, py, wxB + x, v[n1].y, xb[n1]);
+            const int i = 8 * n1 + n2;
+            const bool ok = colok && i >= R && i < FT_N - R;
+            float ra = fmaf(sc, v[n1].x, cfx * xa[n1]), rb = fmaf(sc, v[n1].y, cfx * xb[n1]);
+            if (cl) { ra = fminf(fmaxf(ra, 0.f), 1.f); rb = fminf(fmaxf(rb, 0.f), 1.f); }
+            if (ok) { pb_st(opl + (ooff + n1 * ostep), ra); pb_st(opl + (ooff + n1 * ostep + (unsigned)T), rb); }
         }
     }
+}
+
+// One workgroup per window pair.  Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only): the window
+// pairs of every plane are split into eight contiguous runs, one per XCD, so that neighbouring windows share their halos
+// in that XCD's L2.  g.slots = pairs per plane and XCD when the tiles are the smallest (40 x 40) -- the grid is sized for
+// that; an image with larger tiles leaves the surplus workgroups idle.
+template <typename TIn, typename TX, typename TOut>
+__global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, const FftGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float2 Z[];
+    const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+    const int plane = __builtin_amdgcn_readfirstlane(div_small(s, g.inv_slots)), i = s - plane * g.slots;
+    const int img = __builtin_amdgcn_readfirstlane(plane / a.C);
+    const PB_CONSTANT pb_fft_sel *sel = as_constant(a.fsel + img);
+    if (!sel->use_fft) return;                                  // a stencil body of conv_tile_kernel does this image
+    const int R = sel->rf, c = (R >> 2) - 1;
+    const int local = xcd * g.per[c] + i;
+    if (i >= g.per[c] || local >= g.njobs[c]) return;
+    const int ty = __builtin_amdgcn_readfirstlane(div_small(local, g.inv_pairs_x[c])), pxi = local - ty * g.pairs_x[c];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n2 = 2 * wave + (lane >> 5);
+    cf tw[8];
+    tw[0] = (cf){1.f, 0.f};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const float2 w = kW64[(n2 * k) & 63]; tw[k] = (cf){w.x, w.y}; }
+    window_pair<TIn, TX, TOut>(a, a.info + img, plane, ty, pxi, R, Z, tw, a.khat + (long)img * (FT_N * FT_N));
 }
 
 template <typename TIn, typename TX, typename TOut>
 int launch_fft_typed(pb_ctx *ctx, const ConvPass &p) {
     const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * p.pad;
     const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * p.pad;
-    constexpr int Tmin = FT_N - 2 * PB_KRAD;                   // 40: the grid covers the smallest tile; workgroups past an image's own count exit
-    const long tiles_x = (ow + Tmin - 1) / Tmin, tiles_y = (oh + Tmin - 1) / Tmin;
-    const long jpp = ((tiles_x + 1) / 2) * tiles_y;
-    const long jobs = jpp * p.P;
-    if (jobs <= 0 || jobs > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "conv pass: bad grid");
-    const long grid = (jobs + 7) / 8 * 8;
-    hipLaunchKernelGGL((conv_fft_kernel<TIn, TX, TOut>), dim3((unsigned)grid), dim3(FT_NT), kFftLds, ctx->stream, p, (int)jpp, (int)jobs);
+    FftGeom g;
+    for (int c = 0; c < 3; ++c) {
+        const int T = FT_N - 8 * (c + 1);
+        const long tiles_x = (ow + T - 1) / T, tiles_y = (oh + T - 1) / T;
+        const long px = (tiles_x + 1) / 2, nj = px * tiles_y;
+        if (nj > (1L << 22)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: plane too large for the tile-spectrum body");
+        g.pairs_x[c] = (int)px; g.njobs[c] = (int)nj; g.per[c] = (int)((nj + 7) / 8);
+        g.inv_pairs_x[c] = 1.0f / (float)px;
+    }
+    g.slots = g.per[2];
+    g.inv_slots = 1.0f / (float)g.slots;
+    const long total = (long)g.slots * p.P;
+    if (total <= 0 || total > (1L << 22)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: batch too large for the tile-spectrum body");
+    hipLaunchKernelGGL((conv_fft_kernel<TIn, TX, TOut>), dim3((unsigned)(8 * total)), dim3(FT_NT), kFftLds, ctx->stream, p, g);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
 
 }  // namespace
 
-bool pb_conv_fft_supports(const ConvPass &p) {
-    return p.in_dtype != PB_U8 && p.x_dtype != PB_U8 && p.out_dtype != PB_U8;
-}
-
 // Spectra + per-image body selection for the B images of `info` (B = P / C).
-int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float2 **khat, pb_fft_sel **sel, bool launch) {
-    float2 *k = static_cast<float2 *>(pb_scratch(ctx, "conv.khat", sizeof(float2) * FT_N * FT_N * (size_t)B));
+int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch) {
+    float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat", sizeof(float) * FT_N * FT_N * (size_t)B));
     pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel", sizeof(pb_fft_sel) * (size_t)B));
     if (!k || !s) return PB_ERR_NOMEM;
     if (launch) {
         ProfScope prof(ctx, PB_PROF_PARAMS);
-        hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B), dim3(FT_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases);
+        hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(FT_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases);
         PB_LAUNCH_CHECK();
     }
     *khat = k; *sel = s;
@@ -370,6 +492,11 @@ int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p) {
         case 10: return launch_fft_typed<__half, float, __half>(ctx, p);
         case 12: return launch_fft_typed<__half, __half, float>(ctx, p);
         case 13: return launch_fft_typed<__half, __half, __half>(ctx, p);
+        // 8-bit images (see pb_launch_conv)
+        case 24: return launch_fft_typed<unsigned char, unsigned char, float>(ctx, p);
+        case 6: return launch_fft_typed<float, unsigned char, float>(ctx, p);
+        case 8: return launch_fft_typed<float, unsigned char, unsigned char>(ctx, p);
+        case 2: return launch_fft_typed<float, float, unsigned char>(ctx, p);
         default: return pb_fail(ctx, PB_ERR_UNSUPPORTED, "tile-spectrum pass: unsupported dtype combination %d", key);
     }
 }

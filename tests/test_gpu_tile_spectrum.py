@@ -58,15 +58,21 @@ def test_convolve2d_small_and_ragged(eng, shape, boundary):
     assert maxabs(a, b) < 2e-6
 
 
-def test_arbitrary_asymmetric_taps(eng):
-    # pb_set_kernels: any 25 x 25 taps, not only point-symmetric Gaussians (the spectrum is complex)
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_caller_supplied_taps(eng, symmetric):
+    # pb_set_kernels: any 25 x 25 taps.  Point-symmetric ones (real spectrum) take the tile-spectrum body, the others
+    # keep the stencil body -- either way the result is the oracle's spatial correlation.
     rng = np.random.default_rng(9)
     k = rng.random((1, 25, 25), dtype=np.float32)
+    if symmetric:
+        k = k + k[:, ::-1, ::-1]
     k /= k.sum()
     xp = rng.random((1, 2, 120 + 24, 90 + 24), dtype=np.float32)
     buf = eng.set_kernels(k)
     a, b = both_ways(eng, lambda: eng.convolve2d(xp, buf, capi.PB_ZERO))
     assert maxabs(a, b) < 2e-6
+    want = ref.convolve2d(xp, k[:, None], method="direct")
+    assert maxabs(a, want) < 2e-6
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float16, 1e-3)])
