@@ -322,7 +322,10 @@ static int launch_stencil(pb_ctx *ctx, const ConvPass &p);
 // which -- as in the first -- every image's tiles exit at once unless the image's record selects that body.
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     ConvPass p = p0;
-    const bool fft = ctx->fft_min_phases >= 0 && !p.skip_general;
+    // (the tile-spectrum body addresses planes with 32-bit byte offsets)
+    const long plane_max = (1L << 31) - 4096;
+    const bool fft = ctx->fft_min_phases >= 0 && !p.skip_general && p.in_plane * 4 < plane_max && p.x_plane * 4 < plane_max &&
+                     p.out_plane * 4 < plane_max;
     if (!fft) { p.fsel = nullptr; p.khat = nullptr; }
     else {
         float *k = nullptr; pb_fft_sel *s = nullptr;

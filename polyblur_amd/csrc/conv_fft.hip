@@ -83,6 +83,28 @@ __device__ __forceinline__ cf scale_hi(cf a, cf h) {
     return r;
 }
 
+// Plane-relative accesses of the interior path go through buffer descriptors: a 32-bit byte offset per lane plus a scalar
+// one (tile B sits T samples to the right of tile A), no 64-bit address arithmetic, and an offset at or beyond the plane's size makes a load return 0 and a store vanish -- the halo
+// rows and columns of a window, which produce no output, need no branch.
+typedef __amdgpu_buffer_rsrc_t brsrc;
+constexpr unsigned kNoAccess = 0x80000000u;     // planes are smaller than 2 GiB (checked on the host)
+template <typename T> __device__ __forceinline__ brsrc plane_rsrc(const T *plane, long elems) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(plane), 0, (int)(elems * (long)sizeof(T)), 0x00020000);
+}
+template <typename T> struct BufIO;
+template <> struct BufIO<float> {
+    static __device__ __forceinline__ float ld(brsrc r, unsigned b, int sb) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)b, sb, 0)); }
+    static __device__ __forceinline__ void st(brsrc r, unsigned b, int sb, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)b, sb, 0); }
+};
+template <> struct BufIO<__half> {
+    static __device__ __forceinline__ float ld(brsrc r, unsigned b, int sb) { return __half2float(__builtin_bit_cast(__half, __builtin_amdgcn_raw_buffer_load_b16(r, (int)b, sb, 0))); }
+    static __device__ __forceinline__ void st(brsrc r, unsigned b, int sb, float v) { __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, __float2half_rn(v)), r, (int)b, sb, 0); }
+};
+template <> struct BufIO<unsigned char> {
+    static __device__ __forceinline__ float ld(brsrc r, unsigned b, int sb) { return pb_from_ubyte(__builtin_amdgcn_raw_buffer_load_b8(r, (int)b, sb, 0)); }
+    static __device__ __forceinline__ void st(brsrc r, unsigned b, int sb, float v) { __builtin_amdgcn_raw_buffer_store_b8((unsigned char)pb_to_ubyte(v), r, (int)b, sb, 0); }
+};
+
 // inverse 8-point DFT (unnormalised): the forward one with its outputs read in mirrored order
 __device__ __forceinline__ void idft8(cf (&v)[8]) {
     pbfft::dft_small<8>(v);
@@ -274,14 +296,16 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
         const bool inside = wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB;
         if (inside) {
-            // interior pair: uniform plane pointer + 32-bit offsets
-            const unsigned step = 8u * (unsigned)a.in_pitch;
+            // interior pair: plane descriptor + 32-bit offsets
+            const brsrc rin = plane_rsrc(ipl, a.in_plane);
+            const unsigned step = 8u * (unsigned)a.in_pitch * (unsigned)sizeof(TIn);
+            const int tb = T * (int)sizeof(TIn);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const unsigned off = (unsigned)(wy0 - lo + n2) * (unsigned)a.in_pitch + (unsigned)(wxA - lo + l + 32 * t);
+                const unsigned off = ((unsigned)(wy0 - lo + n2) * (unsigned)a.in_pitch + (unsigned)(wxA - lo + l + 32 * t)) * (unsigned)sizeof(TIn);
                 cf v[8];
 #pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) v[n1] = (cf){pb_ld(ipl + (off + n1 * step)), pb_ld(ipl + (off + n1 * step + (unsigned)T))};
+                for (int n1 = 0; n1 < 8; ++n1) v[n1] = (cf){BufIO<TIn>::ld(rin, off + n1 * step, 0), BufIO<TIn>::ld(rin, off + n1 * step, tb)};
                 pbfft::dft_small<8>(v);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) Z[(8 * k + n2) * FT_P + l + 32 * t] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
@@ -386,20 +410,24 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     }
     const float sc = a.scale, cfx = a.coef;
     const bool cl = a.clamp01 != 0;
-    const unsigned xstep = 8u * (unsigned)a.x_pitch, ostep = 8u * (unsigned)a.out_pitch;
+    const brsrc rx = plane_rsrc(xpl, a.x_plane), ro = plane_rsrc(opl, a.out_plane);
+    const unsigned xstep = 8u * (unsigned)a.x_pitch * (unsigned)sizeof(TX), ostep = 8u * (unsigned)a.out_pitch * (unsigned)sizeof(TOut);
+    const int txb = T * (int)sizeof(TX), tob = T * (int)sizeof(TOut);
+    // window row 8 n1 + n2 yields an output when R <= row < 64 - R: the same answer for both n2 of a wave (R is a
+    // multiple of 4, a wave's n2 are 2 wave and 2 wave + 1), i.e. wave-uniform; window column x when R <= x < 64 - R
+    const int n2u = 2 * __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int x = l + 32 * t;
         const bool colok = x >= R && x < FT_N - R;
-        const unsigned xoff = (unsigned)(wy0 + n2 - xo) * (unsigned)a.x_pitch + (unsigned)(wxA + x - xo);
-        const unsigned ooff = (unsigned)(wy0 + n2 - oo) * (unsigned)a.out_pitch + (unsigned)(wxA + x - oo);
+        const unsigned xoff = colok ? ((unsigned)(wy0 + n2 - xo) * (unsigned)a.x_pitch + (unsigned)(wxA + x - xo)) * (unsigned)sizeof(TX) : kNoAccess;
+        const unsigned ooff = colok ? ((unsigned)(wy0 + n2 - oo) * (unsigned)a.out_pitch + (unsigned)(wxA + x - oo)) * (unsigned)sizeof(TOut) : kNoAccess;
         float xa[8], xb[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-            const int i = 8 * n1 + n2;
-            const bool ok = colok && i >= R && i < FT_N - R;
-            xa[n1] = 0.f; xb[n1] = 0.f;
-            if (ok) { xa[n1] = pb_ld(xpl + (xoff + n1 * xstep)); xb[n1] = pb_ld(xpl + (xoff + n1 * xstep + (unsigned)T)); }
+            const bool rowok = 8 * n1 + n2u >= R && 8 * n1 + n2u + 1 < FT_N - R;
+            const unsigned o = rowok ? xoff + n1 * xstep : kNoAccess;
+            xa[n1] = BufIO<TX>::ld(rx, o, 0); xb[n1] = BufIO<TX>::ld(rx, o, txb);
         }
         const float2 *p = Z + n2 * FT_P + x;
         cf v[8];
@@ -408,11 +436,11 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
         idft8(v);
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-            const int i = 8 * n1 + n2;
-            const bool ok = colok && i >= R && i < FT_N - R;
+            const bool rowok = 8 * n1 + n2u >= R && 8 * n1 + n2u + 1 < FT_N - R;
+            const unsigned o = rowok ? ooff + n1 * ostep : kNoAccess;
             float ra = fmaf(sc, v[n1].x, cfx * xa[n1]), rb = fmaf(sc, v[n1].y, cfx * xb[n1]);
             if (cl) { ra = fminf(fmaxf(ra, 0.f), 1.f); rb = fminf(fmaxf(rb, 0.f), 1.f); }
-            if (ok) { pb_st(opl + (ooff + n1 * ostep), ra); pb_st(opl + (ooff + n1 * ostep + (unsigned)T), rb); }
+            BufIO<TOut>::st(ro, o, 0, ra); BufIO<TOut>::st(ro, o, tob, rb);
         }
     }
 }
