@@ -95,6 +95,7 @@ int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases) {
     if (!ctx || (mode != PB_DENSE_STENCIL && mode != PB_DENSE_AUTO) || min_phases < 0 || min_phases > PB_MAX_PHASES + 1)
         return PB_ERR_BADARG;
     ctx->fft_min_phases = mode == PB_DENSE_STENCIL ? -1 : min_phases;
+    pb_forget_records(ctx, nullptr);
     return PB_OK;
 }
 
@@ -156,6 +157,7 @@ int pb_malloc(pb_ctx *ctx, void **dptr, size_t bytes) {
     return PB_OK;
 }
 int pb_free(pb_ctx *ctx, void *dptr) {
+    if (ctx) pb_forget_records(ctx, nullptr);
     if (!ctx) return PB_ERR_BADARG;
     PB_HIP(hipStreamSynchronize(ctx->stream));
     PB_HIP(hipFree(dptr));
@@ -163,6 +165,7 @@ int pb_free(pb_ctx *ctx, void *dptr) {
 }
 int pb_memcpy_h2d(pb_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return PB_ERR_BADARG;
+    pb_forget_records(ctx, nullptr);                      // (the copy may overwrite records the context has cached facts about)
     PB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
     return PB_OK;
@@ -386,6 +389,7 @@ int pb_estimate_blur(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (rc) return rc;
     if (!in || !opt || !dev_info) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
     PB_HIP(hipSetDevice(ctx->device));
+    pb_forget_records(ctx, dev_info);
     return pb_estimate_impl(ctx, in, dtype, B, C, H, W, opt, dev_info);
 }
 
@@ -398,7 +402,8 @@ int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *ho
     for (int i = 0; i < B; ++i) { h[i].sigma = host_sigma[i]; h[i].rho = host_rho[i]; h[i].theta = host_theta_rad[i]; }
     PB_HIP(hipMemcpyAsync(dev_info, h.data(), sizeof(pb_blur_info) * B, hipMemcpyHostToDevice, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
-    return pb_make_kernels_dev(ctx, B, dev_info, support, 0);
+    const int rc = pb_make_kernels_dev(ctx, B, dev_info, support, 0);
+    return rc ? rc : pb_cache_records(ctx, dev_info, B);
 }
 
 int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *dev_sep, int support,
@@ -410,6 +415,7 @@ int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, 
     const int ksize = pb_kernel_size(&o);
     if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", ker_size, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
+    pb_forget_records(ctx, dev_sep);
     return pb_make_sep_records(ctx, B, dev_info, dev_sep, support, ksize);
 }
 
@@ -421,7 +427,8 @@ int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_b
     for (int i = 0; i < B; ++i) memcpy(h[i].kernel, host_taps + (size_t)i * PB_KSIZE * PB_KSIZE, sizeof(float) * PB_KSIZE * PB_KSIZE);
     PB_HIP(hipMemcpyAsync(dev_info, h.data(), sizeof(pb_blur_info) * B, hipMemcpyHostToDevice, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
-    return pb_make_kernels_dev(ctx, B, dev_info, support, 1);
+    const int rc = pb_make_kernels_dev(ctx, B, dev_info, support, 1);
+    return rc ? rc : pb_cache_records(ctx, dev_info, B);
 }
 
 int pb_fourier_gradients(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy) {

@@ -54,6 +54,14 @@ struct pb_ctx {
     // dense (non rank-1) kernels with at least this many live stencil phases are evaluated per tile in the frequency
     // domain (conv_fft.hip) instead of by the stencil body; < 0: never (pb_set_dense_eval, env PB_DENSE_EVAL)
     int fft_min_phases = 36;
+    // What the host knows about record sets it built itself and read back (pb_make_kernels / pb_set_kernels synchronise
+    // anyway): whether any image takes the tile-spectrum body, whether any takes a stencil body -- a reblurring pass then
+    // skips the launch nobody needs -- and whose spectra the context's scratch currently holds.  Records estimated on the
+    // device (the pipeline) are never in here: their passes issue both launches.
+    struct RecFlags { int B; bool any_fft, any_other; };
+    std::map<const void *, RecFlags> rec_cache;
+    const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)
+    const void *khat_buf = nullptr;
 };
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);
@@ -138,6 +146,8 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // conv_fused.hip (experimental build only)
 int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // conv_xt.hip
 int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch);
+int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // conv.hip: after the host (re)built these records
+void pb_forget_records(pb_ctx *ctx, const void *info);                        // nullptr: all
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 
 // ------------------------------------------------------------------------------------

@@ -319,23 +319,52 @@ int launch_typed(pb_ctx *ctx, const ConvPass &p) {
 static int launch_stencil(pb_ctx *ctx, const ConvPass &p);
 
 // Dense kernels above the context's phase threshold take the tile-spectrum body: a second launch of the same step, in
-// which -- as in the first -- every image's tiles exit at once unless the image's record selects that body.
+// which -- as in the first -- every image's tiles exit at once unless the image's record selects that body.  For record
+// sets the host built and read back itself (rec_cache) the launch no image needs is not issued at all.
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     ConvPass p = p0;
     // (the tile-spectrum body addresses planes with 32-bit byte offsets)
     const long plane_max = (1L << 31) - 4096;
-    const bool fft = ctx->fft_min_phases >= 0 && !p.skip_general && p.in_plane * 4 < plane_max && p.x_plane * 4 < plane_max &&
-                     p.out_plane * 4 < plane_max;
-    if (!fft) { p.fsel = nullptr; p.khat = nullptr; }
-    else {
+    bool fft = ctx->fft_min_phases >= 0 && !p.skip_general && p.in_plane * 4 < plane_max && p.x_plane * 4 < plane_max &&
+               p.out_plane * 4 < plane_max;
+    const int B = p.P / p.C;
+    const auto known = ctx->rec_cache.find(p.info);
+    const bool have = known != ctx->rec_cache.end() && known->second.B == B;
+    if (fft && have && !known->second.any_fft) fft = false;
+    p.fsel = nullptr; p.khat = nullptr;
+    if (fft) {
         float *k = nullptr; pb_fft_sel *s = nullptr;
-        const int rc = pb_build_khat(ctx, p.info, p.P / p.C, &k, &s, !p.khat_ready);
+        const bool built = p.khat_ready || (have && ctx->khat_owner == p.info);
+        const int rc = pb_build_khat(ctx, p.info, B, &k, &s, !built);
         if (rc) return rc;
         p.khat = k; p.fsel = s;
     }
-    int rc = launch_stencil(ctx, p);
-    if (rc || !fft) return rc;
-    return pb_launch_conv_fft(ctx, p);
+    if (!(fft && have && !known->second.any_other)) {
+        const int rc = launch_stencil(ctx, p);
+        if (rc) return rc;
+    }
+    return fft ? pb_launch_conv_fft(ctx, p) : PB_OK;
+}
+
+// The host has just (re)built these B records and is synchronising anyway: build their spectra, read the per-image choice
+// back and remember it.
+int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B) {
+    ctx->rec_cache.erase(info);
+    if (ctx->fft_min_phases < 0) return PB_OK;
+    float *k = nullptr; pb_fft_sel *s = nullptr;
+    int rc = pb_build_khat(ctx, info, B, &k, &s, true);
+    if (rc) return rc;
+    std::vector<pb_fft_sel> h(B);
+    PB_HIP(hipMemcpyAsync(h.data(), s, sizeof(pb_fft_sel) * B, hipMemcpyDeviceToHost, ctx->stream));
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    pb_ctx::RecFlags f{B, false, false};
+    for (const pb_fft_sel &e : h) { if (e.use_fft) f.any_fft = true; else f.any_other = true; }
+    ctx->rec_cache[info] = f;
+    return PB_OK;
+}
+void pb_forget_records(pb_ctx *ctx, const void *info) {
+    if (info) ctx->rec_cache.erase(info); else ctx->rec_cache.clear();
+    if (!info || ctx->khat_owner == info) ctx->khat_owner = nullptr;
 }
 
 static int launch_stencil(pb_ctx *ctx, const ConvPass &p) {

@@ -121,11 +121,11 @@ __device__ __forceinline__ void idft8(cf (&v)[8]) {
 // the spectrum of a point-symmetric real kernel -- every Gaussian the estimator builds is one, bit for bit
 // (k[12+u][12+v] == k[12-u][12-v]) -- is real, so correlation and convolution coincide and a thread's 16 spectrum
 // values fit 16 registers.  Laid out in the transforms' permuted order, both transforms' normalisation folded in.  Only
-// the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double (the spectrum
-// is then the correctly rounded fp32 one).  Caller-supplied taps that are not point-symmetric keep the stencil body.
+// the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double from the
+// fp32 cosine table the transforms use (the spectrum is good to a few 1e-8 of its peak).  Caller-supplied taps that are not point-symmetric keep the stencil body.
 constexpr int KH_SLICES = 8;          // workgroups per image: each evaluates 512 of the 4096 values of the second sum
 __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases) {
-    __shared__ double2 G[PB_KSIZE * FT_N];
+    __shared__ double2 G[(PB_KRAD + 1) * FT_N];
     __shared__ double cs[FT_N], sn[FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
     const pb_blur_info *info = infos + blockIdx.x;
@@ -143,11 +143,15 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
     const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases && min_phases >= 0;
     if (tid == 0 && blockIdx.y == 0) { sel[blockIdx.x].use_fft = use ? 1 : 0; sel[blockIdx.x].rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
     if (!use) return;
-    if (tid < FT_N) { double s, c; sincospi((double)tid / 32.0, &s, &c); cs[tid] = c; sn[tid] = s; }
+    if (tid < FT_N) { cs[tid] = (double)kW64[tid].x; sn[tid] = -(double)kW64[tid].y; }       // fp32 table values, exact in double
     __syncthreads();
-    for (int idx = tid; idx < PB_KSIZE * FT_N; idx += FT_NT) {
-        const int u = idx >> 6, px = idx & 63, fx = (px >> 3) + 8 * (px & 7);
+    // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
+    // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u})
+    constexpr int NR = PB_KRAD + 1;
+    for (int idx = tid; idx < NR * FT_N; idx += FT_NT) {
+        const int u = (idx >> 6) + PB_KRAD, px = idx & 63, fx = (px >> 3) + 8 * (px & 7);
         double ar = 0.0, ai = 0.0;
+#pragma unroll 5
         for (int v = 0; v < PB_KSIZE; ++v) {
             const int m = (fx * (v - PB_KRAD)) & 63;
             const double k = (double)sk[u * PB_KSIZE + v];
@@ -159,13 +163,14 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
     float *out = khat + (long)blockIdx.x * (FT_N * FT_N);
     for (int idx = blockIdx.y * (FT_N * FT_N / KH_SLICES) + tid; idx < (blockIdx.y + 1) * (FT_N * FT_N / KH_SLICES); idx += FT_NT) {
         const int py = idx >> 6, px = idx & 63, fy = (py >> 3) + 8 * (py & 7);
-        double ar = 0.0;
-        for (int u = 0; u < PB_KSIZE; ++u) {
-            const int m = (fy * (u - PB_KRAD)) & 63;
+        double ar = 0.5 * G[px].x;
+#pragma unroll 4
+        for (int u = 1; u < NR; ++u) {
+            const int m = (fy * u) & 63;
             const double2 g = G[u * FT_N + px];
             ar += g.x * cs[m] - g.y * sn[m];
         }
-        out[idx] = (float)(ar * (1.0 / 4096.0));
+        out[idx] = (float)(ar * (2.0 / 4096.0));
     }
 }
 
@@ -499,7 +504,9 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
     float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat", sizeof(float) * FT_N * FT_N * (size_t)B));
     pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel", sizeof(pb_fft_sel) * (size_t)B));
     if (!k || !s) return PB_ERR_NOMEM;
+    if (k != ctx->khat_buf) { ctx->khat_buf = k; ctx->khat_owner = nullptr; launch = true; }     // (the scratch buffer was reallocated)
     if (launch) {
+        ctx->khat_owner = info;
         ProfScope prof(ctx, PB_PROF_PARAMS);
         hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(FT_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases);
         PB_LAUNCH_CHECK();
