@@ -105,6 +105,30 @@ template <> struct BufIO<unsigned char> {
     static __device__ __forceinline__ void st(brsrc r, unsigned b, int sb, float v) { __builtin_amdgcn_raw_buffer_store_b8((unsigned char)pb_to_ubyte(v), r, (int)b, sb, 0); }
 };
 
+// Eight complex values SB bytes apart from the LDS tile as eight ds_read_b64 (256 bytes per clock).  Left to the compiler
+// neighbouring reads are paired into ds_read2_b64, which moves 128 bytes per clock (MI355X_MICROARCH.md, LDS table).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char *)p;
+}
+#pragma clang diagnostic pop
+template <int SB> __device__ __forceinline__ void lds_read8(cf (&v)[8], const float2 *p) {
+    const unsigned a = lds_addr(p);
+    asm volatile("ds_read_b64 %0, %8\n\t"
+                 "ds_read_b64 %1, %8 offset:%9\n\t"
+                 "ds_read_b64 %2, %8 offset:%10\n\t"
+                 "ds_read_b64 %3, %8 offset:%11\n\t"
+                 "ds_read_b64 %4, %8 offset:%12\n\t"
+                 "ds_read_b64 %5, %8 offset:%13\n\t"
+                 "ds_read_b64 %6, %8 offset:%14\n\t"
+                 "ds_read_b64 %7, %8 offset:%15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(a), "n"(SB), "n"(2 * SB), "n"(3 * SB), "n"(4 * SB), "n"(5 * SB), "n"(6 * SB), "n"(7 * SB)
+                 : "memory");
+}
+
 // inverse 8-point DFT (unnormalised): the forward one with its outputs read in mirrored order
 __device__ __forceinline__ void idft8(cf (&v)[8]) {
     pbfft::dft_small<8>(v);
@@ -327,8 +351,7 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (8 * (2 * wave + t)) * FT_P + lane;
         cf v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = pbfft::to_cf(p[j * FT_P]);
+        lds_read8<FT_P * 8>(v, p);
         pbfft::dft_small<8>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[j * FT_P] = pbfft::to_f2(v[j]);
@@ -342,8 +365,7 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (l + 32 * t) * FT_P + n2;
         cf v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = pbfft::to_cf(p[8 * j]);
+        lds_read8<64>(v, p);
         pbfft::dft_small<8>(v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) p[8 * k] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
@@ -357,8 +379,7 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + ((lane & 7) + 8 * wave + 32 * t) * FT_P + 8 * (lane >> 3);
         cf v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = pbfft::to_cf(p[j]);
+        lds_read8<8>(v, p);
         pbfft::dft_small<8>(v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[2 * j] = scale_lo(v[2 * j], kh[t][j]); v[2 * j + 1] = scale_hi(v[2 * j + 1], kh[t][j]); }
@@ -375,8 +396,9 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (l + 32 * t) * FT_P + n2;
         cf v[8];
+        lds_read8<64>(v, p);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { v[k] = pbfft::to_cf(p[8 * k]); if (k) v[k] = cmul_conj(v[k], tw[k]); }
+        for (int k = 1; k < 8; ++k) v[k] = cmul_conj(v[k], tw[k]);
         idft8(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[8 * j] = pbfft::to_f2(v[j]);
@@ -390,8 +412,7 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     for (int t = 0; t < 2; ++t) {
         float2 *p = Z + (8 * (2 * wave + t)) * FT_P + lane;
         cf v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = pbfft::to_cf(p[j * FT_P]);
+        lds_read8<FT_P * 8>(v, p);
         idft8(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[j * FT_P] = pbfft::to_f2(v[j]);
@@ -436,8 +457,9 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
         }
         const float2 *p = Z + n2 * FT_P + x;
         cf v[8];
+        lds_read8<8 * FT_P * 8>(v, p);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { v[k] = pbfft::to_cf(p[8 * k * FT_P]); if (k) v[k] = cmul_conj(v[k], tw[k]); }
+        for (int k = 1; k < 8; ++k) v[k] = cmul_conj(v[k], tw[k]);
         idft8(v);
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
