@@ -17,11 +17,12 @@
 //   the same permuted order by khat_kernel.
 // * Stage order: columns (stage 1 straight from global memory, stage 2), rows (stage 1, stage 2 x spectrum x inverse
 //   stage 2 in registers), rows^-1 stage 1, columns^-1 (stage 2, stage 1 straight into the epilogue and global memory).
-//   Six LDS round trips per window pair.  The first and last stages touch global memory with 32 consecutive window
-//   columns per half wave (128-byte segments).
+//   Six LDS round trips per window pair.  The first and last stages touch global memory with 64 consecutive window
+//   columns per wave (256-byte segments).
 // * LDS rows are 65 complex values long: every row-direction access (stride 8 or contiguous 8 per lane) and every
 //   column-direction access is bank-conflict-free for ds_read_b64 / ds_write_b64.
-// * Each thread keeps ONE set of seven inter-stage twiddles W64^(n2 k) for the whole kernel (its n2 = 2 wave + half).
+// * 512 threads per window pair, one radix-8 butterfly per thread and stage; a wave's eight threads-of-a-line share n2
+//   (= the wave number), so the seven inter-stage twiddles W64^(n2 k) are wave-uniform and live in scalar registers.
 // * Workgroups are persistent (four per CU) and walk the window pairs of their XCD: the 16 spectrum values a thread
 //   multiplies are the same for every window of an image and stay in registers, so the 32 KB spectrum is read once per
 //   workgroup and image, not once per window.
@@ -40,7 +41,8 @@ using pbfft::cf;
 
 constexpr int FT_N = 64;          // window side
 constexpr int FT_P = 65;          // LDS row pitch in complex values
-constexpr int FT_NT = 256;
+constexpr int FT_NT = 512;         // one radix-8 butterfly per thread and stage
+constexpr int KH_NT = 256;
 constexpr size_t kFftLds = sizeof(float2) * FT_N * FT_P;
 
 // W64^m = exp(-2 pi i m / 64)
@@ -69,6 +71,20 @@ __device__ __forceinline__ cf cmul_conj(cf a, cf w) {
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                      // (a.x w.x, a.x w.y)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;                                                                                                    // (.. + a.y w.y, a.y w.x - ..)
+}
+
+// a * w and a * conj(w) for a wave-uniform w held in a scalar register pair
+__device__ __forceinline__ cf cmul_s(cf a, cf w) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ cf cmul_conj_s(cf a, cf w) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
 }
 
 // a * h.x  and  a * h.y  for real h (two spectrum values share a register pair)
@@ -148,7 +164,7 @@ __device__ __forceinline__ void idft8(cf (&v)[8]) {
 // the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double from the
 // fp32 cosine table the transforms use (the spectrum is good to a few 1e-8 of its peak).  Caller-supplied taps that are not point-symmetric keep the stencil body.
 constexpr int KH_SLICES = 8;          // workgroups per image: each evaluates 512 of the 4096 values of the second sum
-__global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases) {
+__global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases) {
     __shared__ double2 G[(PB_KRAD + 1) * FT_N];
     __shared__ double cs[FT_N], sn[FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
     const int nph = info->nphase[0] + info->nphase[1] + info->nphase[2];
     const int R = info->radius;
     bool sym = true;
-    for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += FT_NT) {
+    for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_NT) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
         const bool in = abs(u) <= R && abs(v) <= R;
         const float k = info->kernel[i];
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
     // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u})
     constexpr int NR = PB_KRAD + 1;
-    for (int idx = tid; idx < NR * FT_N; idx += FT_NT) {
+    for (int idx = tid; idx < NR * FT_N; idx += KH_NT) {
         const int u = (idx >> 6) + PB_KRAD, px = idx & 63, fx = (px >> 3) + 8 * (px & 7);
         double ar = 0.0, ai = 0.0;
 #pragma unroll 5
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
     }
     __syncthreads();
     float *out = khat + (long)blockIdx.x * (FT_N * FT_N);
-    for (int idx = blockIdx.y * (FT_N * FT_N / KH_SLICES) + tid; idx < (blockIdx.y + 1) * (FT_N * FT_N / KH_SLICES); idx += FT_NT) {
+    for (int idx = blockIdx.y * (FT_N * FT_N / KH_SLICES) + tid; idx < (blockIdx.y + 1) * (FT_N * FT_N / KH_SLICES); idx += KH_NT) {
         const int py = idx >> 6, px = idx & 63, fy = (py >> 3) + 8 * (py & 7);
         double ar = 0.5 * G[px].x;
 #pragma unroll 4
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(FT_NT) void khat_kernel(const pb_blur_info *infos, 
             const double2 g = G[u * FT_N + px];
             ar += g.x * cs[m] - g.y * sn[m];
         }
-        out[idx] = (float)(ar * (2.0 / 4096.0));
+        out[px * FT_N + py] = (float)(ar * (2.0 / 4096.0));          // stored transposed: [x position][y position]
     }
 }
 
@@ -241,86 +257,86 @@ struct FftGeom {
 };
 __device__ __forceinline__ int div_small(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }   // n < 2^22, exact
 
+// Thread mapping (512 threads, wave w = 0..7, lane = 0..63).  Every 1-D pass of 64 points is two radix-8 stages over the
+// index split  n = 8 n1 + n2 -> k = k1 + 8 k2  (position 8 k1 + k2 of a transformed axis holds frequency k1 + 8 k2):
+//   stage 1:  the thread of (line = lane, n2 = w) takes elements 8 n1 + n2 of its line, transforms over n1 and multiplies
+//             by the inter-stage twiddles W64^(n2 k1) -- wave-uniform, so they sit in scalar registers;
+//   stage 2:  the thread of (line = lane, k1 = w) takes elements 8 k1 .. 8 k1 + 7 and transforms over n2.
+// In the column passes `line` is the window column (64 consecutive columns per wave: 256-byte global segments in the first
+// and last stage, consecutive LDS addresses in between), in the row passes the window row (row pitch 65: rows 0..31 of a
+// half wave fall into 32 different 8-byte bank slots).
+struct Twiddles { cf w[8]; };
+__device__ __forceinline__ Twiddles load_twiddles(int n2u) {
+    Twiddles t;
+    const PB_CONSTANT float *tab = as_constant(reinterpret_cast<const float *>(kW64));       // scalar loads: n2u is uniform
+    t.w[0] = (cf){1.f, 0.f};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const int m = (n2u * k) & 63; t.w[k] = (cf){tab[2 * m], tab[2 * m + 1]}; }
+    return t;
+}
+
 // Border windows: rows and columns are mapped through the boundary model once per window row / column of the thread
-// (12 maps for its 32 samples), then the samples are fetched one by one.
+// (10 maps for its 16 samples), then the samples are fetched one by one.
 template <typename TIn>
 __device__ __forceinline__ void stage1_mapped(const ConvPass &a, const TIn *ipl, int wy0, int wxA, int wxB, bool hasB, float2 *Z,
-                                              const cf (&tw)[8], int n2, int l) {
-    int iy[8];
+                                              const Twiddles &tw, int n2, int x) {
+    const int ixa = map_axis(wxA + x, a.W, a.in_kind, a.boundary, a.pad);
+    const int ixb = hasB ? map_axis(wxB + x, a.W, a.in_kind, a.boundary, a.pad) : -1;
+    cf v[8];
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) iy[n1] = map_axis(wy0 + 8 * n1 + n2, a.H, a.in_kind, a.boundary, a.pad);
-#pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-        const int x = l + 32 * t;
-        const int ixa = map_axis(wxA + x, a.W, a.in_kind, a.boundary, a.pad);
-        const int ixb = hasB ? map_axis(wxB + x, a.W, a.in_kind, a.boundary, a.pad) : -1;
-        cf v[8];
-#pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const TIn *row = ipl + (long)max(iy[n1], 0) * a.in_pitch;
-            v[n1] = (cf){(iy[n1] | ixa) >= 0 ? pb_ld(row + ixa) : 0.f, (iy[n1] | ixb) >= 0 ? pb_ld(row + ixb) : 0.f};
-        }
-        pbfft::dft_small<8>(v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) Z[(8 * k + n2) * FT_P + x] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int iy = map_axis(wy0 + 8 * n1 + n2, a.H, a.in_kind, a.boundary, a.pad);
+        const TIn *row = ipl + (long)max(iy, 0) * a.in_pitch;
+        v[n1] = (cf){(iy | ixa) >= 0 ? pb_ld(row + ixa) : 0.f, (iy | ixb) >= 0 ? pb_ld(row + ixb) : 0.f};
     }
+    pbfft::dft_small<8>(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Z[(8 * k + n2) * FT_P + x] = pbfft::to_f2(k ? cmul_s(v[k], tw.w[k]) : v[0]);
 }
 // Border / taper epilogues, one output at a time.
 template <typename TX, typename TOut>
 __device__ __forceinline__ void epilogue_mapped(const ConvPass &a, const pb_blur_info *info, const TX *xpl, TOut *opl, int wy0,
-                                                int wxA, int R, bool hasB, const float2 *Z, const cf (&tw)[8], int n2, int l) {
+                                                int wxA, int R, bool hasB, const float2 *Z, const Twiddles &tw, int n2, int x) {
     const OutRegion rg = out_region(a);
     const int wxB = wxA + FT_N - 2 * R;
-#pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-        const int x = l + 32 * t;
-        const bool colA = x >= R && x < FT_N - R && wxA + x < rg.x_hi;
-        const bool colB = colA && hasB && wxB + x < rg.x_hi;
-        const float2 *p = Z + n2 * FT_P + x;
-        cf v[8];
+    const bool colA = x >= R && x < FT_N - R && wxA + x < rg.x_hi;
+    const bool colB = colA && hasB && wxB + x < rg.x_hi;
+    cf v[8];
+    lds_read8<8 * FT_P * 8>(v, Z + n2 * FT_P + x);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { v[k] = pbfft::to_cf(p[8 * k * FT_P]); if (k) v[k] = cmul_conj(v[k], tw[k]); }
-        idft8(v);
+    for (int k = 1; k < 8; ++k) v[k] = cmul_conj_s(v[k], tw.w[k]);
+    idft8(v);
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const int i = 8 * n1 + n2, py = wy0 + i;
-            const bool rowok = i >= R && i < FT_N - R && py < rg.y_hi;
-            if (rowok && colA) finish1<TOut>(a, info, opl, py, wxA + x, v[n1].x, load_x1<TX>(a, xpl, py, wxA + x));
-            if (rowok && colB) finish1<TOut>(a, info, opl, py, wxB + x, v[n1].y, load_x1<TX>(a, xpl, py, wxB + x));
-        }
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int i = 8 * n1 + n2, py = wy0 + i;
+        const bool rowok = i >= R && i < FT_N - R && py < rg.y_hi;
+        if (rowok && colA) finish1<TOut>(a, info, opl, py, wxA + x, v[n1].x, load_x1<TX>(a, xpl, py, wxA + x));
+        if (rowok && colB) finish1<TOut>(a, info, opl, py, wxB + x, v[n1].y, load_x1<TX>(a, xpl, py, wxB + x));
     }
 }
 
-// One window pair.  Z: the workgroup's LDS tile; tw: the thread's inter-stage twiddles; kp: the image's spectrum.
+// One window pair.  Z: the workgroup's LDS tile; kp: the image's spectrum, [x position][y position].
 template <typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, int R, float2 *Z,
-                                            const cf (&tw)[8], const float *kp) {
+                                            const float *kp) {
     const int T = FT_N - 2 * R;
     const OutRegion rg = out_region(a);
-    const int wy0_ = rg.y_lo + ty * T - R;                      // window origin, padded coordinates
-    const int wxA_ = rg.x_lo + 2 * pxi * T - R;
-    const bool hasB = wxA_ + T + R < rg.x_hi;
+    const int wy0 = rg.y_lo + ty * T - R;                       // window origin, padded coordinates
+    const int wxA = rg.x_lo + 2 * pxi * T - R, wxB = wxA + T;
+    const bool hasB = wxB + R < rg.x_hi;
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
-    const int tid0 = threadIdx.x;
-#define PB_STAGE_IDS const int tid = tid0, wave = tid >> 6, lane = tid & 63, l = lane & 31, n2 = 2 * wave + (lane >> 5); (void)l; (void)n2;
-
-    // the 16 spectrum values this thread multiplies in the centre stage: row (lane & 7) + 8 wave + 32 t, columns 8 (lane >> 3) ..
-    cf kh[2][4];
-    {
-        PB_STAGE_IDS
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // n2 in the stage-1 passes, k1 in the stage-2 passes
+    const Twiddles tw = load_twiddles(w);
+    // the 8 spectrum values this thread multiplies in the centre stage: window row `lane`, columns 8 w .. 8 w + 7
+    float kh[8];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float4 *hp = reinterpret_cast<const float4 *>(kp + ((lane & 7) + 8 * wave + 32 * t) * FT_N + 8 * (lane >> 3));
-            const float4 h0 = hp[0], h1 = hp[1];
-            kh[t][0] = (cf){h0.x, h0.y}; kh[t][1] = (cf){h0.z, h0.w}; kh[t][2] = (cf){h1.x, h1.y}; kh[t][3] = (cf){h1.z, h1.w};
-        }
-    }
-    // ---- columns, stage 1, straight from global memory: window rows 8 n1 + n2 of columns l, l + 32 ----
+    for (int j = 0; j < 8; ++j) kh[j] = kp[(8 * w + j) * FT_N + lane];
+
+    // ---- columns, stage 1, straight from global memory: window rows 8 n1 + w of column `lane` ----
     {
-        PB_STAGE_IDS
-        const int wy0 = wy0_, wxA = wxA_, wxB = wxA_ + T;
         const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
         const bool inside = wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB;
@@ -329,109 +345,83 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
             const brsrc rin = plane_rsrc(ipl, a.in_plane);
             const unsigned step = 8u * (unsigned)a.in_pitch * (unsigned)sizeof(TIn);
             const int tb = T * (int)sizeof(TIn);
+            const unsigned off = ((unsigned)(wy0 - lo + w) * (unsigned)a.in_pitch + (unsigned)(wxA - lo + lane)) * (unsigned)sizeof(TIn);
+            cf v[8];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const unsigned off = ((unsigned)(wy0 - lo + n2) * (unsigned)a.in_pitch + (unsigned)(wxA - lo + l + 32 * t)) * (unsigned)sizeof(TIn);
-                cf v[8];
+            for (int n1 = 0; n1 < 8; ++n1) v[n1] = (cf){BufIO<TIn>::ld(rin, off + n1 * step, 0), BufIO<TIn>::ld(rin, off + n1 * step, tb)};
+            pbfft::dft_small<8>(v);
 #pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) v[n1] = (cf){BufIO<TIn>::ld(rin, off + n1 * step, 0), BufIO<TIn>::ld(rin, off + n1 * step, tb)};
-                pbfft::dft_small<8>(v);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) Z[(8 * k + n2) * FT_P + l + 32 * t] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
-            }
+            for (int k = 0; k < 8; ++k) Z[(8 * k + w) * FT_P + lane] = pbfft::to_f2(k ? cmul_s(v[k], tw.w[k]) : v[0]);
         } else {
-            stage1_mapped<TIn>(a, ipl, wy0, wxA, wxB, hasB, Z, tw, n2, l);
+            stage1_mapped<TIn>(a, ipl, wy0, wxA, wxB, hasB, Z, tw, w, lane);
         }
     }
     __syncthreads();
-    // ---- columns, stage 2: rows 8 k1 .. 8 k1 + 7 of column `lane` ----
+    // ---- columns, stage 2: rows 8 w .. 8 w + 7 of column `lane` ----
     {
-    PB_STAGE_IDS
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float2 *p = Z + (8 * (2 * wave + t)) * FT_P + lane;
+        float2 *p = Z + (8 * w) * FT_P + lane;
         cf v[8];
         lds_read8<FT_P * 8>(v, p);
         pbfft::dft_small<8>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[j * FT_P] = pbfft::to_f2(v[j]);
     }
-    }
     __syncthreads();
-    // ---- rows, stage 1: columns 8 n1 + n2 of rows l, l + 32 ----
+    // ---- rows, stage 1: columns 8 n1 + w of row `lane` ----
     {
-    PB_STAGE_IDS
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float2 *p = Z + (l + 32 * t) * FT_P + n2;
+        float2 *p = Z + lane * FT_P + w;
         cf v[8];
         lds_read8<64>(v, p);
         pbfft::dft_small<8>(v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[8 * k] = pbfft::to_f2(k ? pbfft::cmul(v[k], tw[k]) : v[0]);
-    }
+        for (int k = 0; k < 8; ++k) p[8 * k] = pbfft::to_f2(k ? cmul_s(v[k], tw.w[k]) : v[0]);
     }
     __syncthreads();
-    // ---- rows, stage 2 -> x spectrum -> inverse stage 2: columns 8 k1 .. 8 k1 + 7 of one row ----
+    // ---- rows, stage 2 -> x spectrum -> inverse stage 2: columns 8 w .. 8 w + 7 of row `lane` ----
     {
-    PB_STAGE_IDS
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float2 *p = Z + ((lane & 7) + 8 * wave + 32 * t) * FT_P + 8 * (lane >> 3);
+        float2 *p = Z + lane * FT_P + 8 * w;
         cf v[8];
         lds_read8<8>(v, p);
         pbfft::dft_small<8>(v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[2 * j] = scale_lo(v[2 * j], kh[t][j]); v[2 * j + 1] = scale_hi(v[2 * j + 1], kh[t][j]); }
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * kh[j];
         idft8(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[j] = pbfft::to_f2(v[j]);
     }
-    }
     __syncthreads();
     // ---- rows, inverse stage 1 ----
     {
-    PB_STAGE_IDS
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float2 *p = Z + (l + 32 * t) * FT_P + n2;
+        float2 *p = Z + lane * FT_P + w;
         cf v[8];
         lds_read8<64>(v, p);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul_conj(v[k], tw[k]);
+        for (int k = 1; k < 8; ++k) v[k] = cmul_conj_s(v[k], tw.w[k]);
         idft8(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[8 * j] = pbfft::to_f2(v[j]);
     }
-    }
     __syncthreads();
     // ---- columns, inverse stage 2 ----
     {
-    PB_STAGE_IDS
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float2 *p = Z + (8 * (2 * wave + t)) * FT_P + lane;
+        float2 *p = Z + (8 * w) * FT_P + lane;
         cf v[8];
         lds_read8<FT_P * 8>(v, p);
         idft8(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[j * FT_P] = pbfft::to_f2(v[j]);
     }
-    }
     __syncthreads();
-    // ---- columns, inverse stage 1, into the epilogue: window rows 8 n1 + n2 of columns l, l + 32 ----
+    // ---- columns, inverse stage 1, into the epilogue: window rows 8 n1 + w of column `lane` ----
     // Fast form: both tiles complete, inside the output region, their x operand addressed without clamping, plain Horner
-    // epilogue -- uniform plane pointers + 32-bit offsets.
-    PB_STAGE_IDS
-#undef PB_STAGE_IDS
+    // epilogue -- plane descriptors + 32-bit offsets; the halo rows (wave-uniform) and columns get an out-of-range offset.
     const int xo = a.x_kind == SRC_VIRTUAL ? a.pad : 0, oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
-    const int wy0 = wy0_, wxA = wxA_;
     const int oy0 = wy0 + R, oxA = wxA + R;
     const bool fast = a.epilogue == EPI_HORNER && hasB && oy0 + T <= rg.y_hi && oxA + 2 * T <= rg.x_hi && oy0 - xo >= 0 &&
                       oxA - xo >= 0 && oy0 + T - xo <= (a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * a.pad) &&
                       oxA + 2 * T - xo <= (a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * a.pad);
     if (!fast) {
-        epilogue_mapped<TX, TOut>(a, info, xpl, opl, wy0, wxA, R, hasB, Z, tw, n2, l);
+        epilogue_mapped<TX, TOut>(a, info, xpl, opl, wy0, wxA, R, hasB, Z, tw, w, lane);
         return;
     }
     const float sc = a.scale, cfx = a.coef;
@@ -439,36 +429,28 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     const brsrc rx = plane_rsrc(xpl, a.x_plane), ro = plane_rsrc(opl, a.out_plane);
     const unsigned xstep = 8u * (unsigned)a.x_pitch * (unsigned)sizeof(TX), ostep = 8u * (unsigned)a.out_pitch * (unsigned)sizeof(TOut);
     const int txb = T * (int)sizeof(TX), tob = T * (int)sizeof(TOut);
-    // window row 8 n1 + n2 yields an output when R <= row < 64 - R: the same answer for both n2 of a wave (R is a
-    // multiple of 4, a wave's n2 are 2 wave and 2 wave + 1), i.e. wave-uniform; window column x when R <= x < 64 - R
-    const int n2u = 2 * __builtin_amdgcn_readfirstlane(wave);
+    const bool colok = lane >= R && lane < FT_N - R;
+    const unsigned xoff = colok ? ((unsigned)(wy0 + w - xo) * (unsigned)a.x_pitch + (unsigned)(wxA + lane - xo)) * (unsigned)sizeof(TX) : kNoAccess;
+    const unsigned ooff = colok ? ((unsigned)(wy0 + w - oo) * (unsigned)a.out_pitch + (unsigned)(wxA + lane - oo)) * (unsigned)sizeof(TOut) : kNoAccess;
+    float xa[8], xb[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int x = l + 32 * t;
-        const bool colok = x >= R && x < FT_N - R;
-        const unsigned xoff = colok ? ((unsigned)(wy0 + n2 - xo) * (unsigned)a.x_pitch + (unsigned)(wxA + x - xo)) * (unsigned)sizeof(TX) : kNoAccess;
-        const unsigned ooff = colok ? ((unsigned)(wy0 + n2 - oo) * (unsigned)a.out_pitch + (unsigned)(wxA + x - oo)) * (unsigned)sizeof(TOut) : kNoAccess;
-        float xa[8], xb[8];
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const bool rowok = 8 * n1 + w >= R && 8 * n1 + w < FT_N - R;
+        const unsigned o = rowok ? xoff + n1 * xstep : kNoAccess;
+        xa[n1] = BufIO<TX>::ld(rx, o, 0); xb[n1] = BufIO<TX>::ld(rx, o, txb);
+    }
+    cf v[8];
+    lds_read8<8 * FT_P * 8>(v, Z + w * FT_P + lane);
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const bool rowok = 8 * n1 + n2u >= R && 8 * n1 + n2u + 1 < FT_N - R;
-            const unsigned o = rowok ? xoff + n1 * xstep : kNoAccess;
-            xa[n1] = BufIO<TX>::ld(rx, o, 0); xb[n1] = BufIO<TX>::ld(rx, o, txb);
-        }
-        const float2 *p = Z + n2 * FT_P + x;
-        cf v[8];
-        lds_read8<8 * FT_P * 8>(v, p);
+    for (int k = 1; k < 8; ++k) v[k] = cmul_conj_s(v[k], tw.w[k]);
+    idft8(v);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul_conj(v[k], tw[k]);
-        idft8(v);
-#pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const bool rowok = 8 * n1 + n2u >= R && 8 * n1 + n2u + 1 < FT_N - R;
-            const unsigned o = rowok ? ooff + n1 * ostep : kNoAccess;
-            float ra = fmaf(sc, v[n1].x, cfx * xa[n1]), rb = fmaf(sc, v[n1].y, cfx * xb[n1]);
-            if (cl) { ra = fminf(fmaxf(ra, 0.f), 1.f); rb = fminf(fmaxf(rb, 0.f), 1.f); }
-            BufIO<TOut>::st(ro, o, 0, ra); BufIO<TOut>::st(ro, o, tob, rb);
-        }
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const bool rowok = 8 * n1 + w >= R && 8 * n1 + w < FT_N - R;
+        const unsigned o = rowok ? ooff + n1 * ostep : kNoAccess;
+        float ra = fmaf(sc, v[n1].x, cfx * xa[n1]), rb = fmaf(sc, v[n1].y, cfx * xb[n1]);
+        if (cl) { ra = fminf(fmaxf(ra, 0.f), 1.f); rb = fminf(fmaxf(rb, 0.f), 1.f); }
+        BufIO<TOut>::st(ro, o, 0, ra); BufIO<TOut>::st(ro, o, tob, rb);
     }
 }
 
@@ -488,13 +470,7 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, co
     const int local = xcd * g.per[c] + i;
     if (i >= g.per[c] || local >= g.njobs[c]) return;
     const int ty = __builtin_amdgcn_readfirstlane(div_small(local, g.inv_pairs_x[c])), pxi = local - ty * g.pairs_x[c];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n2 = 2 * wave + (lane >> 5);
-    cf tw[8];
-    tw[0] = (cf){1.f, 0.f};
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { const float2 w = kW64[(n2 * k) & 63]; tw[k] = (cf){w.x, w.y}; }
-    window_pair<TIn, TX, TOut>(a, a.info + img, plane, ty, pxi, R, Z, tw, a.khat + (long)img * (FT_N * FT_N));
+    window_pair<TIn, TX, TOut>(a, a.info + img, plane, ty, pxi, R, Z, a.khat + (long)img * (FT_N * FT_N));
 }
 
 template <typename TIn, typename TX, typename TOut>
@@ -530,7 +506,7 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
     if (launch) {
         ctx->khat_owner = info;
         ProfScope prof(ctx, PB_PROF_PARAMS);
-        hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(FT_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases);
+        hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases);
         PB_LAUNCH_CHECK();
     }
     *khat = k; *sel = s;
