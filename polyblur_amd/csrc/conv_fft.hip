@@ -334,6 +334,28 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     float kh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) kh[j] = kp[(8 * w + j) * FT_N + lane];
+    // Fast epilogue: both tiles complete, inside the output region, their x operand addressed without clamping, plain Horner
+    // epilogue -- plane descriptors + 32-bit offsets; the halo rows (wave-uniform) and columns get an out-of-range offset.
+    // Its x operand is requested here, at the very start: it arrives while the transforms run.
+    const int xo = a.x_kind == SRC_VIRTUAL ? a.pad : 0, oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
+    const int oy0 = wy0 + R, oxA = wxA + R;
+    const bool fast = a.epilogue == EPI_HORNER && hasB && oy0 + T <= rg.y_hi && oxA + 2 * T <= rg.x_hi && oy0 - xo >= 0 &&
+                      oxA - xo >= 0 && oy0 + T - xo <= (a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * a.pad) &&
+                      oxA + 2 * T - xo <= (a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * a.pad);
+    const bool colok = lane >= R && lane < FT_N - R;
+    float xa[8], xb[8];
+    if (fast) {
+        const brsrc rx = plane_rsrc(xpl, a.x_plane);
+        const unsigned xstep = 8u * (unsigned)a.x_pitch * (unsigned)sizeof(TX);
+        const int txb = T * (int)sizeof(TX);
+        const unsigned xoff = colok ? ((unsigned)(wy0 + w - xo) * (unsigned)a.x_pitch + (unsigned)(wxA + lane - xo)) * (unsigned)sizeof(TX) : kNoAccess;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const bool rowok = 8 * n1 + w >= R && 8 * n1 + w < FT_N - R;
+            const unsigned o = rowok ? xoff + n1 * xstep : kNoAccess;
+            xa[n1] = BufIO<TX>::ld(rx, o, 0); xb[n1] = BufIO<TX>::ld(rx, o, txb);
+        }
+    }
 
     // ---- columns, stage 1, straight from global memory: window rows 8 n1 + w of column `lane` ----
     {
@@ -413,32 +435,16 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
     }
     __syncthreads();
     // ---- columns, inverse stage 1, into the epilogue: window rows 8 n1 + w of column `lane` ----
-    // Fast form: both tiles complete, inside the output region, their x operand addressed without clamping, plain Horner
-    // epilogue -- plane descriptors + 32-bit offsets; the halo rows (wave-uniform) and columns get an out-of-range offset.
-    const int xo = a.x_kind == SRC_VIRTUAL ? a.pad : 0, oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
-    const int oy0 = wy0 + R, oxA = wxA + R;
-    const bool fast = a.epilogue == EPI_HORNER && hasB && oy0 + T <= rg.y_hi && oxA + 2 * T <= rg.x_hi && oy0 - xo >= 0 &&
-                      oxA - xo >= 0 && oy0 + T - xo <= (a.x_kind == SRC_VIRTUAL ? a.H : a.H + 2 * a.pad) &&
-                      oxA + 2 * T - xo <= (a.x_kind == SRC_VIRTUAL ? a.W : a.W + 2 * a.pad);
     if (!fast) {
         epilogue_mapped<TX, TOut>(a, info, xpl, opl, wy0, wxA, R, hasB, Z, tw, w, lane);
         return;
     }
     const float sc = a.scale, cfx = a.coef;
     const bool cl = a.clamp01 != 0;
-    const brsrc rx = plane_rsrc(xpl, a.x_plane), ro = plane_rsrc(opl, a.out_plane);
-    const unsigned xstep = 8u * (unsigned)a.x_pitch * (unsigned)sizeof(TX), ostep = 8u * (unsigned)a.out_pitch * (unsigned)sizeof(TOut);
-    const int txb = T * (int)sizeof(TX), tob = T * (int)sizeof(TOut);
-    const bool colok = lane >= R && lane < FT_N - R;
-    const unsigned xoff = colok ? ((unsigned)(wy0 + w - xo) * (unsigned)a.x_pitch + (unsigned)(wxA + lane - xo)) * (unsigned)sizeof(TX) : kNoAccess;
+    const brsrc ro = plane_rsrc(opl, a.out_plane);
+    const unsigned ostep = 8u * (unsigned)a.out_pitch * (unsigned)sizeof(TOut);
+    const int tob = T * (int)sizeof(TOut);
     const unsigned ooff = colok ? ((unsigned)(wy0 + w - oo) * (unsigned)a.out_pitch + (unsigned)(wxA + lane - oo)) * (unsigned)sizeof(TOut) : kNoAccess;
-    float xa[8], xb[8];
-#pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) {
-        const bool rowok = 8 * n1 + w >= R && 8 * n1 + w < FT_N - R;
-        const unsigned o = rowok ? xoff + n1 * xstep : kNoAccess;
-        xa[n1] = BufIO<TX>::ld(rx, o, 0); xb[n1] = BufIO<TX>::ld(rx, o, txb);
-    }
     cf v[8];
     lds_read8<8 * FT_P * 8>(v, Z + w * FT_P + lane);
 #pragma unroll
