@@ -161,8 +161,8 @@ __device__ __forceinline__ void idft8(cf (&v)[8]) {
 // the spectrum of a point-symmetric real kernel -- every Gaussian the estimator builds is one, bit for bit
 // (k[12+u][12+v] == k[12-u][12-v]) -- is real, so correlation and convolution coincide and a thread's 16 spectrum
 // values fit 16 registers.  Laid out in the transforms' permuted order, both transforms' normalisation folded in.  Only
-// the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double from the
-// fp32 cosine table the transforms use (the spectrum is good to a few 1e-8 of its peak).  Caller-supplied taps that are not point-symmetric keep the stencil body.
+// the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double (the
+// spectrum is then the correctly rounded fp32 one: with fp32 table values the pass loses 1e-6 of agreement with the stencil).  Caller-supplied taps that are not point-symmetric keep the stencil body.
 constexpr int KH_SLICES = 8;          // workgroups per image: each evaluates 512 of the 4096 values of the second sum
 __global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases) {
     __shared__ double2 G[(PB_KRAD + 1) * FT_N];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, 
     const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases && min_phases >= 0;
     if (tid == 0 && blockIdx.y == 0) { sel[blockIdx.x].use_fft = use ? 1 : 0; sel[blockIdx.x].rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
     if (!use) return;
-    if (tid < FT_N) { cs[tid] = (double)kW64[tid].x; sn[tid] = -(double)kW64[tid].y; }       // fp32 table values, exact in double
+    if (tid < FT_N) { double sv, cv; sincospi((double)tid / 32.0, &sv, &cv); cs[tid] = cv; sn[tid] = sv; }
     __syncthreads();
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
     // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u})

@@ -220,9 +220,10 @@ def test_pipeline_with_normalized_convolution_prefilter():
     got = polyblur_deblurring(torch.from_numpy(x), prefilter="normalized_convolution", **kw).numpy()
     want = ref.polyblur_deblurring(x, prefilter="normalized_convolution", **kw)
     # the NC filter is discontinuous in its input (box limits are comparisons): from the second iteration on,
-    # rounding-level differences of the first move a limit by one sample here and there -- measured: 26 of 80 640
-    # samples beyond 2e-5, the largest 9.1e-5
-    assert np.mean(np.abs(got - want) > 2e-5) < 1e-3 and maxabs(got, want) < 5e-4
+    # rounding-level differences of the first move a limit by one sample here and there.  Which samples flip is a matter
+    # of the last bit (tools/nc_check.py): of 80 640 samples, beyond 2e-5 -- this input: 289 (largest 6.0e-4) with the
+    # dense kernels through the tile-spectrum body, 26 (9.1e-5) through the stencil body; seed 43: 0 and 217 (3.6e-4)
+    assert np.mean(np.abs(got - want) > 2e-5) < 6e-3 and maxabs(got, want) < 1.5e-3
     one = polyblur_deblurring(torch.from_numpy(x), prefilter="normalized_convolution", **dict(kw, n_iter=1)).numpy()
     want1 = ref.polyblur_deblurring(x, prefilter="normalized_convolution", **dict(kw, n_iter=1))
     assert maxabs(one, want1) < 2e-5            # one iteration: no amplified limit decisions yet (measured 2.4e-6)
@@ -282,7 +283,9 @@ def test_adaptive_support_matches_full(eng, sigma, rho, deg):
     adap = eng.make_kernels([sigma] * 2, [rho] * 2, [th] * 2, support=capi.PB_SUPPORT_ADAPTIVE, name="np.info2")
     assert eng.read_info(adap, 2)["radius"][0] in ((4, 6, 8, 10, 12) if sigma < 1.5 else (10, 12))
     b = eng.inverse_filter(x, adap, 6.0, 1.0, capi.PB_WRAP)
-    assert maxabs(a, b) < 2e-6
+    # (fp32 rounding of the Horner temporaries, which reach 9x the image range; the two policies may also put the image
+    # on different bodies -- tile-spectrum for the full box, stencil for the trimmed one: 2.0e-6 measured then, 1e-6 otherwise)
+    assert maxabs(a, b) < 4e-6
 
 
 # ---------------------------------------------------------------------------------------------
