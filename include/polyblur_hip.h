@@ -156,7 +156,7 @@ int pb_synchronize(pb_ctx *ctx);
 const char *pb_last_error_string(pb_ctx *ctx);
 void pb_default_options(pb_options *opt);        /* the functional API's defaults, deblurring.py:23-25 */
 /* How dense (non rank-1) kernels are evaluated by the reblurring pass.  PB_DENSE_STENCIL: always by the 2-D stencil
- * body (up to 625 multiply-adds per sample, fp32-vector-bound).  PB_DENSE_AUTO (default, min_phases = 36): images whose
+ * body (up to 625 multiply-adds per sample, fp32-vector-bound).  PB_DENSE_AUTO (default, min_phases = 16): images whose
  * stencil would run at least `min_phases` live (kernel row, 4-tap segment) phases are evaluated per 64 x 64 window in
  * the frequency domain inside LDS (overlap-save; same taps, same boundary models, results agree to fp32 rounding);
  * the others, rank-1 kernels and 8-bit images keep the stencil bodies.  Replaces nothing in the reference: both are

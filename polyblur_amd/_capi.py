@@ -22,7 +22,7 @@ PB_WRAP, PB_ZERO = 0, 1
 PB_PREFILTER_NONE, PB_PREFILTER_BILATERAL, PB_PREFILTER_DOMAIN_TRANSFORM, PB_PREFILTER_NORMALIZED_CONVOLUTION = 0, 1, 2, 3
 PB_SUPPORT_FULL, PB_SUPPORT_ADAPTIVE = 0, 1
 PB_DENSE_STENCIL, PB_DENSE_AUTO = 0, 1
-PB_DENSE_MIN_PHASES = 36
+PB_DENSE_MIN_PHASES = 16
 
 STATUS = {0: "PB_OK", -1: "PB_ERR_BADARG", -2: "PB_ERR_UNSUPPORTED", -3: "PB_ERR_HIP", -4: "PB_ERR_NOMEM"}
 

@@ -53,7 +53,7 @@ struct pb_ctx {
     size_t est_done_bytes = 0;     // size of the zero-initialised arrival counters
     // dense (non rank-1) kernels with at least this many live stencil phases are evaluated per tile in the frequency
     // domain (conv_fft.hip) instead of by the stencil body; < 0: never (pb_set_dense_eval, env PB_DENSE_EVAL)
-    int fft_min_phases = 36;
+    int fft_min_phases = 16;
     // What the host knows about record sets it built itself and read back (pb_make_kernels / pb_set_kernels synchronise
     // anyway): whether any image takes the tile-spectrum body, whether any takes a stencil body -- a reblurring pass then
     // skips the launch nobody needs -- and whose spectra the context's scratch currently holds.  Records estimated on the

@@ -253,7 +253,7 @@ struct FftGeom {
     int pairs_x[3], njobs[3], per[3];
     float inv_pairs_x[3];
     int slots;                    // per[2]: pairs per plane and XCD for the smallest tile (the job grid is sized for it)
-    float inv_slots;
+    float inv_planes;
 };
 __device__ __forceinline__ int div_small(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }   // n < 2^22, exact
 
@@ -467,8 +467,10 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
 template <typename TIn, typename TX, typename TOut>
 __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, const FftGeom g) {
     extern __shared__ __attribute__((aligned(16))) float2 Z[];
+    // (slot-major order: slot i of every plane, then slot i + 1 ...  The slots an image with larger tiles leaves idle are
+    // the last ones of the grid, not gaps in the middle of it.)
     const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-    const int plane = __builtin_amdgcn_readfirstlane(div_small(s, g.inv_slots)), i = s - plane * g.slots;
+    const int i = __builtin_amdgcn_readfirstlane(div_small(s, g.inv_planes)), plane = s - i * a.P;
     const int img = __builtin_amdgcn_readfirstlane(plane / a.C);
     const PB_CONSTANT pb_fft_sel *sel = as_constant(a.fsel + img);
     if (!sel->use_fft) return;                                  // a stencil body of conv_tile_kernel does this image
@@ -493,7 +495,7 @@ int launch_fft_typed(pb_ctx *ctx, const ConvPass &p) {
         g.inv_pairs_x[c] = 1.0f / (float)px;
     }
     g.slots = g.per[2];
-    g.inv_slots = 1.0f / (float)g.slots;
+    g.inv_planes = 1.0f / (float)p.P;
     const long total = (long)g.slots * p.P;
     if (total <= 0 || total > (1L << 22)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: batch too large for the tile-spectrum body");
     hipLaunchKernelGGL((conv_fft_kernel<TIn, TX, TOut>), dim3((unsigned)(8 * total)), dim3(FT_NT), kFftLds, ctx->stream, p, g);

@@ -82,7 +82,7 @@ class Engine:
     def synchronize(self):
         self._check(self.lib.pb_synchronize(self.ctx))
 
-    def set_dense_eval(self, mode: str = "auto", min_phases: int = 36):
+    def set_dense_eval(self, mode: str = "auto", min_phases: int = 16):
         """How dense (non rank-1) kernels are evaluated: 'stencil' = always the 2-D stencil body; 'auto' = kernels with
         at least `min_phases` live stencil phases take the tile-spectrum body (pb_set_dense_eval)."""
         m = {"stencil": capi.PB_DENSE_STENCIL, "auto": capi.PB_DENSE_AUTO}[mode]

@@ -95,7 +95,7 @@ def test_mixed_batch(eng):
     th = np.deg2rad(np.float32([0.0, 24.0, 66.0]))
     sig, rho = [2.0, 0.6, 3.0], [1.0, 0.4, 2.0]
     buf = eng.make_kernels(sig, rho, th, support=capi.PB_SUPPORT_ADAPTIVE)
-    eng.set_dense_eval("auto", capi.PB_DENSE_MIN_PHASES)
+    eng.set_dense_eval("auto", 36)                           # (0.6, 0.4, 24 deg) has 19 live phases: stencil body
     out = eng.inverse_filter(x, buf, 6.0, 1.0, capi.PB_WRAP)
     k = ref.gaussian_kernel_2d(th, sig, rho)
     want = ref.inverse_filtering_rank3(x, k[:, None], 6.0, 1.0, method="fft")
