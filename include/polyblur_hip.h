@@ -157,7 +157,8 @@ const char *pb_last_error_string(pb_ctx *ctx);
 void pb_default_options(pb_options *opt);        /* the functional API's defaults, deblurring.py:23-25 */
 /* How dense (non rank-1) kernels are evaluated by the reblurring pass.  PB_DENSE_STENCIL: always by the 2-D stencil
  * body (up to 625 multiply-adds per sample, fp32-vector-bound).  PB_DENSE_AUTO (default, min_phases = 16): images whose
- * stencil would run at least `min_phases` live (kernel row, 4-tap segment) phases are evaluated per 64 x 64 window in
+ * stencil would run at least `min_phases` live (kernel row, 4-tap segment) phases (8 more when the support fits a
+ * 4-sample halo; min_phases = 0: every dense point-symmetric kernel) are evaluated per 64 x 64 window in
  * the frequency domain inside LDS (overlap-save; same taps, same boundary models, results agree to fp32 rounding);
  * the others, rank-1 kernels and 8-bit images keep the stencil bodies.  Replaces nothing in the reference: both are
  * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>. */

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, 
         sk[i] = in ? k : 0.f;
         sym = sym && (!in || k == info->kernel[PB_KSIZE * PB_KSIZE - 1 - i]);
     }
-    const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases && min_phases >= 0;
+    // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
+    const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0) && min_phases >= 0;
     if (tid == 0 && blockIdx.y == 0) { sel[blockIdx.x].use_fft = use ? 1 : 0; sel[blockIdx.x].rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
     if (!use) return;
     if (tid < FT_N) { double sv, cv; sincospi((double)tid / 32.0, &sv, &cv); cs[tid] = cv; sn[tid] = sv; }
@@ -253,7 +254,7 @@ struct FftGeom {
     int pairs_x[3], njobs[3], per[3];
     float inv_pairs_x[3];
     int slots;                    // per[2]: pairs per plane and XCD for the smallest tile (the job grid is sized for it)
-    float inv_planes;
+    float inv_slots;
 };
 __device__ __forceinline__ int div_small(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }   // n < 2^22, exact
 
@@ -467,16 +468,21 @@ __device__ __forceinline__ void window_pair(const ConvPass &a, const pb_blur_inf
 template <typename TIn, typename TX, typename TOut>
 __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, const FftGeom g) {
     extern __shared__ __attribute__((aligned(16))) float2 Z[];
-    // (slot-major order: slot i of every plane, then slot i + 1 ...  The slots an image with larger tiles leaves idle are
-    // the last ones of the grid, not gaps in the middle of it.)
     const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-    const int i = __builtin_amdgcn_readfirstlane(div_small(s, g.inv_planes)), plane = s - i * a.P;
+    const int plane = __builtin_amdgcn_readfirstlane(div_small(s, g.inv_slots)), i = s - plane * g.slots;
     const int img = __builtin_amdgcn_readfirstlane(plane / a.C);
     const PB_CONSTANT pb_fft_sel *sel = as_constant(a.fsel + img);
     if (!sel->use_fft) return;                                  // a stencil body of conv_tile_kernel does this image
     const int R = sel->rf, c = (R >> 2) - 1;
-    const int local = xcd * g.per[c] + i;
-    if (i >= g.per[c] || local >= g.njobs[c]) return;
+    // This XCD's run of the plane has per <= slots pairs.  They are dealt to the slots evenly -- slot i takes pair
+    // floor(i per / slots) when that differs from its successor's -- so that the idle workgroups of an image with larger
+    // tiles are sprinkled between the working ones (a run of idle workgroups in front of the next plane's would drain
+    // the chip while the dispatcher works through it) and a plane's pairs still run in order (halo rows of the window
+    // row above are still in the XCD's L2).  (double: exact for any plane the engine accepts)
+    const int per = g.per[c];
+    const int j0 = (int)(((double)i * (double)per) / (double)g.slots), j1 = (int)(((double)(i + 1) * (double)per) / (double)g.slots);
+    const int local = __builtin_amdgcn_readfirstlane(xcd * per + j0);
+    if (__builtin_amdgcn_readfirstlane(j1) == local - xcd * per || local >= g.njobs[c]) return;
     const int ty = __builtin_amdgcn_readfirstlane(div_small(local, g.inv_pairs_x[c])), pxi = local - ty * g.pairs_x[c];
     window_pair<TIn, TX, TOut>(a, a.info + img, plane, ty, pxi, R, Z, a.khat + (long)img * (FT_N * FT_N));
 }
@@ -495,7 +501,7 @@ int launch_fft_typed(pb_ctx *ctx, const ConvPass &p) {
         g.inv_pairs_x[c] = 1.0f / (float)px;
     }
     g.slots = g.per[2];
-    g.inv_planes = 1.0f / (float)p.P;
+    g.inv_slots = 1.0f / (float)g.slots;
     const long total = (long)g.slots * p.P;
     if (total <= 0 || total > (1L << 22)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: batch too large for the tile-spectrum body");
     hipLaunchKernelGGL((conv_fft_kernel<TIn, TX, TOut>), dim3((unsigned)(8 * total)), dim3(FT_NT), kFftLds, ctx->stream, p, g);
