@@ -14,8 +14,9 @@ differ in the reference), and the same in/out type rule:
 The work is done by the HIP engine behind include/polyblur_hip.h; there is no CPU
 implementation here.  ``method`` keeps the reference's meaning as a *boundary model*:
 'fft' = circular reblurring on the replicate-padded domain (the reference default),
-'direct' = zero-padded reblurring -- both evaluated by the same spatial-domain Gaussian
-stencil kernels (no FFT convolution on the device).
+'direct' = zero-padded reblurring -- both evaluated by the same reblurring pass (separable or 2-D
+stencil, or -- dense kernels -- overlap-save on 64x64 windows inside LDS; no image-sized transform
+exists on the device).
 
 Extras that the reference does not have (all keyword-only, defaults keep reference
 behaviour): ``support`` ('full' | 'adaptive'), ``prefilter`` ('bilateral' |
