@@ -165,7 +165,7 @@ int pb_free(pb_ctx *ctx, void *dptr) {
 }
 int pb_memcpy_h2d(pb_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return PB_ERR_BADARG;
-    pb_forget_records(ctx, nullptr);                      // (the copy may overwrite records the context has cached facts about)
+    pb_forget_range(ctx, dst, bytes);                     // (the copy may overwrite records the context has cached facts about)
     PB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
     return PB_OK;

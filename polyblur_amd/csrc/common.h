@@ -148,6 +148,7 @@ int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // 
 int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch);
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // conv.hip: after the host (re)built these records
 void pb_forget_records(pb_ctx *ctx, const void *info);                        // nullptr: all
+void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 
 // ------------------------------------------------------------------------------------

@@ -362,6 +362,17 @@ int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B) {
     ctx->rec_cache[info] = f;
     return PB_OK;
 }
+// a write of `bytes` bytes at dst: forget what is known about the record sets it overlaps
+void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes) {
+    const char *lo = static_cast<const char *>(dst), *hi = lo + bytes;
+    for (auto it = ctx->rec_cache.begin(); it != ctx->rec_cache.end();) {
+        const char *a = static_cast<const char *>(it->first), *b = a + sizeof(pb_blur_info) * (size_t)it->second.B;
+        if (a < hi && lo < b) {
+            if (ctx->khat_owner == it->first) ctx->khat_owner = nullptr;
+            it = ctx->rec_cache.erase(it);
+        } else ++it;
+    }
+}
 void pb_forget_records(pb_ctx *ctx, const void *info) {
     if (info) ctx->rec_cache.erase(info); else ctx->rec_cache.clear();
     if (!info || ctx->khat_owner == info) ctx->khat_owner = nullptr;

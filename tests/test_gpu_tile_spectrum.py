@@ -100,3 +100,29 @@ def test_mixed_batch(eng):
     k = ref.gaussian_kernel_2d(th, sig, rho)
     want = ref.inverse_filtering_rank3(x, k[:, None], 6.0, 1.0, method="fft")
     assert maxabs(out, want) < 1e-5
+
+
+def test_host_side_record_facts_follow_the_records(eng):
+    # pb_make_kernels / pb_set_kernels let the context remember which bodies a record set needs (a pass then skips the
+    # launch nobody needs); whatever rewrites the records -- another build into the same buffer, a raw upload -- must
+    # make it forget.  Same buffer, three kinds of records in turn, each result checked against the oracle.
+    rng = np.random.default_rng(3)
+    xp = rng.random((1, 2, 90 + 24, 130 + 24), dtype=np.float32)
+    eng.set_dense_eval("auto", capi.PB_DENSE_MIN_PHASES)
+
+    def check(buf, k):
+        out = eng.convolve2d(xp, buf, capi.PB_ZERO)
+        assert maxabs(out, ref.convolve2d(xp, k[:, None], method="direct")) < 2e-6
+
+    th0, th1 = np.float32(0.0), np.deg2rad(np.float32(66.0))
+    k_rank1 = ref.gaussian_kernel_2d([th0], [2.0], [1.0])
+    k_dense = ref.gaussian_kernel_2d([th1], [3.0], [2.0])
+    buf = eng.make_kernels([2.0], [1.0], [th0], name="np.facts")          # rank-1: stencil launch only
+    check(buf, k_rank1)
+    buf = eng.make_kernels([3.0], [2.0], [th1], name="np.facts")          # dense: tile-spectrum launch only
+    dense_records = eng.read_info(buf, 1).copy()
+    check(buf, k_dense)
+    buf = eng.make_kernels([2.0], [1.0], [th0], name="np.facts")
+    check(buf, k_rank1)
+    buf.upload(dense_records)                                             # raw upload of the dense records over the rank-1 ones
+    check(buf, k_dense)
