@@ -194,7 +194,11 @@ int pb_estimate_blur(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                      const pb_options *opt, pb_blur_info *dev_info);
 
 /* create_gaussian_filter (blur_estimation.py:211-232) + support analysis, for caller-
- * supplied parameters: fills kernel/separable/radius of B device records from host arrays. */
+ * supplied parameters: fills kernel/separable/radius of B device records from host arrays.
+ * pb_make_kernels and pb_set_kernels synchronise, and the context remembers which bodies of the reblurring pass
+ * these B records need (later passes on them skip the launch no image needs).  Records are to be rewritten through
+ * this API only (pb_make_kernels, pb_set_kernels, pb_estimate_blur, pb_make_separable_kernels, pb_memcpy_h2d -- each
+ * makes the context forget); after a raw copy into them call pb_set_dense_eval, which forgets everything.         */
 int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *host_rho,
                     const float *host_theta_rad, int support, pb_blur_info *dev_info);
 /* Same, but the caller supplies arbitrary 25x25 taps (host, B*625 floats). */
