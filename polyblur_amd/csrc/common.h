@@ -150,6 +150,7 @@ int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // co
 void pb_forget_records(pb_ctx *ctx, const void *info);                        // nullptr: all
 void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
+bool pb_conv_fft_feasible(const ConvPass &p);                                // window counts within the kernel's index arithmetic
 
 // ------------------------------------------------------------------------------------
 // estimation (estimate.hip)

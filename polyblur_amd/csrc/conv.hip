@@ -326,7 +326,7 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     // (the tile-spectrum body addresses planes with 32-bit byte offsets)
     const long plane_max = (1L << 31) - 4096;
     bool fft = ctx->fft_min_phases >= 0 && !p.skip_general && p.in_plane * 4 < plane_max && p.x_plane * 4 < plane_max &&
-               p.out_plane * 4 < plane_max;
+               p.out_plane * 4 < plane_max && pb_conv_fft_feasible(p);
     const int B = p.P / p.C;
     const auto known = ctx->rec_cache.find(p.info);
     const bool have = known != ctx->rec_cache.end() && known->second.B == B;

@@ -487,23 +487,30 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, co
     window_pair<TIn, TX, TOut>(a, a.info + img, plane, ty, pxi, R, Z, a.khat + (long)img * (FT_N * FT_N));
 }
 
-template <typename TIn, typename TX, typename TOut>
-int launch_fft_typed(pb_ctx *ctx, const ConvPass &p) {
+// Geometry of the pass; false when a plane or the batch has more window pairs than the kernel's index arithmetic takes
+// (2^22: the caller then keeps the stencil bodies).
+bool fft_geometry(const ConvPass &p, FftGeom &g) {
     const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * p.pad;
     const int ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * p.pad;
-    FftGeom g;
     for (int c = 0; c < 3; ++c) {
         const int T = FT_N - 8 * (c + 1);
         const long tiles_x = (ow + T - 1) / T, tiles_y = (oh + T - 1) / T;
         const long px = (tiles_x + 1) / 2, nj = px * tiles_y;
-        if (nj > (1L << 22)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: plane too large for the tile-spectrum body");
+        if (nj > (1L << 22)) return false;
         g.pairs_x[c] = (int)px; g.njobs[c] = (int)nj; g.per[c] = (int)((nj + 7) / 8);
         g.inv_pairs_x[c] = 1.0f / (float)px;
     }
     g.slots = g.per[2];
     g.inv_slots = 1.0f / (float)g.slots;
     const long total = (long)g.slots * p.P;
-    if (total <= 0 || total > (1L << 22)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: batch too large for the tile-spectrum body");
+    return total > 0 && total <= (1L << 22);
+}
+
+template <typename TIn, typename TX, typename TOut>
+int launch_fft_typed(pb_ctx *ctx, const ConvPass &p) {
+    FftGeom g;
+    if (!fft_geometry(p, g)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: too many windows for the tile-spectrum body");
+    const long total = (long)g.slots * p.P;
     hipLaunchKernelGGL((conv_fft_kernel<TIn, TX, TOut>), dim3((unsigned)(8 * total)), dim3(FT_NT), kFftLds, ctx->stream, p, g);
     PB_LAUNCH_CHECK();
     return PB_OK;
@@ -526,6 +533,8 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
     *khat = k; *sel = s;
     return PB_OK;
 }
+
+bool pb_conv_fft_feasible(const ConvPass &p) { FftGeom g; return fft_geometry(p, g); }
 
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p) {
     ProfScope prof(ctx, PB_PROF_CONV_FFT);
