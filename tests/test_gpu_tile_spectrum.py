@@ -126,3 +126,14 @@ def test_host_side_record_facts_follow_the_records(eng):
     check(buf, k_rank1)
     buf.upload(dense_records)                                             # raw upload of the dense records over the rank-1 ones
     check(buf, k_dense)
+
+
+def test_dense_eval_arguments(eng):
+    bad = -1                                                                        # PB_ERR_BADARG
+    assert eng.lib.pb_set_dense_eval(eng.ctx, 7, 0) == bad                          # unknown mode
+    assert eng.lib.pb_set_dense_eval(eng.ctx, capi.PB_DENSE_AUTO, -1) == bad
+    assert eng.lib.pb_set_dense_eval(eng.ctx, capi.PB_DENSE_AUTO, 10 ** 6) == bad
+    with pytest.raises(KeyError):
+        eng.set_dense_eval("spectrum")
+    eng.set_dense_eval("stencil")
+    eng.set_dense_eval("auto", 0)
