@@ -161,17 +161,57 @@ __device__ __forceinline__ void idft8(cf (&v)[8]) {
 // the spectrum of a point-symmetric real kernel -- every Gaussian the estimator builds is one, bit for bit
 // (k[12+u][12+v] == k[12-u][12-v]) -- is real, so correlation and convolution coincide and a thread's 16 spectrum
 // values fit 16 registers.  Laid out in the transforms' permuted order, both transforms' normalisation folded in.  Only
-// the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double (the
-// spectrum is then the correctly rounded fp32 one: with fp32 table values the pass loses 1e-6 of agreement with the stencil).  Caller-supplied taps that are not point-symmetric keep the stencil body.
-constexpr int KH_SLICES = 8;          // workgroups per image: each evaluates 512 of the 4096 values of the second sum
+// the taps inside the record's support box count, exactly as in the stencil body.  Accumulated in double with a
+// double cosine table (the spectrum is then the correctly rounded fp32 one: with fp32 table values the pass loses 1e-6 of
+// agreement with the stencil).  Caller-supplied taps that are not point-symmetric keep the stencil body.
+// cos / sin (2 pi m / 64) in double, for the spectra
+static __device__ const double kCos64[64] = {
+    1, 0.99518472667219693, 0.98078528040323043, 0.95694033573220882,
+    0.92387953251128674, 0.88192126434835505, 0.83146961230254524, 0.77301045336273699,
+    0.70710678118654757, 0.63439328416364549, 0.55557023301960229, 0.47139673682599781,
+    0.38268343236508984, 0.29028467725446233, 0.19509032201612833, 0.09801714032956077,
+    0, -0.098017140329560645, -0.19509032201612819, -0.29028467725446216,
+    -0.38268343236508973, -0.4713967368259977, -0.55557023301960196, -0.63439328416364538,
+    -0.70710678118654746, -0.77301045336273699, -0.83146961230254535, -0.88192126434835494,
+    -0.92387953251128674, -0.95694033573220882, -0.98078528040323043, -0.99518472667219682,
+    -1, -0.99518472667219693, -0.98078528040323043, -0.95694033573220894,
+    -0.92387953251128685, -0.88192126434835505, -0.83146961230254546, -0.7730104533627371,
+    -0.70710678118654768, -0.63439328416364593, -0.55557023301960218, -0.47139673682599786,
+    -0.38268343236509034, -0.29028467725446244, -0.19509032201612866, -0.098017140329560451,
+    0, 0.09801714032956009, 0.1950903220161283, 0.29028467725446205,
+    0.38268343236509, 0.47139673682599759, 0.55557023301960184, 0.6343932841636456,
+    0.70710678118654735, 0.77301045336273666, 0.83146961230254524, 0.88192126434835483,
+    0.92387953251128652, 0.95694033573220882, 0.98078528040323032, 0.99518472667219693
+};
+static __device__ const double kSin64[64] = {
+    0, 0.098017140329560604, 0.19509032201612825, 0.29028467725446233,
+    0.38268343236508978, 0.47139673682599764, 0.55557023301960218, 0.63439328416364549,
+    0.70710678118654746, 0.77301045336273699, 0.83146961230254524, 0.88192126434835494,
+    0.92387953251128674, 0.95694033573220894, 0.98078528040323043, 0.99518472667219682,
+    1, 0.99518472667219693, 0.98078528040323043, 0.95694033573220894,
+    0.92387953251128674, 0.88192126434835505, 0.83146961230254546, 0.7730104533627371,
+    0.70710678118654757, 0.63439328416364549, 0.55557023301960218, 0.47139673682599786,
+    0.38268343236508989, 0.29028467725446239, 0.19509032201612861, 0.098017140329560826,
+    0, -0.09801714032956059, -0.19509032201612836, -0.29028467725446211,
+    -0.38268343236508967, -0.47139673682599764, -0.55557023301960196, -0.63439328416364527,
+    -0.70710678118654746, -0.77301045336273666, -0.83146961230254524, -0.88192126434835494,
+    -0.92387953251128652, -0.95694033573220882, -0.98078528040323032, -0.99518472667219693,
+    -1, -0.99518472667219693, -0.98078528040323043, -0.95694033573220894,
+    -0.92387953251128663, -0.88192126434835505, -0.83146961230254546, -0.77301045336273688,
+    -0.70710678118654768, -0.63439328416364593, -0.55557023301960218, -0.47139673682599792,
+    -0.38268343236509039, -0.2902846772544625, -0.19509032201612872, -0.098017140329560506
+};
+constexpr int KH_SLICES = 8;          // workgroups per image: each forms the spectrum at 8 of the 64 x positions
 __global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases) {
-    __shared__ double2 G[(PB_KRAD + 1) * FT_N];
+    constexpr int NR = PB_KRAD + 1, PXS = FT_N / KH_SLICES;
+    __shared__ double2 G[NR * PXS];
     __shared__ double cs[FT_N], sn[FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
     const pb_blur_info *info = infos + blockIdx.x;
     const int tid = threadIdx.x;
     const int nph = info->nphase[0] + info->nphase[1] + info->nphase[2];
     const int R = info->radius;
+    if (tid < FT_N) { cs[tid] = kCos64[tid]; sn[tid] = kSin64[tid]; }
     bool sym = true;
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_NT) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
@@ -184,13 +224,11 @@ __global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, 
     const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0) && min_phases >= 0;
     if (tid == 0 && blockIdx.y == 0) { sel[blockIdx.x].use_fft = use ? 1 : 0; sel[blockIdx.x].rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
     if (!use) return;
-    if (tid < FT_N) { double sv, cv; sincospi((double)tid / 32.0, &sv, &cv); cs[tid] = cv; sn[tid] = sv; }
-    __syncthreads();
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
-    // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u})
-    constexpr int NR = PB_KRAD + 1;
-    for (int idx = tid; idx < NR * FT_N; idx += KH_NT) {
-        const int u = (idx >> 6) + PB_KRAD, px = idx & 63, fx = (px >> 3) + 8 * (px & 7);
+    // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u}); this workgroup's x positions only
+    const int px0 = blockIdx.y * PXS;
+    if (tid < NR * PXS) {
+        const int u = tid / PXS + PB_KRAD, px = px0 + tid % PXS, fx = (px >> 3) + 8 * (px & 7);
         double ar = 0.0, ai = 0.0;
 #pragma unroll 5
         for (int v = 0; v < PB_KSIZE; ++v) {
@@ -198,20 +236,20 @@ __global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, 
             const double k = (double)sk[u * PB_KSIZE + v];
             ar += k * cs[m]; ai += k * sn[m];
         }
-        G[idx] = make_double2(ar, ai);
+        G[tid] = make_double2(ar, ai);
     }
     __syncthreads();
-    float *out = khat + (long)blockIdx.x * (FT_N * FT_N);
-    for (int idx = blockIdx.y * (FT_N * FT_N / KH_SLICES) + tid; idx < (blockIdx.y + 1) * (FT_N * FT_N / KH_SLICES); idx += KH_NT) {
-        const int py = idx >> 6, px = idx & 63, fy = (py >> 3) + 8 * (py & 7);
-        double ar = 0.5 * G[px].x;
+    float *out = khat + (long)blockIdx.x * (FT_N * FT_N);                 // stored transposed: [x position][y position]
+    for (int idx = tid; idx < PXS * FT_N; idx += KH_NT) {
+        const int pxl = idx >> 6, py = idx & 63, fy = (py >> 3) + 8 * (py & 7);
+        double ar = 0.5 * G[pxl].x;
 #pragma unroll 4
         for (int u = 1; u < NR; ++u) {
             const int m = (fy * u) & 63;
-            const double2 g = G[u * FT_N + px];
+            const double2 g = G[u * PXS + pxl];
             ar += g.x * cs[m] - g.y * sn[m];
         }
-        out[px * FT_N + py] = (float)(ar * (2.0 / 4096.0));          // stored transposed: [x position][y position]
+        out[(px0 + pxl) * FT_N + py] = (float)(ar * (2.0 / 4096.0));
     }
 }
 
