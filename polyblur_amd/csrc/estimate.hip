@@ -1202,7 +1202,15 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
                            lds, ctx->stream, planes, gx, gy, H, W, lognb, normalize ? 1 : 0, mm,
                            planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);
     }
-    else if (n_angles == 6) PB_COLS(1, 7);          // the default grid of directions, unrolled
+    else if (n_angles == 6) {
+        // 8-column (or narrower) tiles, two workgroups per CU: 512 threads each (measured against 256: 700x500 31 -> 23 us,
+        // 1080p 56 -> 40 us, 512x512 28 -> 25 us)
+        int rc = allow_lds(ctx, grad_cols_kernel<1, 7, 512>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((grad_cols_kernel<1, 7, 512>), dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(512),
+                           lds, ctx->stream, planes, gx, gy, H, W, lognb, normalize ? 1 : 0, mm,
+                           planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);
+    }
     else PB_COLS(1, 0);
 #undef PB_COLS
     PB_LAUNCH_CHECK();
