@@ -7,7 +7,7 @@
 // the kernel's 64 x 64 spectrum, inverse DFT, of which only the samples at least R from the window's edge (those no tap
 // reaches around the wrap) are kept -- overlap-save.  Nothing leaves LDS between the two transforms; HBM sees what the
 // stencil pass sees (a window read, the x operand, one store).  The 625 multiply-adds per sample of the dense stencil
-// (fp32-vector-bound: 0.30 ms per 4K launch) become ~110 flops per sample, and the pass is bound by LDS and memory.
+// (fp32-vector-bound: 0.30 ms per 4K launch) become ~110 flops per sample: 0.09 ms per 4K launch.
 //
 // * Two real tiles ride one complex transform: z = A + iB for two horizontally adjacent windows.  The kernel is real,
 //   so K (*) z = K (*) A + i K (*) B -- no real-to-complex packing or unpacking step exists.
@@ -21,11 +21,14 @@
 //   columns per wave (256-byte segments).
 // * LDS rows are 65 complex values long: every row-direction access (stride 8 or contiguous 8 per lane) and every
 //   column-direction access is bank-conflict-free for ds_read_b64 / ds_write_b64.
-// * 512 threads per window pair, one radix-8 butterfly per thread and stage; a wave's eight threads-of-a-line share n2
-//   (= the wave number), so the seven inter-stage twiddles W64^(n2 k) are wave-uniform and live in scalar registers.
-// * Workgroups are persistent (four per CU) and walk the window pairs of their XCD: the 16 spectrum values a thread
-//   multiplies are the same for every window of an image and stay in registers, so the 32 KB spectrum is read once per
-//   workgroup and image, not once per window.
+// * 512 threads per window pair, one radix-8 butterfly per thread and stage; all threads of a wave share n2 (stage 1)
+//   or k1 (stage 2) -- the wave number -- so the seven inter-stage twiddles W64^(n2 k) are wave-uniform and live in
+//   scalar registers.  One workgroup per window pair, four workgroups (32 waves) per CU.
+// * The kernels are point-symmetric (every Gaussian the estimator builds is, bit for bit), so their spectrum is real:
+//   16 KB per image, 8 values per thread, requested -- like the x operand of the epilogue -- before the first stage.
+//   Caller-supplied taps that are not point-symmetric keep the stencil body (khat_kernel decides per image).
+// * The interior path addresses planes through buffer descriptors (32-bit offsets; halo rows and columns get an
+//   out-of-range offset instead of a branch); LDS reads are single ds_read_b64 from inline assembly.
 //
 // The window keeps R = 4, 8 or 12 samples of halo (the record's radius class rounded up to a multiple of 4: 16-byte
 // aligned windows), i.e. 56, 48 or 40 outputs per side; every image picks its own on the device, like its body.
