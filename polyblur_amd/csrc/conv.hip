@@ -17,7 +17,10 @@
 // * general (rotated anisotropic) kernels: the exact 2-D stencil from the same LDS tile, 4x4 outputs per thread, the
 //   25-tap rows of the kernel streamed through SGPRs (208 packed FMAs per kernel row).  fp32 VALU-bound by design.
 //
-// No MFMA anywhere: the pass is bound by HBM / latency (rank-1) or by the fp32 vector rate (general).
+// * dense kernels with enough live phases take a third body in a second launch of the same step (conv_fft.hip: the same
+//   stencil evaluated per 64 x 64 window in the frequency domain inside LDS); this kernel's tiles of such images exit.
+//
+// No MFMA anywhere: the pass is bound by HBM / latency (rank-1) or by the fp32 vector rate (2-D stencil).
 
 #include "common.h"
 #include "conv_common.h"
