@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libpolyblur_hip.so"
-SOURCES = ["api.hip", "conv.hip", "conv_fft.hip", "conv_xt.hip", "estimate.hip", "filters.hip", "nc.hip"]
+SOURCES = ["api.hip", "conv.hip", "conv_fft.hip", "conv_wfft.hip", "conv_xt.hip", "estimate.hip", "filters.hip", "nc.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
 
@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = True, experimental: bool = False)
     headers.append(os.path.join(os.path.dirname(HERE), "include", "polyblur_hip.h"))
     jobs = []
     objs = []
-    flags = FLAGS + (["-DPB_WITH_FUSED"] if experimental else [])
+    flags = FLAGS + (["-DPB_WITH_FUSED"] if experimental else []) + os.environ.get("PB_EXTRA_FLAGS", "").split()
     stamp = os.path.join(objdir, "experimental" if experimental else "default")
     if not os.path.exists(stamp):                      # switching flavours rebuilds everything
         force = True

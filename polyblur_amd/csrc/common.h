@@ -54,6 +54,9 @@ struct pb_ctx {
     // dense (non rank-1) kernels with at least this many live stencil phases are evaluated per tile in the frequency
     // domain (conv_fft.hip) instead of by the stencil body; < 0: never (pb_set_dense_eval, env PB_DENSE_EVAL)
     int fft_min_phases = 16;
+    // which tile-spectrum body evaluates them: 1 = one wave per window pair (conv_wfft.hip), 0 = one workgroup per
+    // window pair (conv_fft.hip); env PB_FFT_BODY=wg|wave
+    int fft_wave = 1;
     // What the host knows about record sets it built itself and read back (pb_make_kernels / pb_set_kernels synchronise
     // anyway): whether any image takes the tile-spectrum body, whether any takes a stencil body -- a reblurring pass then
     // skips the launch nobody needs -- and whose spectra the context's scratch currently holds.  Records estimated on the
@@ -150,6 +153,7 @@ int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // co
 void pb_forget_records(pb_ctx *ctx, const void *info);                        // nullptr: all
 void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
+int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p);                     // conv_wfft.hip; PB_ERR_UNSUPPORTED: dtype combination not built
 bool pb_conv_fft_feasible(const ConvPass &p);                                // window counts within the kernel's index arithmetic
 
 // ------------------------------------------------------------------------------------

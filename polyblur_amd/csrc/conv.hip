@@ -346,7 +346,12 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
         const int rc = launch_stencil(ctx, p);
         if (rc) return rc;
     }
-    return fft ? pb_launch_conv_fft(ctx, p) : PB_OK;
+    if (!fft) return PB_OK;
+    if (ctx->fft_wave) {
+        const int rc = pb_launch_conv_wfft(ctx, p);
+        if (rc != PB_ERR_UNSUPPORTED) return rc;
+    }
+    return pb_launch_conv_fft(ctx, p);
 }
 
 // The host has just (re)built these B records and is synchronising anyway: build their spectra, read the per-image choice

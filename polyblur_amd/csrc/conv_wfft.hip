@@ -1,0 +1,632 @@
+// Tile-spectrum body of the reblurring pass, one WAVE per window pair.
+//
+// Same pass, same operands, same result as conv_fft.hip (one Horner step  t <- K*t + coef*x  of the polynomial
+// deconvolution, reference deblurring.py:122-138 / :141-169, or one edgetaper blend, edgetaper.py:30-32, with the
+// boundary models of filters.py:14-49): the exact 2-D stencil of a 64 x 64 window is evaluated as a circular correlation
+// -- forward 2-D DFT, product with the kernel's real 64 x 64 spectrum (khat_kernel, conv_fft.hip), inverse DFT, of which
+// the samples at least R from the window's edge are kept (overlap-save); two horizontally adjacent real windows ride
+// one complex transform, z = A + iB.
+//
+// What differs is who does it.  conv_fft.hip spreads a window pair over 512 threads: eight 8-point butterfly stages,
+// six LDS round trips and seven workgroup barriers per pair, every stage exposing an LDS or barrier latency.  Here a
+// window pair belongs to ONE wave and a whole 64-point line to one lane (64 complex values = 128 registers):
+//
+//   load      lane = window column x, register y = window row: 2 x 64 row-segment loads of 256 bytes per wave
+//   columns   fft64 in registers (two radix-8 stages, compile-time twiddles in scalar registers), no LDS, no barrier
+//   transpose through the wave's private LDS tile: lane = transformed row, register = column
+//   rows      fft64, x real spectrum (64 values per lane, [x position][y position] layout: coalesced), inverse fft64
+//   transpose back
+//   columns   inverse fft64; lane = window column again: the epilogue (scale, + coef * x, clamp) and the stores walk
+//             rows with 256-byte segments per wave instruction
+//
+// Two LDS round trips per pair instead of six, no workgroup barrier at all (a wave's DS operations execute in order;
+// only the compiler has to be told, wave_lds_fence), rows wave-uniform -- every row offset, boundary mapping and
+// validity test is scalar work -- and columns one map per lane and window.  Border windows, the taper epilogue and
+// ragged ends therefore run the same code as interior ones with different offsets (an out-of-range buffer offset
+// loads 0 / drops the store).
+//
+// The transposes keep only HALF a window pair in LDS at a time (16.6 KB per wave, eight waves per CU): a 64 x 64
+// transpose is the swap of the two off-diagonal 32 x 32 quadrants -- v_permlane32_swap between the wave's halves --
+// followed by a transpose inside each quadrant, and the quadrant pairs go through the same 32 x 64 LDS tile one after
+// the other.
+//
+// Work items: window pairs of the images whose record selects this body, numbered image by image with every image's
+// own tile size (prefix sum over the batch's pb_fft_sel records inside the kernel: no idle slots for images with larger
+// tiles, no host read-back); workgroup b runs on XCD b % 8 (observed, used for speed only) and every XCD takes one
+// contiguous run of pairs, so neighbouring windows share their halos in that XCD's L2.
+// No MFMA, no library FFT.
+
+#include <algorithm>
+#include <type_traits>
+
+#include "conv_fft_common.h"
+
+namespace {
+
+constexpr int WF_WAVES = 4;                          // independent waves per workgroup
+constexpr int WF_ROWS = 32;                          // LDS tile rows per wave (half a window pair)
+constexpr size_t kWfLdsWave = sizeof(float2) * WF_ROWS * FT_P;
+
+// cos / sin (2 pi m / 64): indexed with compile-time constants only (the values fold into scalar moves)
+static __device__ const float kC64[64] = {
+    1.0f, 0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f, 0.9238795042037964f, 0.8819212913513184f,
+    0.8314695954322815f, 0.7730104327201843f, 0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f,
+    0.4713967442512512f, 0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f, 0.0f,
+    -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f, -0.3826834261417389f, -0.4713967442512512f,
+    -0.5555702447891235f, -0.6343932747840881f, -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f,
+    -0.8819212913513184f, -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f, -1.0f,
+    -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f, -0.9238795042037964f, -0.8819212913513184f,
+    -0.8314695954322815f, -0.7730104327201843f, -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f,
+    -0.4713967442512512f, -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f, 0.0f,
+    0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f, 0.3826834261417389f, 0.4713967442512512f,
+    0.5555702447891235f, 0.6343932747840881f, 0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f,
+    0.8819212913513184f, 0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f};
+static __device__ const float kS64[64] = {
+    0.0f, 0.0980171412229538f, 0.19509032368659973f, 0.290284663438797f, 0.3826834261417389f, 0.4713967442512512f,
+    0.5555702447891235f, 0.6343932747840881f, 0.7071067690849304f, 0.7730104327201843f, 0.8314695954322815f,
+    0.8819212913513184f, 0.9238795042037964f, 0.9569403529167175f, 0.9807852506637573f, 0.9951847195625305f, 1.0f,
+    0.9951847195625305f, 0.9807852506637573f, 0.9569403529167175f, 0.9238795042037964f, 0.8819212913513184f,
+    0.8314695954322815f, 0.7730104327201843f, 0.7071067690849304f, 0.6343932747840881f, 0.5555702447891235f,
+    0.4713967442512512f, 0.3826834261417389f, 0.290284663438797f, 0.19509032368659973f, 0.0980171412229538f, 0.0f,
+    -0.0980171412229538f, -0.19509032368659973f, -0.290284663438797f, -0.3826834261417389f, -0.4713967442512512f,
+    -0.5555702447891235f, -0.6343932747840881f, -0.7071067690849304f, -0.7730104327201843f, -0.8314695954322815f,
+    -0.8819212913513184f, -0.9238795042037964f, -0.9569403529167175f, -0.9807852506637573f, -0.9951847195625305f, -1.0f,
+    -0.9951847195625305f, -0.9807852506637573f, -0.9569403529167175f, -0.9238795042037964f, -0.8819212913513184f,
+    -0.8314695954322815f, -0.7730104327201843f, -0.7071067690849304f, -0.6343932747840881f, -0.5555702447891235f,
+    -0.4713967442512512f, -0.3826834261417389f, -0.290284663438797f, -0.19509032368659973f, -0.0980171412229538f};
+
+// ---------------------------------------------------------------------------------------------
+// 64-point DFT of a line held in registers.  Index split n = 8 n1 + n2 -> k = k1 + 8 k2 (decimation in frequency):
+// register 8 k1 + k2 of the transformed line holds frequency k1 + 8 k2 -- the order khat_kernel lays the spectrum out
+// in -- and the inverse runs the mirrored stages, so nothing is ever reordered.  Unnormalised (khat carries 1/4096).
+// ---------------------------------------------------------------------------------------------
+// forward stage 1 of group n2: registers 8 n1 + n2 over n1, then x W64^(n2 k1)
+template <int N2> __device__ __forceinline__ void fwd_stage1(cf (&v)[64]) {
+    cf a[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) a[n1] = v[8 * n1 + N2];
+    pbfft::dft_small<8>(a);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        const int m = (N2 * k1) & 63;
+        v[8 * k1 + N2] = m ? cmul_s(a[k1], (cf){kC64[m], -kS64[m]}) : a[k1];
+    }
+}
+// forward stage 2 of group k1: registers 8 k1 + n2 over n2
+template <int K1> __device__ __forceinline__ void fwd_stage2(cf (&v)[64]) {
+    cf b[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) b[n2] = v[8 * K1 + n2];
+    pbfft::dft_small<8>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[8 * K1 + k2] = b[k2];
+}
+// inverse stage 2 of group k1, then x conj W64^(n2 k1)
+template <int K1> __device__ __forceinline__ void inv_stage2(cf (&v)[64]) {
+    cf b[8];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) b[k2] = v[8 * K1 + k2];
+    idft8(b);
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) {
+        const int m = (n2 * K1) & 63;
+        v[8 * K1 + n2] = m ? cmul_conj_s(b[n2], (cf){kC64[m], -kS64[m]}) : b[n2];
+    }
+}
+// the two of them around the product with the real spectrum (group k1 of a transformed row)
+template <int K1> __device__ __forceinline__ void centre_stage(cf (&v)[64], const float (&kh)[64]) {
+    cf b[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) b[n2] = v[8 * K1 + n2];
+    pbfft::dft_small<8>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) b[k2] = b[k2] * kh[8 * K1 + k2];
+    idft8(b);
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) {
+        const int m = (n2 * K1) & 63;
+        v[8 * K1 + n2] = m ? cmul_conj_s(b[n2], (cf){kC64[m], -kS64[m]}) : b[n2];
+    }
+}
+// inverse stage 1 of group n2: its eight outputs are registers (window rows, in the last pass) 8 n1 + n2
+template <int N2> __device__ __forceinline__ void inv_stage1(cf (&v)[64]) {
+    cf a[8];
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) a[k1] = v[8 * k1 + N2];
+    idft8(a);
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) v[8 * n1 + N2] = a[n1];
+}
+#define PB_EACH8(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
+__device__ __forceinline__ void fft64_fwd(cf (&v)[64]) {
+#define PB_S(i) fwd_stage1<i>(v);
+    PB_EACH8(PB_S)
+#undef PB_S
+#define PB_S(i) fwd_stage2<i>(v);
+    PB_EACH8(PB_S)
+#undef PB_S
+}
+__device__ __forceinline__ void fft64_fwd_stage1(cf (&v)[64]) {
+#define PB_S(i) fwd_stage1<i>(v);
+    PB_EACH8(PB_S)
+#undef PB_S
+}
+__device__ __forceinline__ void fft64_centre(cf (&v)[64], const float (&kh)[64]) {
+#define PB_S(i) centre_stage<i>(v, kh);
+    PB_EACH8(PB_S)
+#undef PB_S
+}
+__device__ __forceinline__ void fft64_inv_stage1(cf (&v)[64]) {
+#define PB_S(i) inv_stage1<i>(v);
+    PB_EACH8(PB_S)
+#undef PB_S
+}
+__device__ __forceinline__ void fft64_inv_stage2(cf (&v)[64]) {
+#define PB_S(i) inv_stage2<i>(v);
+    PB_EACH8(PB_S)
+#undef PB_S
+}
+
+// v_permlane32_swap: lanes 32..63 of `hi_part` <-> lanes 0..31 of `lo_part`
+__device__ __forceinline__ void swap_halves(cf &hi_part, cf &lo_part) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(hi_part.x), __float_as_uint(lo_part.x), false, false);
+    const u2 y = __builtin_amdgcn_permlane32_swap(__float_as_uint(hi_part.y), __float_as_uint(lo_part.y), false, false);
+    hi_part = (cf){__uint_as_float(x[0]), __uint_as_float(y[0])};
+    lo_part = (cf){__uint_as_float(x[1]), __uint_as_float(y[1])};
+}
+
+// Transpose of the 64 x 64 matrix whose column `lane` sits in lane `lane`'s registers: afterwards lane l holds row l
+// (register c = column c).  The off-diagonal 32 x 32 quadrants swap between the wave's halves, then each half
+// transposes its two quadrants through the 32 x 64 LDS tile, one quadrant pair after the other.  The same routine
+// takes the matrix back.  STRIDED: the reads of a quadrant pair are issued in the order the next stage consumes them
+// (register 8 n1 + n2, n2-major).  Row pitch 65 complex values: the writes (consecutive lanes, consecutive 8-byte
+// words) and the reads (lane i reads word 65 i + c: 32 different banks pairs per half wave) are conflict-free.
+__device__ __forceinline__ void transpose64(cf (&v)[64], float2 *Z, int lane) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) swap_halves(v[r], v[32 + r]);
+    const float2 *rd = Z + (lane & 31) * FT_P + (lane & 32);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) Z[r * FT_P + lane] = pbfft::to_f2(v[32 * h + r]);
+        wave_lds_fence();
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[32 * h + c] = pbfft::to_cf(rd[c]);
+        wave_lds_fence();
+    }
+}
+
+// Geometry of a pass, per window halo class (index R / 4 - 1), computed on the host.
+struct WGeom {
+    int pairs_x[3], njobs[3];               // window pairs per row, per plane
+    float inv_pairs_x[3], inv_njobs[3];
+};
+
+// inclusive prefix sum over the wave
+__device__ __forceinline__ int wave_scan(int x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(x, d, 64);
+        if (lane >= d) x += t;
+    }
+    return x;
+}
+
+#ifdef PB_WF_TRACE
+// Debug build only (python -m polyblur_amd.build with PB_EXTRA_FLAGS=-DPB_WF_TRACE): shader-clock stamps of the first
+// waves' phases, read back with pb_debug_wf_trace (tools/wf_trace.py).
+constexpr int kTraceWaves = 8192, kTraceStamps = 12;
+__device__ unsigned long long g_wf_trace[kTraceWaves * kTraceStamps];
+#define PB_T(i) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PB_TWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define PB_T(i)
+#define PB_TWAIT()
+#endif
+
+// 16 bytes per lane from a buffer straight into LDS (1 KiB per wave instruction, no staging registers): lane i's bytes
+// land at lds + 16 i.  An offset at or beyond the descriptor's size writes zeros.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ lds_char *lds_ptr(void *p) { return (lds_char *)p; }
+template <int IMM> __device__ __forceinline__ void dma16(brsrc r, lds_char *dst, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)dst, 16, (int)voffset, soffset, IMM, 0);
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lds0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v ld_b128(brsrc r, unsigned voffset, int soffset) {
+    return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, soffset, 0));
+}
+__device__ __forceinline__ void st_b128(brsrc r, unsigned voffset, int soffset, f4v v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)voffset, soffset, 0);
+}
+
+// One window pair.  zb: the wave's LDS region (kWfLdsWave bytes); kp: the image's spectrum, [x position][y position].
+template <int R, bool FAST, typename TIn, typename TX, typename TOut>
+__device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, char *zb,
+                                          const float *kp, unsigned long long *tr) {
+    constexpr int T = FT_N - 2 * R;
+    PB_T(1);
+    float2 *Z = reinterpret_cast<float2 *>(zb);
+    float *Zf = reinterpret_cast<float *>(zb);
+    const OutRegion rg = out_region(a);
+    const int wy0 = rg.y_lo + ty * T - R;                       // window origin, padded coordinates
+    const int wxA = rg.x_lo + 2 * pxi * T - R, wxB = wxA + T;
+    const bool hasB = wxB + R < rg.x_hi;
+    const int lane = threadIdx.x & 63;
+    const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
+    const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
+    TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
+    cf v[64];
+
+    // ---- the window: lane = column, register = row ----
+    {
+        const brsrc rin = plane_rsrc(ipl, a.in_plane);
+        const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
+        const unsigned pitchb = (unsigned)a.in_pitch * (unsigned)sizeof(TIn);
+        if constexpr (FAST) {
+            // Interior fp32 pair on 16-byte boundaries: the union of the two windows (64 + T columns) goes global -> LDS in
+            // 16-byte pieces, half the rows at a time -- the rows of the first-stage groups n2 = 0..3, then those of
+            // n2 = 4..7, LDS rows of 128 floats: one wave instruction fills two of them -- and every lane picks its
+            // column's two samples per row from there.  (Four-byte loads straight into the registers cost one vector
+            // memory instruction per row and tile, 128 per pair instead of 32: the pass was bound by their issue.)
+            constexpr int C4 = (FT_N + T) / 4;
+            const int c = lane & 31;
+            const unsigned vo = c < C4 ? (unsigned)(lane >> 5) * pitchb + (unsigned)(wxA - lo + 4 * c) * 4u : kNoAccess;
+            const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
+            lds_char *zl = lds_ptr(zb);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int y0 = 8 * (k >> 1) + 2 * (k & 1) + 4 * h;
+                    dma16<0>(rin, zl + k * 1024, vo, (int)(row0 + (unsigned)y0 * pitchb));
+                }
+                wait_vm0();
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int y = 8 * (r >> 2) + (r & 3) + 4 * h;
+                    v[y] = (cf){Zf[r * 128 + lane], Zf[r * 128 + T + lane]};
+                }
+                wave_lds_fence();
+                wait_lds0();                                    // the next pieces may land on these rows
+            }
+        } else if (wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB) {
+            const unsigned colA = (unsigned)(wxA - lo + lane) * (unsigned)sizeof(TIn), colB = colA + T * (unsigned)sizeof(TIn);
+            const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                const int y = 8 * (q & 7) + (q >> 3);
+                const int so = (int)(row0 + (unsigned)y * pitchb);
+                v[y] = (cf){BufIO<TIn>::ld(rin, colA, so), BufIO<TIn>::ld(rin, colB, so)};
+            }
+        } else {
+            // border window: columns mapped through the boundary model once per lane, rows on the scalar side
+            const int ixa = map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad);
+            const int ixb = hasB ? map_axis(wxB + lane, a.W, a.in_kind, a.boundary, a.pad) : -1;
+            const unsigned colA = ixa >= 0 ? (unsigned)ixa * (unsigned)sizeof(TIn) : kNoAccess;
+            const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
+            const bool wrap = a.boundary == PB_WRAP;
+            const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(wy0, Hp)) : wy0;
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                const int y = 8 * (q & 7) + (q >> 3);
+                int p = base + y;
+                if (wrap) { while (p >= Hp) p -= Hp; }
+                const bool ok = wrap || (p >= 0 && p < Hp);
+                const int iy = ok ? (a.in_kind == SRC_VIRTUAL ? min(max(p - a.pad, 0), a.H - 1) : p) : 0;
+                const int so = (int)((unsigned)iy * pitchb);
+                v[y] = (cf){BufIO<TIn>::ld(rin, ok ? colA : kNoAccess, so), BufIO<TIn>::ld(rin, ok ? colB : kNoAccess, so)};
+            }
+        }
+    }
+    PB_T(2);
+    fft64_fwd(v);                                               // columns
+    PB_T(3);
+    transpose64(v, Z, lane);
+    PB_T(4);
+    {
+        // the image's spectrum (16 KB) goes global -> LDS while the first row stage runs; lane = transformed row py reads
+        // kh[px][py] for the eight px of each centre-stage group
+        wait_lds0();
+        const brsrc rk = plane_rsrc(kp, (long)FT_N * FT_N);
+        lds_char *zl = lds_ptr(zb);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dma16<0>(rk, zl + k * 1024, (unsigned)lane * 16u, k * 1024);
+        fft64_fwd_stage1(v);                                    // rows
+        wait_vm0();
+        PB_T(5);
+        float kh[64];
+#pragma unroll
+        for (int p = 0; p < 64; ++p) kh[p] = Zf[p * FT_N + lane];
+        fft64_centre(v, kh);                                    // stage 2, x spectrum, inverse stage 2
+        wave_lds_fence();
+    }
+    fft64_inv_stage1(v);
+    PB_T(6);
+    transpose64(v, Z, lane);
+    PB_T(7);
+
+    // ---- epilogue: lane = window column again ----
+    const bool virt = a.x_kind == SRC_VIRTUAL;
+    const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
+    const int xmax = virt ? a.W - 1 : Wp - 1, ymax = virt ? a.H - 1 : Hp - 1, xsh = virt ? a.pad : 0;
+    const unsigned xpitchb = (unsigned)a.x_pitch * (unsigned)sizeof(TX), opitchb = (unsigned)a.out_pitch * (unsigned)sizeof(TOut);
+    const brsrc rx = plane_rsrc(xpl, a.x_plane);
+    const brsrc ro = plane_rsrc(opl, a.out_plane);
+    const bool colin = lane >= R && lane < FT_N - R;
+    const float sc = a.scale, cfx = a.coef;
+    const bool cl = a.clamp01 != 0;
+    const int oy0 = wy0 + R, oxA = wxA + R;
+    if constexpr (FAST) {
+        // Complete interior pair, plain Horner epilogue, everything on 16-byte boundaries: the 2T-wide block of outputs goes
+        // through an LDS tile (written by columns, read back as 16-byte row pieces), NR rows at a time, so that the
+        // x operand arrives and the result leaves in 16-byte accesses: 2 NK vector memory instructions per NR rows instead
+        // of 4 NR.  The x operand of the round after next is requested when a round has been stored.
+        constexpr int NRND = R == 12 ? 2 : 4, NR = T / NRND, PT = 2 * T, C = PT / 4, NK = (NR * C + 63) / 64;
+        static_assert(NR * NRND == T, "rounds must tile the rows");
+        f4v xq[2][NK];
+        const int xso = (int)((unsigned)(oy0 - xsh) * xpitchb + (unsigned)(oxA - xsh) * 4u);
+        const int oso = (int)((unsigned)(oy0 - oo) * opitchb + (unsigned)(oxA - oo) * 4u);
+        auto request = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < NRND) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int e = 64 * k + lane, rl = e / C, ch = e - rl * C;
+                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * xpitchb + (unsigned)ch * 16u : kNoAccess;
+                    xq[q & 1][k] = ld_b128(rx, vo, xso);
+                }
+            }
+        };
+        auto round = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < NRND) {
+                if (colin) {
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        Zf[i * PT + lane - R] = v[R + q * NR + i].x; Zf[i * PT + T + lane - R] = v[R + q * NR + i].y;
+                    }
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int e = 64 * k + lane, rl = e / C, ch = e - rl * C;
+                    const f4v acc = *reinterpret_cast<const f4v *>(Zf + min(rl, NR - 1) * PT + 4 * ch);
+                    const f4v x4 = xq[q & 1][k];
+                    f4v o;
+                    o.x = fmaf(sc, acc.x, cfx * x4.x); o.y = fmaf(sc, acc.y, cfx * x4.y);
+                    o.z = fmaf(sc, acc.z, cfx * x4.z); o.w = fmaf(sc, acc.w, cfx * x4.w);
+                    if (cl) {
+                        o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
+                        o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
+                    }
+                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * opitchb + (unsigned)ch * 16u : kNoAccess;
+                    st_b128(ro, vo, oso, o);
+                }
+                wave_lds_fence();
+            }
+        };
+        typedef std::integral_constant<int, 0> Q0; typedef std::integral_constant<int, 1> Q1; typedef std::integral_constant<int, 2> Q2;
+        typedef std::integral_constant<int, 3> Q3; typedef std::integral_constant<int, 4> Q4; typedef std::integral_constant<int, 5> Q5;
+        fft64_inv_stage2(v);                                    // columns
+        request(Q0{});
+        fft64_inv_stage1(v);
+        PB_T(8);
+        request(Q1{});
+        round(Q0{}); request(Q2{});
+        round(Q1{}); request(Q3{});
+        round(Q2{}); request(Q4{});
+        round(Q3{}); request(Q5{});
+        PB_T(9);
+        PB_TWAIT();
+        PB_T(10);
+        return;
+    }
+    (void)oxA;
+    const int pxA = wxA + lane, pxB = wxB + lane;
+    const bool okA = colin && pxA < rg.x_hi, okB = colin && hasB && pxB < rg.x_hi;
+    const unsigned xoffA = okA ? (unsigned)min(max(pxA - xsh, 0), xmax) * (unsigned)sizeof(TX) : kNoAccess;
+    const unsigned xoffB = okB ? (unsigned)min(max(pxB - xsh, 0), xmax) * (unsigned)sizeof(TX) : kNoAccess;
+    const unsigned ooffA = okA ? (unsigned)(pxA - oo) * (unsigned)sizeof(TOut) : kNoAccess;
+    const unsigned ooffB = okB ? (unsigned)(pxB - oo) * (unsigned)sizeof(TOut) : kNoAccess;
+    const bool taper = a.epilogue == EPI_TAPER;
+    float txa = 0.f, txb = 0.f;
+    if (taper) {
+        txa = taper_weight(info->acorr_x, min(max(pxA, 0), Wp - 1), Wp);
+        txb = taper_weight(info->acorr_x, min(max(pxB, 0), Wp - 1), Wp);
+    }
+    // Border pairs, the taper blend, narrower types: the last transform's second stage finishes the window rows 8 n1 + n2
+    // group by group (n2 = 0 .. 7); each group's rows go through the epilogue and to memory at once, and the x operand
+    // travels in a ring four groups deep -- the loads of group n2 + 4 are issued when group n2 has been stored.
+    float xa[8][8], xb[8][8];
+    auto request = [&](auto n2c) {
+        constexpr int n2 = decltype(n2c)::value;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int y = 8 * n1 + n2;
+            if (y >= R && y < FT_N - R) {
+                const int xr = min(max(wy0 + y - xsh, 0), ymax);
+                const int so = (int)((unsigned)xr * xpitchb);
+                xa[n2][n1] = BufIO<TX>::ld(rx, xoffA, so); xb[n2][n1] = BufIO<TX>::ld(rx, xoffB, so);
+            }
+        }
+    };
+    auto finish = [&](auto n2c) {
+        constexpr int n2 = decltype(n2c)::value;
+        inv_stage1<n2>(v);
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int y = 8 * n1 + n2;
+            if (y >= R && y < FT_N - R) {
+                const int py = wy0 + y;
+                if (py < rg.y_hi) {
+                    float ra, rb;
+                    if (taper) {
+                        const float tyw = taper_weight(info->acorr_y, py, Hp);
+                        const float ala = tyw * txa, alb = tyw * txb;
+                        ra = ala * xa[n2][n1] + (1.f - ala) * v[y].x; rb = alb * xb[n2][n1] + (1.f - alb) * v[y].y;
+                    } else {
+                        ra = fmaf(sc, v[y].x, cfx * xa[n2][n1]); rb = fmaf(sc, v[y].y, cfx * xb[n2][n1]);
+                    }
+                    if (cl) { ra = fminf(fmaxf(ra, 0.f), 1.f); rb = fminf(fmaxf(rb, 0.f), 1.f); }
+                    const int so = (int)((unsigned)(py - oo) * opitchb);
+                    BufIO<TOut>::st(ro, ooffA, so, ra); BufIO<TOut>::st(ro, ooffB, so, rb);
+                }
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3; typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 5> I5;
+    typedef std::integral_constant<int, 6> I6; typedef std::integral_constant<int, 7> I7;
+    request(I0{}); request(I1{}); request(I2{}); request(I3{});
+    fft64_inv_stage2(v);                                        // columns
+    PB_T(8);
+    finish(I0{}); request(I4{});
+    finish(I1{}); request(I5{});
+    finish(I2{}); request(I6{});
+    finish(I3{}); request(I7{});
+    finish(I4{}); finish(I5{}); finish(I6{}); finish(I7{});
+    PB_T(9);
+    PB_TWAIT();
+    PB_T(10);
+}
+
+// Whether a pair takes the all-16-byte path: fp32 everywhere, plain Horner epilogue, both windows inside the source
+// without boundary mapping, both tiles complete inside the output region, the x operand addressed without clamping, and
+// rows / origins on 16-byte boundaries.
+template <int R, typename TIn, typename TX, typename TOut>
+__device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi) {
+    if (sizeof(TIn) != 4 || sizeof(TX) != 4 || sizeof(TOut) != 4 || a.epilogue != EPI_HORNER) return false;
+    constexpr int T = FT_N - 2 * R;
+    const OutRegion rg = out_region(a);
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
+    const int wy0 = rg.y_lo + ty * T - R, wxA = rg.x_lo + 2 * pxi * T - R, wxB = wxA + T;
+    const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
+    const bool virt = a.x_kind == SRC_VIRTUAL;
+    const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0, xsh = virt ? a.pad : 0;
+    const int xw = virt ? a.W : Wp, xh = virt ? a.H : Hp;
+    const int oy0 = wy0 + R, oxA = wxA + R;
+    return wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && oy0 + T <= rg.y_hi && oxA + 2 * T <= rg.x_hi &&
+           oy0 - xsh >= 0 && oxA - xsh >= 0 && oy0 + T - xsh <= xh && oxA + 2 * T - xsh <= xw &&
+           ((a.in_pitch | a.x_pitch | a.out_pitch | (wxA - lo) | (oxA - xsh) | (oxA - oo)) & 3) == 0;
+}
+
+// One wave per window pair.  Jobs of image i = its window pairs with its own tile size x planes, 0 when another body does
+// the image; the waves number them with an inclusive prefix sum over the batch's records (64 images per round).
+// Workgroup b runs on XCD b % 8: XCD x takes the contiguous run [x per, (x + 1) per) of the job list.
+template <typename TIn, typename TX, typename TOut>
+__global__ __launch_bounds__(64 * WF_WAVES, 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char zall[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned long long *tr = nullptr;
+#ifdef PB_WF_TRACE
+    { const int gw = blockIdx.x * WF_WAVES + wave; if (gw < kTraceWaves) tr = g_wf_trace + (long)gw * kTraceStamps; }
+    PB_T(0);
+#endif
+    char *zb = zall + wave * kWfLdsWave;
+    const int B = a.P / a.C;
+    auto jobs_of = [&](int i) -> int {
+        if (i >= B) return 0;
+        const pb_fft_sel s = a.fsel[i];
+        if (!s.use_fft) return 0;
+        return (s.rf <= 4 ? g.njobs[0] : (s.rf <= 8 ? g.njobs[1] : g.njobs[2])) * a.C;
+    };
+    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3) * WF_WAVES + wave;
+    int img = 0, local = 0;
+    if (B == 1) {
+        const int total = __builtin_amdgcn_readfirstlane(jobs_of(0));
+        const int per = (total + 7) >> 3;
+        local = xcd * per + slot;
+        if (slot >= per || local >= total) return;
+    } else {
+        const int n0 = jobs_of(lane), incl0 = wave_scan(n0, lane);
+        int total = __builtin_amdgcn_readlane(incl0, 63);
+        for (int c0 = 64; c0 < B; c0 += 64) total += __builtin_amdgcn_readlane(wave_scan(jobs_of(c0 + lane), lane), 63);
+        const int per = (total + 7) >> 3;
+        const int j = xcd * per + slot;
+        if (slot >= per || j >= total) return;
+        const unsigned long long m = __ballot(incl0 > j);
+        if (m) {
+            const int l = __builtin_ctzll(m);
+            img = l;
+            local = j - (__builtin_amdgcn_readlane(incl0, l) - __builtin_amdgcn_readlane(n0, l));
+        } else {
+            int base = __builtin_amdgcn_readlane(incl0, 63);
+            for (int c0 = 64; c0 < B; c0 += 64) {
+                const int n = jobs_of(c0 + lane), incl = wave_scan(n, lane);
+                const unsigned long long m2 = __ballot(base + incl > j);
+                if (m2) {
+                    const int l = __builtin_ctzll(m2);
+                    img = c0 + l;
+                    local = j - base - (__builtin_amdgcn_readlane(incl, l) - __builtin_amdgcn_readlane(n, l));
+                    break;
+                }
+                base += __builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+        img = __builtin_amdgcn_readfirstlane(img); local = __builtin_amdgcn_readfirstlane(local);
+    }
+    const PB_CONSTANT pb_fft_sel *sel = as_constant(a.fsel + img);
+    const int R = sel->rf, c = R <= 4 ? 0 : (R <= 8 ? 1 : 2);
+    const int pl = __builtin_amdgcn_readfirstlane(div_small(local, g.inv_njobs[c])), pair = local - pl * g.njobs[c];
+    const int ty = __builtin_amdgcn_readfirstlane(div_small(pair, g.inv_pairs_x[c])), pxi = pair - ty * g.pairs_x[c];
+    const int plane = img * a.C + pl;
+    const float *kp = a.khat + (long)img * (FT_N * FT_N);
+    const pb_blur_info *info = a.info + img;
+#define PB_RUN(RR)                                                                                  \
+    if (pair_is_fast<RR, TIn, TX, TOut>(a, ty, pxi)) wave_pair<RR, true, TIn, TX, TOut>(a, info, plane, ty, pxi, zb, kp, tr); \
+    else wave_pair<RR, false, TIn, TX, TOut>(a, info, plane, ty, pxi, zb, kp, tr);
+    if (c == 2) { PB_RUN(12) } else if (c == 1) { PB_RUN(8) } else { PB_RUN(4) }
+#undef PB_RUN
+}
+
+bool wfft_geometry(const ConvPass &p, WGeom &g, long &total_max) {
+    FftGeom f;
+    if (!fft_geometry(p, f)) return false;
+    for (int c = 0; c < 3; ++c) {
+        g.pairs_x[c] = f.pairs_x[c]; g.njobs[c] = f.njobs[c];
+        g.inv_pairs_x[c] = f.inv_pairs_x[c]; g.inv_njobs[c] = 1.0f / (float)f.njobs[c];
+    }
+    total_max = (long)f.njobs[2] * p.P;
+    return total_max > 0 && total_max <= (1L << 22);
+}
+
+template <typename TIn, typename TX, typename TOut>
+int launch_wfft_typed(pb_ctx *ctx, const ConvPass &p) {
+    WGeom g;
+    long total_max = 0;
+    if (!wfft_geometry(p, g, total_max)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: too many windows for the tile-spectrum body");
+    const long per_max = (total_max + 7) / 8;
+    const long groups = 8 * ((per_max + WF_WAVES - 1) / WF_WAVES);
+    hipLaunchKernelGGL((conv_wfft_kernel<TIn, TX, TOut>), dim3((unsigned)groups), dim3(64 * WF_WAVES), kWfLdsWave * WF_WAVES,
+                       ctx->stream, p, g);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+}  // namespace
+
+#ifdef PB_WF_TRACE
+extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
+    if (n_waves > kTraceWaves) n_waves = kTraceWaves;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wf_trace), sizeof(unsigned long long) * kTraceStamps * n_waves);
+}
+#endif
+
+int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
+    ProfScope prof(ctx, PB_PROF_CONV_FFT);
+    const int key = p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype;
+    switch (key) {
+        case 0: return launch_wfft_typed<float, float, float>(ctx, p);
+        default: return PB_ERR_UNSUPPORTED;         // (the caller falls back to the workgroup body)
+    }
+}

@@ -23,6 +23,9 @@ run grbm GRBM_GUI_ACTIVE GRBM_TA_BUSY
 run tcc1 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
 run tcc2 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run tcc3 TCC_WRITE_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_sum
+run sq3 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_IFETCH SQ_IFETCH_LEVEL
+run sq4 SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL
+run sqc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQC_TC_STALL SQC_ICACHE_BUSY_CYCLES
 run tcp1 TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
 python tools/pmc_report.py "$OUT" "$PAT" 20 > "$OUT/report.txt" 2>&1
 cat "$OUT/report.txt"
