@@ -279,25 +279,40 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
             // memory instruction per row and tile, 128 per pair instead of 32: the pass was bound by their issue.)
             constexpr int C4 = (FT_N + T) / 4;
             const int c = lane & 31;
-            const unsigned vo = c < C4 ? (unsigned)(lane >> 5) * pitchb + (unsigned)(wxA - lo + 4 * c) * 4u : kNoAccess;
+            // (lanes past the union's last piece repeat it rather than go out of range: see the note at dma16)
+            const unsigned vo = (unsigned)(lane >> 5) * pitchb + (unsigned)(wxA - lo + 4 * min(c, C4 - 1)) * 4u;
             const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
             lds_char *zl = lds_ptr(zb);
+            // (the rows of groups 0..3 go straight into LDS; those of groups 4..7 are requested at the same time into
+            // registers and pass through the same LDS rows once the first half has been picked up: one memory latency
+            // per pair, not two)
+            f4v late[16];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int y0 = 8 * (k >> 1) + 2 * (k & 1) + 4 * h;
-                    dma16<0>(rin, zl + k * 1024, vo, (int)(row0 + (unsigned)y0 * pitchb));
-                }
-                wait_vm0();
-#pragma unroll
-                for (int r = 0; r < 32; ++r) {
-                    const int y = 8 * (r >> 2) + (r & 3) + 4 * h;
-                    v[y] = (cf){Zf[r * 128 + lane], Zf[r * 128 + T + lane]};
-                }
-                wave_lds_fence();
-                wait_lds0();                                    // the next pieces may land on these rows
+            for (int k = 0; k < 16; ++k) {
+                const int y0 = 8 * (k >> 1) + 2 * (k & 1);
+                dma16<0>(rin, zl + k * 1024, vo, (int)(row0 + (unsigned)y0 * pitchb));
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int y0 = 8 * (k >> 1) + 2 * (k & 1) + 4;
+                late[k] = ld_b128(rin, vo, (int)(row0 + (unsigned)y0 * pitchb));
+            }
+            wait_vm0();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int y = 8 * (r >> 2) + (r & 3);
+                v[y] = (cf){Zf[r * 128 + lane], Zf[r * 128 + T + lane]};
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f4v *>(Zf + k * 256 + lane * 4) = late[k];
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int y = 8 * (r >> 2) + (r & 3) + 4;
+                v[y] = (cf){Zf[r * 128 + lane], Zf[r * 128 + T + lane]};
+            }
+            wave_lds_fence();
         } else if (wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB) {
             const unsigned colA = (unsigned)(wxA - lo + lane) * (unsigned)sizeof(TIn), colB = colA + T * (unsigned)sizeof(TIn);
             const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
@@ -370,7 +385,9 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         // through an LDS tile (written by columns, read back as 16-byte row pieces), NR rows at a time, so that the
         // x operand arrives and the result leaves in 16-byte accesses: 2 NK vector memory instructions per NR rows instead
         // of 4 NR.  The x operand of the round after next is requested when a round has been stored.
-        constexpr int NRND = R == 12 ? 2 : 4, NR = T / NRND, PT = 2 * T, C = PT / 4, NK = (NR * C + 63) / 64;
+                constexpr int NRND = R == 12 ? 2 : (R == 8 ? 3 : 4);
+        constexpr int NR = T / NRND, C = 2 * T / 4, NK = (NR * C + 63) / 64;
+        constexpr int PT = 2 * T;
         static_assert(NR * NRND == T, "rounds must tile the rows");
         f4v xq[2][NK];
         const int xso = (int)((unsigned)(oy0 - xsh) * xpitchb + (unsigned)(oxA - xsh) * 4u);
@@ -389,11 +406,11 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         auto round = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if constexpr (q < NRND) {
-                if (colin) {
+                {
+                    // (halo lanes write to a scratch copy of the tile behind it rather than sit out under an exec mask)
+                    float *zt = Zf + (colin ? lane - R : NR * PT + lane);
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        Zf[i * PT + lane - R] = v[R + q * NR + i].x; Zf[i * PT + T + lane - R] = v[R + q * NR + i].y;
-                    }
+                    for (int i = 0; i < NR; ++i) { zt[i * PT] = v[R + q * NR + i].x; zt[i * PT + T] = v[R + q * NR + i].y; }
                 }
                 wave_lds_fence();
 #pragma unroll
