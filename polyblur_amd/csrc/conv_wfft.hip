@@ -43,7 +43,13 @@
 
 namespace {
 
-constexpr int WF_WAVES = 4;                          // independent waves per workgroup
+// timing-only ablations (wrong results; PB_EXTRA_FLAGS=-DPB_ABL=bits): 1 no window loads, 2 no spectrum DMA, 4 no x loads /
+// stores, 8 no transposes, 16 no butterflies
+#ifndef PB_ABL
+#define PB_ABL 0
+#endif
+
+constexpr int WF_WAVES = 1;                          // waves per workgroup (each wave is independent: no barriers)
 constexpr int WF_ROWS = 32;                          // LDS tile rows per wave (half a window pair)
 constexpr size_t kWfLdsWave = sizeof(float2) * WF_ROWS * FT_P;
 
@@ -80,12 +86,14 @@ static __device__ const float kS64[64] = {
 // register 8 k1 + k2 of the transformed line holds frequency k1 + 8 k2 -- the order khat_kernel lays the spectrum out
 // in -- and the inverse runs the mirrored stages, so nothing is ever reordered.  Unnormalised (khat carries 1/4096).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bf8(cf (&v)[8]) { if constexpr (!(PB_ABL & 16)) pbfft::dft_small<8>(v); }
+__device__ __forceinline__ void ibf8(cf (&v)[8]) { if constexpr (!(PB_ABL & 16)) idft8(v); }
 // forward stage 1 of group n2: registers 8 n1 + n2 over n1, then x W64^(n2 k1)
 template <int N2> __device__ __forceinline__ void fwd_stage1(cf (&v)[64]) {
     cf a[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) a[n1] = v[8 * n1 + N2];
-    pbfft::dft_small<8>(a);
+    bf8(a);
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) {
         const int m = (N2 * k1) & 63;
@@ -97,7 +105,7 @@ template <int K1> __device__ __forceinline__ void fwd_stage2(cf (&v)[64]) {
     cf b[8];
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) b[n2] = v[8 * K1 + n2];
-    pbfft::dft_small<8>(b);
+    bf8(b);
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) v[8 * K1 + k2] = b[k2];
 }
@@ -106,7 +114,7 @@ template <int K1> __device__ __forceinline__ void inv_stage2(cf (&v)[64]) {
     cf b[8];
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) b[k2] = v[8 * K1 + k2];
-    idft8(b);
+    ibf8(b);
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) {
         const int m = (n2 * K1) & 63;
@@ -118,10 +126,10 @@ template <int K1> __device__ __forceinline__ void centre_stage(cf (&v)[64], cons
     cf b[8];
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) b[n2] = v[8 * K1 + n2];
-    pbfft::dft_small<8>(b);
+    bf8(b);
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) b[k2] = b[k2] * kh[8 * K1 + k2];
-    idft8(b);
+    ibf8(b);
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) {
         const int m = (n2 * K1) & 63;
@@ -133,7 +141,7 @@ template <int N2> __device__ __forceinline__ void inv_stage1(cf (&v)[64]) {
     cf a[8];
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) a[k1] = v[8 * k1 + N2];
-    idft8(a);
+    ibf8(a);
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) v[8 * n1 + N2] = a[n1];
 }
@@ -183,6 +191,7 @@ __device__ __forceinline__ void swap_halves(cf &hi_part, cf &lo_part) {
 // (register 8 n1 + n2, n2-major).  Row pitch 65 complex values: the writes (consecutive lanes, consecutive 8-byte
 // words) and the reads (lane i reads word 65 i + c: 32 different banks pairs per half wave) are conflict-free.
 __device__ __forceinline__ void transpose64(cf (&v)[64], float2 *Z, int lane) {
+    if constexpr (PB_ABL & 8) return;
 #pragma unroll
     for (int r = 0; r < 32; ++r) swap_halves(v[r], v[32 + r]);
     const float2 *rd = Z + (lane & 31) * FT_P + (lane & 32);
@@ -216,13 +225,15 @@ __device__ __forceinline__ int wave_scan(int x, int lane) {
 #ifdef PB_WF_TRACE
 // Debug build only (python -m polyblur_amd.build with PB_EXTRA_FLAGS=-DPB_WF_TRACE): shader-clock stamps of the first
 // waves' phases, read back with pb_debug_wf_trace (tools/wf_trace.py).
-constexpr int kTraceWaves = 8192, kTraceStamps = 12;
+constexpr int kTraceWaves = 8192, kTraceStamps = 14;
 __device__ unsigned long long g_wf_trace[kTraceWaves * kTraceStamps];
 #define PB_T(i) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define PB_TWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define PB_TRT(i) do { if (tr) tr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PB_T(i)
 #define PB_TWAIT()
+#define PB_TRT(i)
 #endif
 
 // 16 bytes per lane from a buffer straight into LDS (1 KiB per wave instruction, no staging registers): lane i's bytes
@@ -271,7 +282,10 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         const brsrc rin = plane_rsrc(ipl, a.in_plane);
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
         const unsigned pitchb = (unsigned)a.in_pitch * (unsigned)sizeof(TIn);
-        if constexpr (FAST) {
+        if constexpr (FAST && (PB_ABL & 1)) {
+#pragma unroll
+            for (int y = 0; y < 64; ++y) v[y] = (cf){(float)(lane + y), (float)(lane - y)};
+        } else if constexpr (FAST) {
             // Interior fp32 pair on 16-byte boundaries: the union of the two windows (64 + T columns) goes global -> LDS in
             // 16-byte pieces, half the rows at a time -- the rows of the first-stage groups n2 = 0..3, then those of
             // n2 = 4..7, LDS rows of 128 floats: one wave instruction fills two of them -- and every lane picks its
@@ -354,7 +368,7 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         const brsrc rk = plane_rsrc(kp, (long)FT_N * FT_N);
         lds_char *zl = lds_ptr(zb);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) dma16<0>(rk, zl + k * 1024, (unsigned)lane * 16u, k * 1024);
+        for (int k = 0; k < ((PB_ABL & 2) ? 0 : 16); ++k) dma16<0>(rk, zl + k * 1024, (unsigned)lane * 16u, k * 1024);
         fft64_fwd_stage1(v);                                    // rows
         wait_vm0();
         PB_T(5);
@@ -399,7 +413,7 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                 for (int k = 0; k < NK; ++k) {
                     const int e = 64 * k + lane, rl = e / C, ch = e - rl * C;
                     const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * xpitchb + (unsigned)ch * 16u : kNoAccess;
-                    xq[q & 1][k] = ld_b128(rx, vo, xso);
+                    if constexpr (PB_ABL & 4) xq[q & 1][k] = (f4v){1.f, 2.f, 3.f, (float)lane}; else xq[q & 1][k] = ld_b128(rx, vo, xso);
                 }
             }
         };
@@ -426,7 +440,7 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                         o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
                     }
                     const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * opitchb + (unsigned)ch * 16u : kNoAccess;
-                    st_b128(ro, vo, oso, o);
+                    if constexpr (PB_ABL & 4) { if (o.x == 123.456f) st_b128(ro, vo, oso, o); } else st_b128(ro, vo, oso, o);
                 }
                 wave_lds_fence();
             }
@@ -445,6 +459,7 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         PB_T(9);
         PB_TWAIT();
         PB_T(10);
+        PB_TRT(13);
         return;
     }
     (void)oxA;
@@ -514,6 +529,7 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
     PB_T(9);
     PB_TWAIT();
     PB_T(10);
+    PB_TRT(13);
 }
 
 // Whether a pair takes the all-16-byte path: fp32 everywhere, plain Horner epilogue, both windows inside the source
@@ -540,7 +556,7 @@ __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi)
 // the image; the waves number them with an inclusive prefix sum over the batch's records (64 images per round).
 // Workgroup b runs on XCD b % 8: XCD x takes the contiguous run [x per, (x + 1) per) of the job list.
 template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(64 * WF_WAVES, 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
+__global__ __launch_bounds__(64 * WF_WAVES, 2 / (4 / WF_WAVES) > 0 ? 2 : 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
     extern __shared__ __attribute__((aligned(16))) char zall[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -548,6 +564,7 @@ __global__ __launch_bounds__(64 * WF_WAVES, 2) void conv_wfft_kernel(const ConvP
 #ifdef PB_WF_TRACE
     { const int gw = blockIdx.x * WF_WAVES + wave; if (gw < kTraceWaves) tr = g_wf_trace + (long)gw * kTraceStamps; }
     PB_T(0);
+    PB_TRT(12);
 #endif
     char *zb = zall + wave * kWfLdsWave;
     const int B = a.P / a.C;
@@ -560,7 +577,9 @@ __global__ __launch_bounds__(64 * WF_WAVES, 2) void conv_wfft_kernel(const ConvP
     const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3) * WF_WAVES + wave;
     int img = 0, local = 0;
     if (B == 1) {
-        const int total = __builtin_amdgcn_readfirstlane(jobs_of(0));
+        // (one image: its record is read on the scalar side -- no trip through the vector memory queue)
+        const PB_CONSTANT pb_fft_sel *s0 = as_constant(a.fsel);
+        const int total = s0->use_fft ? (s0->rf <= 4 ? g.njobs[0] : (s0->rf <= 8 ? g.njobs[1] : g.njobs[2])) * a.C : 0;
         const int per = (total + 7) >> 3;
         local = xcd * per + slot;
         if (slot >= per || local >= total) return;
@@ -633,6 +652,11 @@ int launch_wfft_typed(pb_ctx *ctx, const ConvPass &p) {
 }  // namespace
 
 #ifdef PB_WF_TRACE
+extern "C" int pb_debug_wf_trace_clear(void) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wf_trace)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * kTraceStamps * kTraceWaves);
+}
 extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
     if (n_waves > kTraceWaves) n_waves = kTraceWaves;
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wf_trace), sizeof(unsigned long long) * kTraceStamps * n_waves);
