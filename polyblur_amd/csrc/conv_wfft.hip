@@ -254,8 +254,12 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v ld_b128(brsrc r, unsigned voffset, int soffset) {
     return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, soffset, 0));
 }
+// 16-byte store.  The whole offset travels in the vector register and the scalar-offset field stays 0: a VALU write to
+// the data registers right behind a store of more than 8 bytes reads as a hazard to the compiler only in that form (it
+// assumes a register in the scalar-offset field buys the wait state; on gfx950 it does not -- the first data dword of the
+// last lanes was sporadically replaced by the next instruction's result).
 __device__ __forceinline__ void st_b128(brsrc r, unsigned voffset, int soffset, f4v v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)voffset, soffset, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)(voffset + (unsigned)soffset), 0, 0);
 }
 
 // One window pair.  zb: the wave's LDS region (kWfLdsWave bytes); kp: the image's spectrum, [x position][y position].
