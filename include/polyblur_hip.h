@@ -288,7 +288,7 @@ typedef enum pb_prof_tag {
     PB_PROF_HALO = 5,        /* halo masking + its reductions */
     PB_PROF_PREFILTER = 6,   /* bilateral / domain transform / recombination */
     PB_PROF_OTHER = 7,
-    PB_PROF_CONV_FUSED = 8,  /* Horner steps 2 + 3 in one launch (rank-1 kernels) */
+    PB_PROF_CONV_FUSED = 8,  /* reserved (an experiment of round 2 used it) */
     PB_PROF_CONV_FFT = 9     /* the same pass for dense kernels: tile-spectrum body (conv_fft.hip) */
 } pb_prof_tag;
 int pb_profile_begin(pb_ctx *ctx);

@@ -39,10 +39,7 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-EXPERIMENTAL = ["conv_fused.hip"]      # measured slower than the default path; built only on request (-DPB_WITH_FUSED)
-
-
-def build(force: bool = False, verbose: bool = True, experimental: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
@@ -51,15 +48,8 @@ def build(force: bool = False, verbose: bool = True, experimental: bool = False)
     headers.append(os.path.join(os.path.dirname(HERE), "include", "polyblur_hip.h"))
     jobs = []
     objs = []
-    flags = FLAGS + (["-DPB_WITH_FUSED"] if experimental else []) + os.environ.get("PB_EXTRA_FLAGS", "").split()
-    stamp = os.path.join(objdir, "experimental" if experimental else "default")
-    if not os.path.exists(stamp):                      # switching flavours rebuilds everything
-        force = True
-        for f in ("experimental", "default"):
-            if os.path.exists(os.path.join(objdir, f)):
-                os.remove(os.path.join(objdir, f))
-        open(stamp, "w").close()
-    for src in SOURCES + (EXPERIMENTAL if experimental else []):
+    flags = FLAGS + os.environ.get("PB_EXTRA_FLAGS", "").split()
+    for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
@@ -84,4 +74,4 @@ def build(force: bool = False, verbose: bool = True, experimental: bool = False)
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, experimental="--experimental" in sys.argv))
+    print(build(force="--force" in sys.argv))

@@ -96,7 +96,7 @@ int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases) {
     if (!ctx || (mode != PB_DENSE_STENCIL && mode != PB_DENSE_AUTO) || min_phases < 0 || min_phases > PB_MAX_PHASES + 1)
         return PB_ERR_BADARG;
     ctx->fft_min_phases = mode == PB_DENSE_STENCIL ? -1 : min_phases;
-    pb_forget_records(ctx, nullptr);
+    pb_forget_records(ctx, nullptr, 0);
     return PB_OK;
 }
 
@@ -158,7 +158,7 @@ int pb_malloc(pb_ctx *ctx, void **dptr, size_t bytes) {
     return PB_OK;
 }
 int pb_free(pb_ctx *ctx, void *dptr) {
-    if (ctx) pb_forget_records(ctx, nullptr);
+    if (ctx) pb_forget_records(ctx, nullptr, 0);
     if (!ctx) return PB_ERR_BADARG;
     PB_HIP(hipStreamSynchronize(ctx->stream));
     PB_HIP(hipFree(dptr));
@@ -298,36 +298,21 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     auto set_x = [&](ConvPass &q) { if (xpadded) set_x_padded(q, g, xpadded); else set_x_virtual(q, g, xsrc, x_dtype); };
     const int tdt = g.t1h ? PB_F16 : PB_F32;
     void *T1 = g.t1h ? g.t1h : static_cast<void *>(t1), *T2 = g.t2h ? g.t2h : static_cast<void *>(t2);
+    ConvPass steps[3];
     // t1 = K * (a3 x) + a2 x
     if (xpadded) set_in_padded(p, g, xpadded); else set_in_virtual(p, g, xsrc, x_dtype);
     set_x(p); set_out_padded(p, g, T1, tdt);
     p.scale = a3; p.coef = a2;
-    int rc = pb_launch_conv(ctx, p);
-    if (rc) return rc;
-#ifdef PB_WITH_FUSED
-    // EXPERIMENT (python -m polyblur_amd.build --experimental, then PB_FUSE=1): rank-1 kernels take steps 2 and 3 in one
-    // launch, t2 stays in LDS (conv_fused.hip); each image's record decides on the device which path does its tiles.
-    // Measured on MI355X at 4K: 167 us against 2 x 74 us for the two one-step launches -- not
-    // part of the default build.
-    static const bool fuse = [] { const char *e = getenv("PB_FUSE"); return e && e[0] == '1'; }();
-    if (fuse) {
-        ConvPass f = p;
-        set_in_padded(f, g, t1); set_out_interior(f, g, dst, dst_dtype);
-        f.scale = 1.f; f.coef = beta; f.clamp01 = clamp01;
-        rc = pb_launch_conv_fused(ctx, f, a1);
-        if (rc == PB_OK) p.skip_sep = 1;
-        else if (rc != PB_ERR_UNSUPPORTED) return rc;
-    }
-#endif
-    // t2 = K * t1 + a1 x   (the kernels' spectra, where the tile-spectrum body is used, were built by the first pass)
+    steps[0] = p;
+    // t2 = K * t1 + a1 x
     set_in_padded(p, g, T1, tdt); set_out_padded(p, g, T2, tdt);
-    p.scale = 1.f; p.coef = a1; p.khat_ready = 1;
-    rc = pb_launch_conv(ctx, p);
-    if (rc) return rc;
+    p.scale = 1.f; p.coef = a1;
+    steps[1] = p;
     // y = K * t2 + beta x   (only the crop is needed)
     set_in_padded(p, g, T2, tdt); set_out_interior(p, g, dst, dst_dtype);
     p.coef = beta; p.clamp01 = clamp01;
-    return pb_launch_conv(ctx, p);
+    steps[2] = p;
+    return pb_launch_conv_poly(ctx, steps);
 }
 
 struct InverseScratch {
@@ -390,7 +375,7 @@ int pb_estimate_blur(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (rc) return rc;
     if (!in || !opt || !dev_info) return pb_fail(ctx, PB_ERR_BADARG, "null argument");
     PB_HIP(hipSetDevice(ctx->device));
-    pb_forget_records(ctx, dev_info);
+    pb_forget_records(ctx, dev_info, B);
     return pb_estimate_impl(ctx, in, dtype, B, C, H, W, opt, dev_info);
 }
 
@@ -416,7 +401,7 @@ int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, 
     const int ksize = pb_kernel_size(&o);
     if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", ker_size, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
-    pb_forget_records(ctx, dev_sep);
+    pb_forget_records(ctx, dev_sep, 2 * B);
     return pb_make_sep_records(ctx, B, dev_info, dev_sep, support, ksize);
 }
 

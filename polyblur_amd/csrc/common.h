@@ -143,14 +143,16 @@ struct ConvPass {
     const pb_fft_sel *fsel;
     const float *khat;
     int khat_ready;
+    int no_fft;          // this pass keeps the stencil bodies (pb_launch_conv_poly: some step of the polynomial does not suit the other)
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
-int pb_launch_conv_fused(pb_ctx *ctx, const ConvPass &p, float coef_mid);   // conv_fused.hip (experimental build only)
+// the three Horner steps of one polynomial (same planes, records and x operand; step s reads what step s - 1 wrote)
+int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps);
 int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // conv_xt.hip
 int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch);
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // conv.hip: after the host (re)built these records
-void pb_forget_records(pb_ctx *ctx, const void *info);                        // nullptr: all
+void pb_forget_records(pb_ctx *ctx, const void *info, int B);                 // B records at info are about to be rewritten; nullptr: all
 void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p);                     // conv_wfft.hip; PB_ERR_UNSUPPORTED: dtype combination not built

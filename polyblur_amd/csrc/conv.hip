@@ -324,12 +324,17 @@ static int launch_stencil(pb_ctx *ctx, const ConvPass &p);
 // Dense kernels above the context's phase threshold take the tile-spectrum body: a second launch of the same step, in
 // which -- as in the first -- every image's tiles exit at once unless the image's record selects that body.  For record
 // sets the host built and read back itself (rec_cache) the launch no image needs is not issued at all.
+// What the tile-spectrum body needs of a pass: planes within its 32-bit byte offsets, window counts within its index
+// arithmetic.
+static bool fft_pass_ok(const ConvPass &p) {
+    const long plane_max = (1L << 31) - 4096;
+    return !p.skip_general && p.in_plane * 4 < plane_max && p.x_plane * 4 < plane_max && p.out_plane * 4 < plane_max &&
+           pb_conv_fft_feasible(p);
+}
+
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     ConvPass p = p0;
-    // (the tile-spectrum body addresses planes with 32-bit byte offsets)
-    const long plane_max = (1L << 31) - 4096;
-    bool fft = ctx->fft_min_phases >= 0 && !p.skip_general && p.in_plane * 4 < plane_max && p.x_plane * 4 < plane_max &&
-               p.out_plane * 4 < plane_max && pb_conv_fft_feasible(p);
+    bool fft = ctx->fft_min_phases >= 0 && !p.no_fft && fft_pass_ok(p);
     const int B = p.P / p.C;
     const auto known = ctx->rec_cache.find(p.info);
     const bool have = known != ctx->rec_cache.end() && known->second.B == B;
@@ -337,10 +342,13 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     p.fsel = nullptr; p.khat = nullptr;
     if (fft) {
         float *k = nullptr; pb_fft_sel *s = nullptr;
-        const bool built = p.khat_ready || (have && ctx->khat_owner == p.info);
+        // (spectra an earlier pass built count only while the scratch still holds them for these records)
+        const bool built = (p.khat_ready || have) && ctx->khat_owner == p.info;
         const int rc = pb_build_khat(ctx, p.info, B, &k, &s, !built);
         if (rc) return rc;
         p.khat = k; p.fsel = s;
+    } else if (!p.khat_ready && !have) {
+        ctx->khat_owner = nullptr;      // device-built records took a pass without spectra: whatever the scratch holds is not theirs
     }
     if (!(fft && have && !known->second.any_other)) {
         const int rc = launch_stencil(ctx, p);
@@ -354,10 +362,26 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     return pb_launch_conv_fft(ctx, p);
 }
 
+// The three Horner steps of one polynomial.  Whether the tile-spectrum body may be used is decided ONCE, from all three
+// geometries (a body decided per step could meet spectra no earlier step had built); its spectra are built by the first
+// step.  One launch sequence per step.
+int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
+    bool fft = true;
+    for (int s = 0; s < 3; ++s) fft = fft && fft_pass_ok(steps[s]);
+    for (int s = 0; s < 3; ++s) {
+        ConvPass p = steps[s];
+        p.khat_ready = s > 0;
+        if (!fft) p.no_fft = 1;
+        const int rc = pb_launch_conv(ctx, p);
+        if (rc) return rc;
+    }
+    return PB_OK;
+}
+
 // The host has just (re)built these B records and is synchronising anyway: build their spectra, read the per-image choice
 // back and remember it.
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B) {
-    ctx->rec_cache.erase(info);
+    pb_forget_records(ctx, info, B);
     if (ctx->fft_min_phases < 0) return PB_OK;
     float *k = nullptr; pb_fft_sel *s = nullptr;
     int rc = pb_build_khat(ctx, info, B, &k, &s, true);
@@ -381,9 +405,10 @@ void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes) {
         } else ++it;
     }
 }
-void pb_forget_records(pb_ctx *ctx, const void *info) {
-    if (info) ctx->rec_cache.erase(info); else ctx->rec_cache.clear();
-    if (!info || ctx->khat_owner == info) ctx->khat_owner = nullptr;
+void pb_forget_records(pb_ctx *ctx, const void *info, int B) {
+    if (info) { pb_forget_range(ctx, info, sizeof(pb_blur_info) * (size_t)B); return; }
+    ctx->rec_cache.clear();
+    ctx->khat_owner = nullptr;
 }
 
 static int launch_stencil(pb_ctx *ctx, const ConvPass &p) {

@@ -30,10 +30,10 @@
 // followed by a transpose inside each quadrant, and the quadrant pairs go through the same 32 x 64 LDS tile one after
 // the other.
 //
-// Work items: window pairs of the images whose record selects this body, numbered image by image with every image's
-// own tile size (prefix sum over the batch's pb_fft_sel records inside the kernel: no idle slots for images with larger
-// tiles, no host read-back); workgroup b runs on XCD b % 8 (observed, used for speed only) and every XCD takes one
-// contiguous run of pairs, so neighbouring windows share their halos in that XCD's L2.
+// Work items: window pairs of the images whose record selects this body, every image with its own tile size (prefix sum
+// over the batch's pb_fft_sel records inside the kernel: no idle slots for images with larger tiles, no host read-back);
+// workgroup b runs on XCD b % 8 (observed, used for speed only) and every XCD takes the same contiguous eighth of every
+// plane's pairs, so neighbouring windows share their halos in that XCD's L2.
 // No MFMA, no library FFT.
 
 #include <algorithm>
@@ -49,7 +49,6 @@ namespace {
 #define PB_ABL 0
 #endif
 
-constexpr int WF_WAVES = 1;                          // waves per workgroup (each wave is independent: no barriers)
 constexpr int WF_ROWS = 32;                          // LDS tile rows per wave (half a window pair)
 constexpr size_t kWfLdsWave = sizeof(float2) * WF_ROWS * FT_P;
 
@@ -208,8 +207,8 @@ __device__ __forceinline__ void transpose64(cf (&v)[64], float2 *Z, int lane) {
 
 // Geometry of a pass, per window halo class (index R / 4 - 1), computed on the host.
 struct WGeom {
-    int pairs_x[3], njobs[3];               // window pairs per row, per plane
-    float inv_pairs_x[3], inv_njobs[3];
+    int pairs_x[3], njobs[3], per[3];       // window pairs per row, per plane, per plane and XCD
+    float inv_pairs_x[3], inv_per[3];
 };
 
 // inclusive prefix sum over the wave
@@ -230,6 +229,9 @@ __device__ unsigned long long g_wf_trace[kTraceWaves * kTraceStamps];
 #define PB_T(i) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define PB_TWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define PB_TRT(i) do { if (tr) tr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per wave: up to kJobSlots jobs x {taken, done (100 MHz ticks), step << 28 | pair}
+constexpr int kJobWaves = 2048, kJobSlots = 40;
+__device__ unsigned long long g_wf_jobs[kJobWaves * kJobSlots * 3];
 #else
 #define PB_T(i)
 #define PB_TWAIT()
@@ -556,70 +558,71 @@ __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi)
            ((a.in_pitch | a.x_pitch | a.out_pitch | (wxA - lo) | (oxA - xsh) | (oxA - oo)) & 3) == 0;
 }
 
-// One wave per window pair.  Jobs of image i = its window pairs with its own tile size x planes, 0 when another body does
-// the image; the waves number them with an inclusive prefix sum over the batch's records (64 images per round).
-// Workgroup b runs on XCD b % 8: XCD x takes the contiguous run [x per, (x + 1) per) of the job list.
+// One wave (= one workgroup) per window pair; the GRID is the job list.  The jobs are the window pairs of the images whose
+// record selects this body, every image with its own tile size (prefix sum over the batch's pb_fft_sel records: no host
+// read-back; the grid is sized for the smallest tile and the surplus workgroups leave at once).  Workgroup b belongs to
+// list b % 8 (the XCD it is observed to run on -- used for speed only) at position b / 8; every list owns the same eighth
+// of EVERY plane's pairs -- a contiguous run, so neighbouring windows share their halos in that XCD's L2 -- in the order
+// image, plane, pair.
+//
+// (Measured and dropped: the three Horner steps of a polynomial in ONE launch -- step-major lists, per-plane completion
+// counters, write-through stores for the planes a later step reads, one agent-scope acquire per pair -- once with
+// persistent waves taking pairs from queue heads in memory, once with the grid as the queue.  With every
+// synchronisation compiled out the single launch takes exactly what the three launches take, 254 us per 4K polynomial:
+// the launch tails it removes were not idle time, the waves that remain in a tail run faster; with the acquire and the
+// write-through stores in place 282 us.  The persistent form also cost 50 more spilled registers.)
 template <typename TIn, typename TX, typename TOut>
-__global__ __launch_bounds__(64 * WF_WAVES, 2 / (4 / WF_WAVES) > 0 ? 2 : 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
-    extern __shared__ __attribute__((aligned(16))) char zall[];
+__global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char zb[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long *tr = nullptr;
 #ifdef PB_WF_TRACE
-    { const int gw = blockIdx.x * WF_WAVES + wave; if (gw < kTraceWaves) tr = g_wf_trace + (long)gw * kTraceStamps; }
+    if (blockIdx.x < kTraceWaves) tr = g_wf_trace + (long)blockIdx.x * kTraceStamps;
     PB_T(0);
     PB_TRT(12);
 #endif
-    char *zb = zall + wave * kWfLdsWave;
-    const int B = a.P / a.C;
-    auto jobs_of = [&](int i) -> int {
-        if (i >= B) return 0;
-        const pb_fft_sel s = a.fsel[i];
-        if (!s.use_fft) return 0;
-        return (s.rf <= 4 ? g.njobs[0] : (s.rf <= 8 ? g.njobs[1] : g.njobs[2])) * a.C;
-    };
-    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3) * WF_WAVES + wave;
-    int img = 0, local = 0;
+    const int C = a.C, B = a.P / C;
+    const int q = (int)(blockIdx.x & 7u);
+    int rem = (int)(blockIdx.x >> 3);                  // position in the list
+    int img = 0, R = 0;
     if (B == 1) {
         // (one image: its record is read on the scalar side -- no trip through the vector memory queue)
         const PB_CONSTANT pb_fft_sel *s0 = as_constant(a.fsel);
-        const int total = s0->use_fft ? (s0->rf <= 4 ? g.njobs[0] : (s0->rf <= 8 ? g.njobs[1] : g.njobs[2])) * a.C : 0;
-        const int per = (total + 7) >> 3;
-        local = xcd * per + slot;
-        if (slot >= per || local >= total) return;
+        if (!s0->use_fft) return;
+        R = s0->rf;
     } else {
-        const int n0 = jobs_of(lane), incl0 = wave_scan(n0, lane);
-        int total = __builtin_amdgcn_readlane(incl0, 63);
-        for (int c0 = 64; c0 < B; c0 += 64) total += __builtin_amdgcn_readlane(wave_scan(jobs_of(c0 + lane), lane), 63);
-        const int per = (total + 7) >> 3;
-        const int j = xcd * per + slot;
-        if (slot >= per || j >= total) return;
-        const unsigned long long m = __ballot(incl0 > j);
-        if (m) {
-            const int l = __builtin_ctzll(m);
-            img = l;
-            local = j - (__builtin_amdgcn_readlane(incl0, l) - __builtin_amdgcn_readlane(n0, l));
-        } else {
-            int base = __builtin_amdgcn_readlane(incl0, 63);
-            for (int c0 = 64; c0 < B; c0 += 64) {
-                const int n = jobs_of(c0 + lane), incl = wave_scan(n, lane);
-                const unsigned long long m2 = __ballot(base + incl > j);
-                if (m2) {
-                    const int l = __builtin_ctzll(m2);
-                    img = c0 + l;
-                    local = j - base - (__builtin_amdgcn_readlane(incl, l) - __builtin_amdgcn_readlane(n, l));
-                    break;
-                }
-                base += __builtin_amdgcn_readlane(incl, 63);
+        // list entries of image i: its share of every plane
+        auto share_of = [&](int i) -> int {
+            if (i >= B) return 0;
+            const pb_fft_sel s = a.fsel[i];
+            if (!s.use_fft) return 0;
+            return (s.rf <= 4 ? g.per[0] : (s.rf <= 8 ? g.per[1] : g.per[2])) * C;
+        };
+        bool work = false;
+        int base = 0;
+        for (int c0 = 0; c0 < B; c0 += 64) {
+            const int n = share_of(c0 + lane), incl = wave_scan(n, lane);
+            const unsigned long long m = __ballot(base + incl > rem);
+            if (m) {
+                const int l = __builtin_ctzll(m);
+                img = c0 + l;
+                rem -= base + (__builtin_amdgcn_readlane(incl, l) - __builtin_amdgcn_readlane(n, l));
+                work = true;
+                break;
             }
+            base += __builtin_amdgcn_readlane(incl, 63);
         }
-        img = __builtin_amdgcn_readfirstlane(img); local = __builtin_amdgcn_readfirstlane(local);
+        if (!work) return;
+        img = __builtin_amdgcn_readfirstlane(img); rem = __builtin_amdgcn_readfirstlane(rem);
+        R = as_constant(a.fsel + img)->rf;
     }
-    const PB_CONSTANT pb_fft_sel *sel = as_constant(a.fsel + img);
-    const int R = sel->rf, c = R <= 4 ? 0 : (R <= 8 ? 1 : 2);
-    const int pl = __builtin_amdgcn_readfirstlane(div_small(local, g.inv_njobs[c])), pair = local - pl * g.njobs[c];
+    const int c = R <= 4 ? 0 : (R <= 8 ? 1 : 2);
+    const int pl = __builtin_amdgcn_readfirstlane(div_small(rem, g.inv_per[c]));
+    if (pl >= C) return;                               // (one image: positions beyond its planes)
+    const int pair = q * g.per[c] + (rem - pl * g.per[c]);
+    if (pair >= g.njobs[c]) return;                    // (the ragged end of the last list's run)
     const int ty = __builtin_amdgcn_readfirstlane(div_small(pair, g.inv_pairs_x[c])), pxi = pair - ty * g.pairs_x[c];
-    const int plane = img * a.C + pl;
+    const int plane = img * C + pl;
     const float *kp = a.khat + (long)img * (FT_N * FT_N);
     const pb_blur_info *info = a.info + img;
 #define PB_RUN(RR)                                                                                  \
@@ -633,8 +636,8 @@ bool wfft_geometry(const ConvPass &p, WGeom &g, long &total_max) {
     FftGeom f;
     if (!fft_geometry(p, f)) return false;
     for (int c = 0; c < 3; ++c) {
-        g.pairs_x[c] = f.pairs_x[c]; g.njobs[c] = f.njobs[c];
-        g.inv_pairs_x[c] = f.inv_pairs_x[c]; g.inv_njobs[c] = 1.0f / (float)f.njobs[c];
+        g.pairs_x[c] = f.pairs_x[c]; g.njobs[c] = f.njobs[c]; g.per[c] = (f.njobs[c] + 7) / 8;
+        g.inv_pairs_x[c] = f.inv_pairs_x[c]; g.inv_per[c] = 1.0f / (float)g.per[c];
     }
     total_max = (long)f.njobs[2] * p.P;
     return total_max > 0 && total_max <= (1L << 22);
@@ -645,10 +648,8 @@ int launch_wfft_typed(pb_ctx *ctx, const ConvPass &p) {
     WGeom g;
     long total_max = 0;
     if (!wfft_geometry(p, g, total_max)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: too many windows for the tile-spectrum body");
-    const long per_max = (total_max + 7) / 8;
-    const long groups = 8 * ((per_max + WF_WAVES - 1) / WF_WAVES);
-    hipLaunchKernelGGL((conv_wfft_kernel<TIn, TX, TOut>), dim3((unsigned)groups), dim3(64 * WF_WAVES), kWfLdsWave * WF_WAVES,
-                       ctx->stream, p, g);
+    const long groups = 8L * g.per[2] * p.P;             // list entries if every image had the smallest tiles
+    hipLaunchKernelGGL((conv_wfft_kernel<TIn, TX, TOut>), dim3((unsigned)groups), dim3(64), kWfLdsWave, ctx->stream, p, g);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
@@ -661,17 +662,23 @@ extern "C" int pb_debug_wf_trace_clear(void) {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wf_trace)) != hipSuccess) return -1;
     return (int)hipMemset(p, 0, sizeof(unsigned long long) * kTraceStamps * kTraceWaves);
 }
+extern "C" int pb_debug_wf_jobs(unsigned long long *host, int clear) {
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wf_jobs)) != hipSuccess) return -1;
+        return (int)hipMemset(p, 0, sizeof(unsigned long long) * kJobWaves * kJobSlots * 3);
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wf_jobs), sizeof(unsigned long long) * kJobWaves * kJobSlots * 3);
+}
 extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
     if (n_waves > kTraceWaves) n_waves = kTraceWaves;
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wf_trace), sizeof(unsigned long long) * kTraceStamps * n_waves);
 }
 #endif
 
+// PB_ERR_UNSUPPORTED: dtype combination not built (the caller falls back to the workgroup body).
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
     ProfScope prof(ctx, PB_PROF_CONV_FFT);
-    const int key = p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype;
-    switch (key) {
-        case 0: return launch_wfft_typed<float, float, float>(ctx, p);
-        default: return PB_ERR_UNSUPPORTED;         // (the caller falls back to the workgroup body)
-    }
+    if (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype != 0) return PB_ERR_UNSUPPORTED;
+    return launch_wfft_typed<float, float, float>(ctx, p);
 }
