@@ -1,0 +1,68 @@
+"""The RCCL leg of bench.py on the one GPU of the lease: started the way the driver starts the N-rank runs
+(torch.distributed.run, RANK / WORLD_SIZE / MASTER_* in the environment), so `nccl` initialisation with a device id, the
+all-reduce, the barrier-bracketed timing and the max-over-ranks reduction all execute on an MI355X."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _line(out):
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_under_torchrun_one_rank():
+    args = ["--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-context", "--no-parity"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ranked = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                             "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py")] + args,
+                            capture_output=True, text=True, env=env, timeout=600)
+    assert ranked.returncode == 0, ranked.stderr[-2000:]
+    a, b = _line(plain.stdout), _line(ranked.stdout)
+    assert a["rccl_ranks"] == 1 and a["n_gpus"] == 1
+    assert b["rccl_ranks"] == 1 and b["n_gpus"] == 1 and b["scaling"] == "weak"
+    # the same workload on the same GPU: the RCCL-bracketed timing must tell the same story (boxes jitter by a few per cent)
+    assert abs(b["value"] / a["value"] - 1.0) < 0.15, (a["value"], b["value"])
+
+
+def test_from_root_one_rank_matches_direct_call(tmp_path):
+    """deblur_from_root over the nccl backend with a world of one: the degenerate exchange plan (plain device copies)."""
+    code = r'''
+import os, sys, json, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from polyblur_amd import polyblur_deblurring
+from polyblur_amd.distributed import deblur_from_root
+from polyblur_amd.synthetic import synthetic_blurry_batch
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+x = torch.from_numpy(synthetic_blurry_batch(3, 3, 120, 160, seed0=5)[0]).to(dev)
+kw = dict(n_iter=2, c=0.362, b=0.468, alpha=6, beta=1)
+a = deblur_from_root(x, tuple(x.shape), torch.float32, device=dev, **kw)
+b = polyblur_deblurring(x, **kw)
+print(json.dumps({"equal": bool(torch.equal(a, b)), "world": dist.get_world_size()}))
+dist.barrier(); dist.destroy_process_group()
+''' % REPO
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = tmp_path / "from_root_one_rank.py"
+    script.write_text(code)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _line(r.stdout)
+    assert res == {"equal": True, "world": 1}
