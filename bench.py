@@ -243,6 +243,26 @@ def main():
             side["from_root_scatter_compute_gather"] = dict(error="%s: %s" % (type(e).__name__, str(e)[:200]))
         del xr
 
+    if world > 1 and not from_root and not args.no_context and args.config == "cfg2":
+        # BASELINE's multi-GPU configs as resident per-GPU shares, so that a scaling run reports them without extra flags:
+        # cfg4 = 256 x 1080p fp32 over 8 GPUs (32 per GPU), cfg5 = 8 x 8K fp16, n_iter=5 (one per GPU)
+        for name in ("cfg4", "cfg5"):
+            c2 = CONFIGS[name]
+            try:
+                xs = torch.from_numpy(make_batch(c2["batch"], c2["height"], c2["width"], DEFAULT_SEED + 1000 * rank)[0]).to(dev)
+                xs = xs.to(torch.float32 if c2["dtype"] == "f32" else torch.float16).contiguous()
+                kw2 = dict(KW, n_iter=c2["n_iter"])
+                f2 = lambda: polyblur_deblurring(xs, **kw2)
+                f2()
+                dt2, _ = timed(3, f2)
+                ms2 = 1e3 * dt2 / 3
+                side[name + "_share_resident"] = dict(ms_per_step=round(ms2, 3), images_per_gpu=c2["batch"], n_iter=c2["n_iter"], dtype=c2["dtype"],
+                                                      mp_per_s=round(c2["batch"] * c2["height"] * c2["width"] * world / 1e6 / (ms2 * 1e-3), 1),
+                                                      note="whole-job MP/s over %d GPUs, shards resident" % world)
+                del xs
+            except Exception as e:                   # noqa: BLE001 -- a side measurement
+                side[name + "_share_resident"] = dict(error="%s: %s" % (type(e).__name__, str(e)[:200]))
+
     if rank != 0:
         if use_dist:
             dist.barrier()                       # leave together with rank 0 (it prints the line first)
@@ -259,7 +279,8 @@ def main():
     dom_kernel = "conv_tile_kernel"
     if prof.get("conv_fft", (0.0, 0))[0] > conv_ms:
         conv_ms, conv_n = prof["conv_fft"]
-        dom_kernel = "conv_fft_kernel"
+        # fp32 planes: one wave per window pair (csrc/conv_wfft.hip); fp16 / 8-bit planes: one workgroup per pair (conv_fft.hip)
+        dom_kernel = "conv_wfft_kernel" if s == 4 and os.environ.get("PB_FFT_BODY", "wave") != "wg" else "conv_fft_kernel"
     # one polynomial application = (2s + 3s + 3s) bytes per sample, spread over its launches
     calls_per_step = B if from_root else 1                       # from_root deblurs image by image as they arrive
     launches_per_poly = max(conv_n / (args.steps * cfg["n_iter"] * calls_per_step), 1e-9)
@@ -271,13 +292,21 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
+        import hashlib
         cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_traffic.json")))
         if cands and args.config == "cfg2" and B == 1 and (H, W) == (2160, 3840) and s == 4:
             tj = json.load(open(cands[-1]))
-            for k, v in tj.get("traffic", {}).items():
-                if k.startswith(dom_kernel + "<float, float, float>"):
-                    traffic = v["hbm_bytes_per_launch"]
-                    traffic_src = "%s (rocprofv3 --pmc passes of this command at git %s)" % (os.path.basename(cands[-1]), tj.get("git", "?"))
+            h = hashlib.sha256()
+            for f in sorted(glob.glob(os.path.join(REPO, "polyblur_amd", "csrc", "conv*"))):
+                h.update(open(f, "rb").read())
+            if tj.get("conv_sources_sha256_16") != h.hexdigest()[:16]:
+                # counters taken from other code say nothing about this build: no number rather than a stale one
+                traffic_src = "%s was taken from other sources of the reblurring pass (git %s): not used" % (os.path.basename(cands[-1]), tj.get("git", "?"))
+            else:
+                for k, v in tj.get("traffic", {}).items():
+                    if k.startswith(dom_kernel + "<float, float, float>"):
+                        traffic = v["hbm_bytes_per_launch"]
+                        traffic_src = "%s (rocprofv3 --pmc passes of this command at git %s, same sources of the pass)" % (os.path.basename(cands[-1]), tj.get("git", "?"))
     except Exception:
         pass
     roofline = dict(bound="hbm", kernel=dom_kernel + " (stencil pass; taps as estimated, full 25x25 support)",
@@ -286,11 +315,18 @@ def main():
                     launches_per_polynomial=round(launches_per_poly, 3),
                     algorithmic_bytes_per_launch=int(alg_bytes_per_launch),
                     ms_per_step_with_launch_events=round(ms_per_step_prof, 4))
-    # whole-step figure of SURVEY 8d: 9 words per sample per iteration (8 for the polynomial + 1 read for the estimate)
-    e2e_gbs = 9.0 * s * samples * cfg["n_iter"] * world / (ms_per_step * 1e-3) / 1e9
-    roofline["end_to_end"] = dict(algorithmic_bytes_per_step=int(9.0 * s * samples * cfg["n_iter"]), achieved=round(e2e_gbs, 1),
+    # whole-step figure of SURVEY 8d: 9 words per sample per iteration (8 for the polynomial + 1 read for the estimate),
+    # plus the options' adders: halo masking 3, domain-transform prefilter 4 + 1 for the residual add-back, bilateral 2
+    words = 9.0
+    if cfg["opts"].get("remove_halo"):
+        words += 3.0
+    if cfg["opts"].get("prefiltering"):
+        words += 5.0 if cfg["opts"].get("prefilter") == "domain_transform" else 2.0
+    e2e_gbs = words * s * samples * cfg["n_iter"] * world / (ms_per_step * 1e-3) / 1e9
+    roofline["end_to_end"] = dict(algorithmic_bytes_per_step=int(words * s * samples * cfg["n_iter"]), achieved=round(e2e_gbs, 1),
                                   unit="GB/s", frac=round(e2e_gbs / (HBM_PEAK_GBS * world), 4),
-                                  note="options of cfg3 (halo, prefilter) add bytes that this figure does not count")
+                                  words_per_sample_per_iteration=words,
+                                  note="SURVEY 8d: 9 words per sample and iteration, + 3 halo masking, + 5 domain-transform prefilter")
     stages_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]}
 
     est, infos = None, None

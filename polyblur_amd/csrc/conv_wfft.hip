@@ -570,7 +570,14 @@ __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi)
 // persistent waves taking pairs from queue heads in memory, once with the grid as the queue.  With every
 // synchronisation compiled out the single launch takes exactly what the three launches take, 254 us per 4K polynomial:
 // the launch tails it removes were not idle time, the waves that remain in a tail run faster; with the acquire and the
-// write-through stores in place 282 us.  The persistent form also cost 50 more spilled registers.)
+// write-through stores in place 282 us.  The persistent form also cost 50 more spilled registers.
+//  Three waves per SIMD instead of two -- 168 registers per lane and 13 KiB of LDS per wave: the spectrum streamed from L2
+// eight values ahead, the window staged through a ring of three 8-row LDS buffers, the transposes through a 16-row tile
+// after a v_permlane16_swap level, the x operand three pieces per lane ahead -- was built, passed every test and ran at
+// 119 us per 4K pass against 85: with 40 registers beside the window pair nothing can be requested far enough ahead
+// (epilogue 30 k cycles per pair instead of 6 k, the centre stage 15.5 k instead of 4.8 k), twelve waves per CU queue
+// on the LDS (transposes 9 k cycles instead of 3.5 k) and the compiler still spilled 28 window rows per pair.  The 128
+// registers a wave has beside its window pair at two waves per SIMD are what hides this kernel's latencies.)
 template <typename TIn, typename TX, typename TOut>
 __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
     extern __shared__ __attribute__((aligned(16))) char zb[];

@@ -65,12 +65,19 @@ for c in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS
           "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"):
     for k, (v, n) in counter_avg("pmc_sq", c).items():
         sq.setdefault(k, {})[c] = round(v)
-import subprocess
+import hashlib, subprocess
+def conv_sources_hash():
+    """sha256 over the reblurring pass's sources: bench.py refuses HBM-traffic numbers taken from other code"""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(here, "polyblur_amd", "csrc", "conv*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 try:
     sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PB_GIT_SHA", "?")
 except Exception:
     sha = os.environ.get("PB_GIT_SHA", "?")
-json.dump(dict(tag=tag, git=os.environ.get("PB_GIT_SHA", sha), note="per-launch averages over every launch of the profiled bench.py run; "
+json.dump(dict(tag=tag, git=os.environ.get("PB_GIT_SHA", sha), conv_sources_sha256_16=conv_sources_hash(), note="per-launch averages over every launch of the profiled bench.py run; "
                              "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction)",
                traffic=traffic, sq=sq), open(os.path.join(root, tag + "_traffic.json"), "w"), indent=1)
 print(open(os.path.join(root, tag + "_kernel_stats.csv")).read() if stats else "no stats csv found")
