@@ -88,6 +88,16 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
+    const char *side = getenv("PB_SIDE_STREAM");
+    if (!(side && side[0] == '0')) {
+        if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+            ctx->aux = nullptr;                                  // (the engine works without it)
+        }
+    }
     *out = ctx;
     return PB_OK;
 }
@@ -119,6 +129,9 @@ int pb_destroy(pb_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
     return PB_OK;
 }
@@ -130,8 +143,12 @@ int pb_set_stream(pb_ctx *ctx, void *stream) {
         // the context's scratch buffers may still be in use by work queued on the old stream: order the new
         // stream behind it (device-side dependency, no host wait)
         PB_HIP(hipSetDevice(ctx->device));
-        PB_HIP(hipEventRecord(ctx->ev_switch, ctx->stream));
-        PB_HIP(hipStreamWaitEvent(next, ctx->ev_switch, 0));
+        if (hipEventRecord(ctx->ev_switch, ctx->stream) != hipSuccess || hipStreamWaitEvent(next, ctx->ev_switch, 0) != hipSuccess) {
+            // (the old stream may have been destroyed by its owner: nothing can be ordered behind it any more -- wait
+            // for the device instead and adopt the new stream all the same)
+            (void)hipGetLastError();
+            PB_HIP(hipDeviceSynchronize());
+        }
         ctx->stream = next;
     }
     return PB_OK;

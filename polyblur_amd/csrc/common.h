@@ -50,6 +50,10 @@ struct pb_ctx {
     float *interp_w = nullptr;     // (n_interp x (n_angles+1)) Keys weights
     int interp_na = 0, interp_ni = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_switch = nullptr;
+    // A second stream for the launches of a polynomial that device-built records may leave without work (pb_launch_conv_poly):
+    // forked from and joined back into `stream` inside the call, idle between calls.  nullptr: not used (env PB_SIDE_STREAM=0).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t est_done_bytes = 0;     // size of the zero-initialised arrival counters
     // dense (non rank-1) kernels with at least this many live stencil phases are evaluated per tile in the frequency
     // domain (conv_fft.hip) instead of by the stencil body; < 0: never (pb_set_dense_eval, env PB_DENSE_EVAL)

@@ -365,17 +365,52 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
 // The three Horner steps of one polynomial.  Whether the tile-spectrum body may be used is decided ONCE, from all three
 // geometries (a body decided per step could meet spectra no earlier step had built); its spectra are built by the first
 // step.  One launch sequence per step.
+//
+// Records built on the device (the pipeline) leave the host ignorant of which body an image takes, so every step issues
+// both kernels and, for the usual all-dense or all-separable batch, one of them finds no work: three launches of a few
+// thousand workgroups that leave at once, 6 us each on the critical path.  The two kernels of a step touch different
+// images, so the stencil bodies' three launches go to the context's side stream -- forked behind the spectra, joined
+// before the call returns -- and run (or evaporate) beside the tile-spectrum launches instead of between them.
 int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
-    bool fft = true;
+    bool fft = ctx->fft_min_phases >= 0;
     for (int s = 0; s < 3; ++s) fft = fft && fft_pass_ok(steps[s]);
+    const int B = steps[0].P / steps[0].C;
+    const auto known = ctx->rec_cache.find(steps[0].info);
+    const bool have = known != ctx->rec_cache.end() && known->second.B == B;
+    if (!fft || have || !ctx->aux) {
+        for (int s = 0; s < 3; ++s) {
+            ConvPass p = steps[s];
+            p.khat_ready = s > 0;
+            if (!fft) p.no_fft = 1;
+            const int rc = pb_launch_conv(ctx, p);
+            if (rc) return rc;
+        }
+        return PB_OK;
+    }
+    float *k = nullptr; pb_fft_sel *sel = nullptr;
+    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, true);
+    if (rc) return rc;
+    PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->aux;
+    for (int s = 0; s < 3 && !rc; ++s) {
+        ConvPass p = steps[s];
+        p.khat = k; p.fsel = sel;
+        rc = launch_stencil(ctx, p);
+    }
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    PB_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
     for (int s = 0; s < 3; ++s) {
         ConvPass p = steps[s];
-        p.khat_ready = s > 0;
-        if (!fft) p.no_fft = 1;
-        const int rc = pb_launch_conv(ctx, p);
-        if (rc) return rc;
+        p.khat = k; p.fsel = sel;
+        rc = ctx->fft_wave ? pb_launch_conv_wfft(ctx, p) : PB_ERR_UNSUPPORTED;
+        if (rc == PB_ERR_UNSUPPORTED) rc = pb_launch_conv_fft(ctx, p);
+        if (rc) break;
     }
-    return PB_OK;
+    PB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return rc;
 }
 
 // The host has just (re)built these B records and is synchronising anyway: build their spectra, read the per-image choice
