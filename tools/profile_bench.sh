@@ -3,7 +3,7 @@
 # default bench.py command; summaries land in gpurun_out/ and are then committed under profiles/.
 #   gpurun -- 'bash tools/profile_bench.sh r02'   (every pass under `timeout`: a failed pass must not hang the box)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
