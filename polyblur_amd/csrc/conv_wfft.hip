@@ -293,46 +293,49 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
             for (int y = 0; y < 64; ++y) v[y] = (cf){(float)(lane + y), (float)(lane - y)};
         } else if constexpr (FAST) {
             // Interior fp32 pair on 16-byte boundaries: the union of the two windows (64 + T columns) goes global -> LDS in
-            // 16-byte pieces, half the rows at a time -- the rows of the first-stage groups n2 = 0..3, then those of
-            // n2 = 4..7, LDS rows of 128 floats: one wave instruction fills two of them -- and every lane picks its
-            // column's two samples per row from there.  (Four-byte loads straight into the registers cost one vector
-            // memory instruction per row and tile, 128 per pair instead of 32: the pass was bound by their issue.)
+            // 16-byte pieces (four-byte loads straight into the registers cost one vector memory instruction per row and
+            // tile, 128 per pair instead of 32: the pass was bound by their issue), LDS rows of 128 floats -- one wave
+            // instruction fills two of them --, sixteen rows at a time through two LDS buffers: chunk k holds the rows
+            // 8 n1 + 2k, 8 n1 + 2k + 1 of the first-stage groups n2 = 2k, 2k + 1, so the column transform starts on what
+            // has arrived while the rest is in flight, and every lane picks its column's two samples per row with one
+            // ds_read2_b32.  Two chunks are requested before the first is waited for and the next as soon as a buffer has
+            // been read: one memory latency per pair.
             constexpr int C4 = (FT_N + T) / 4;
             const int c = lane & 31;
             // (lanes past the union's last piece repeat it rather than go out of range: see the note at dma16)
             const unsigned vo = (unsigned)(lane >> 5) * pitchb + (unsigned)(wxA - lo + 4 * min(c, C4 - 1)) * 4u;
             const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
             lds_char *zl = lds_ptr(zb);
-            // (the rows of groups 0..3 go straight into LDS; those of groups 4..7 are requested at the same time into
-            // registers and pass through the same LDS rows once the first half has been picked up: one memory latency
-            // per pair, not two)
-            f4v late[16];
+            auto request = [&](int k, int buf) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int y0 = 8 * (k >> 1) + 2 * (k & 1);
-                dma16<0>(rin, zl + k * 1024, vo, (int)(row0 + (unsigned)y0 * pitchb));
-            }
+                for (int j = 0; j < 8; ++j) dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (int)(row0 + (unsigned)(8 * j + 2 * k) * pitchb));
+            };
+            // (the LDS reads are issued behind the compiler's back: it would make every read of either buffer wait for ALL
+            // outstanding LDS-DMA; the waits for the right chunk are placed by hand, and the wait that follows a chunk's
+            // reads names their destinations, so that nothing using them can be scheduled above it)
+            const unsigned la = lds_addr(zb) + (unsigned)lane * 4u;
+            auto pick = [&](int k, int buf) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int y0 = 8 * (k >> 1) + 2 * (k & 1) + 4;
-                late[k] = ld_b128(rin, vo, (int)(row0 + (unsigned)y0 * pitchb));
-            }
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned ad = la + (unsigned)(buf * 8192 + j * 1024);
+                    asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(v[8 * j + 2 * k]) : "v"(ad), "n"(T));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:%2" : "=v"(v[8 * j + 2 * k + 1]) : "v"(ad), "n"(128 + T));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[2 * k]), "+v"(v[2 * k + 1]), "+v"(v[8 + 2 * k]), "+v"(v[9 + 2 * k]), "+v"(v[16 + 2 * k]),
+                             "+v"(v[17 + 2 * k]), "+v"(v[24 + 2 * k]), "+v"(v[25 + 2 * k]), "+v"(v[32 + 2 * k]), "+v"(v[33 + 2 * k]), "+v"(v[40 + 2 * k]),
+                             "+v"(v[41 + 2 * k]), "+v"(v[48 + 2 * k]), "+v"(v[49 + 2 * k]), "+v"(v[56 + 2 * k]), "+v"(v[57 + 2 * k]) :: "memory");
+            };
+            request(0, 0); request(1, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            pick(0, 0);
+            request(2, 0);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            pick(1, 1);
+            request(3, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            pick(2, 0);
             wait_vm0();
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int y = 8 * (r >> 2) + (r & 3);
-                v[y] = (cf){Zf[r * 128 + lane], Zf[r * 128 + T + lane]};
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < 16; ++k) *reinterpret_cast<f4v *>(Zf + k * 256 + lane * 4) = late[k];
-            wave_lds_fence();
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int y = 8 * (r >> 2) + (r & 3) + 4;
-                v[y] = (cf){Zf[r * 128 + lane], Zf[r * 128 + T + lane]};
-            }
-            wave_lds_fence();
+            pick(3, 1);
         } else if (wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB) {
             const unsigned colA = (unsigned)(wxA - lo + lane) * (unsigned)sizeof(TIn), colB = colA + T * (unsigned)sizeof(TIn);
             const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
