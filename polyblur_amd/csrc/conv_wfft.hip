@@ -371,21 +371,18 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
     transpose64(v, Z, lane);
     PB_T(4);
     {
-        // the image's spectrum (16 KB) goes global -> LDS while the first row stage runs; lane = transformed row py reads
-        // kh[px][py] for the eight px of each centre-stage group
-        wait_lds0();
+        // the image's spectrum (16 KB, resident in L2), [x position][y position]: lane = transformed row py reads kh[px][py]
+        // for every px -- 64 coalesced requests that travel while the first row stage runs (through LDS they cost a
+        // DMA pass, 64 LDS reads and the wait for both)
         const brsrc rk = plane_rsrc(kp, (long)FT_N * FT_N);
-        lds_char *zl = lds_ptr(zb);
-#pragma unroll
-        for (int k = 0; k < ((PB_ABL & 2) ? 0 : 16); ++k) dma16<0>(rk, zl + k * 1024, (unsigned)lane * 16u, k * 1024);
-        fft64_fwd_stage1(v);                                    // rows
-        wait_vm0();
-        PB_T(5);
         float kh[64];
 #pragma unroll
-        for (int p = 0; p < 64; ++p) kh[p] = Zf[p * FT_N + lane];
+        for (int p = 0; p < 64; ++p) {
+            if constexpr (PB_ABL & 2) kh[p] = 1.0f; else kh[p] = BufIO<float>::ld(rk, (unsigned)lane * 4u, p * (FT_N * 4));
+        }
+        fft64_fwd_stage1(v);                                    // rows
+        PB_T(5);
         fft64_centre(v, kh);                                    // stage 2, x spectrum, inverse stage 2
-        wave_lds_fence();
     }
     fft64_inv_stage1(v);
     PB_T(6);
