@@ -294,6 +294,31 @@ typedef enum pb_prof_tag {
 int pb_profile_begin(pb_ctx *ctx);
 int pb_profile_end(pb_ctx *ctx, float *host_ms, int *host_count);
 
+/* ---- batch scatter / gather over RCCL (one process per GPU) ----------------------------------
+ * The reference has no communication (its only batching is the sequential patch-group loop of
+ * deblurring.py:310-336).  Images are independent, so the one exchange the engine needs is: the batch
+ * lives on a root rank, every rank deblurs a contiguous shard, the results return to the root.  These
+ * entry points give that to a host without torch.distributed (the Python layer uses torch's process
+ * group, polyblur_amd/distributed.py): grouped ncclSend / ncclRecv on the context's stream, xGMI
+ * inside a node.  RCCL (librccl.so) is loaded when the first id / communicator is made.
+ *
+ *   rank 0:      pb_comm_unique_id(id);  ship the 128 bytes to the other ranks (file, socket, MPI ...)
+ *   every rank:  pb_comm_init(&comm, ctx, rank, world, id);        (world == 1: id may be NULL)
+ *                pb_comm_shard(B, world, rank, &first, &count);    contiguous shards, the first B % world get one more
+ *                pb_comm_scatter(comm, root_batch, shard, dtype, B, C, H, W, root);
+ *                pb_polyblur_batch(ctx, shard, shard_out, dtype, count, C, H, W, &opt, NULL);
+ *                pb_comm_gather(comm, shard_out, root_batch_out, dtype, B, C, H, W, root);
+ * root_batch is read / written on the root only (NULL elsewhere); a rank whose shard is empty may pass
+ * NULL for its shard.  Everything is asynchronous on the context's stream.                              */
+#define PB_COMM_ID_BYTES 128
+typedef struct pb_comm pb_comm;
+int pb_comm_shard(int B, int world, int rank, int *first, int *count);
+int pb_comm_unique_id(unsigned char *id);
+int pb_comm_init(pb_comm **comm, pb_ctx *ctx, int rank, int world, const unsigned char *id);
+int pb_comm_destroy(pb_comm *comm);
+int pb_comm_scatter(pb_comm *comm, const void *root_batch, void *shard, int dtype, int B, int C, int H, int W, int root);
+int pb_comm_gather(pb_comm *comm, const void *shard, void *root_batch, int dtype, int B, int C, int H, int W, int root);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@ SYMBOLS = [
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
     "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
     "pb_fft_length_supported", "pb_make_separable_kernels", "pb_set_dense_eval",
+    "pb_comm_shard", "pb_comm_unique_id", "pb_comm_init", "pb_comm_destroy", "pb_comm_scatter", "pb_comm_gather",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused", "conv_fft"]
 
@@ -138,6 +139,12 @@ def load_library():
             "pb_make_separable_kernels": (ci, [vp, ci, vp, vp, ci, ci]),
             "pb_profile_begin": (ci, [vp]),
             "pb_profile_end": (ci, [vp, fp, C.POINTER(ci)]),
+            "pb_comm_shard": (ci, [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]),
+            "pb_comm_unique_id": (ci, [C.c_char_p]),
+            "pb_comm_init": (ci, [C.POINTER(vp), vp, ci, ci, C.c_char_p]),
+            "pb_comm_destroy": (ci, [vp]),
+            "pb_comm_scatter": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci]),
+            "pb_comm_gather": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci]),
         }
         for name in SYMBOLS:
             fn = getattr(lib, name)           # AttributeError if the library does not export it

@@ -110,3 +110,20 @@ def test_patch_lattice_matches_reference_formulas():
     import torch
     for n in (400, 7):
         assert np.abs(kaiser_window_periodic(n) - torch.kaiser_window(n, periodic=True, beta=5.0).numpy()).max() < 1e-6
+
+
+def test_comm_shards_match_the_python_layer(lib):
+    """pb_comm_shard (csrc/comm.hip) and polyblur_amd.distributed.shard_bounds cut a batch the same way."""
+    from polyblur_amd.distributed import shard_bounds
+    for B in (0, 1, 7, 8, 9, 64, 256):
+        for world in (1, 2, 3, 8):
+            covered = 0
+            for rank in range(world):
+                first, count = ctypes.c_int(), ctypes.c_int()
+                assert lib.pb_comm_shard(B, world, rank, ctypes.byref(first), ctypes.byref(count)) == 0
+                lo, hi = shard_bounds(B, world, rank)
+                assert (first.value, first.value + count.value) == (lo, hi)
+                covered += count.value
+            assert covered == B
+    first, count = ctypes.c_int(), ctypes.c_int()
+    assert lib.pb_comm_shard(4, 2, 2, ctypes.byref(first), ctypes.byref(count)) != 0      # rank out of range

@@ -66,3 +66,28 @@ dist.barrier(); dist.destroy_process_group()
     assert r.returncode == 0, r.stderr[-2000:]
     res = _line(r.stdout)
     assert res == {"equal": True, "world": 1}
+
+
+def test_c_abi_communicator_world_of_one():
+    """pb_comm_* with one rank: no RCCL traffic, the scatter and the gather are device copies of the whole batch; the
+    unique id comes from the RCCL library the engine loads on demand."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from polyblur_amd import _capi as capi
+    from polyblur_amd.engine import get_engine
+    eng = get_engine(0)
+    lib = eng.lib
+    ident = C.create_string_buffer(128)
+    assert lib.pb_comm_unique_id(ident) == 0 and any(ident.raw)
+    comm = C.c_void_p()
+    eng._check(lib.pb_comm_init(C.byref(comm), eng.ctx, 0, 1, None))
+    B, Cc, H, W = 3, 3, 40, 56
+    x = torch.rand(B, Cc, H, W, device="cuda")
+    shard = torch.zeros_like(x)
+    back = torch.zeros_like(x)
+    eng._check(lib.pb_comm_scatter(comm, C.c_void_p(x.data_ptr()), C.c_void_p(shard.data_ptr()), capi.PB_F32, B, Cc, H, W, 0))
+    eng._check(lib.pb_comm_gather(comm, C.c_void_p(shard.data_ptr()), C.c_void_p(back.data_ptr()), capi.PB_F32, B, Cc, H, W, 0))
+    eng.synchronize()
+    assert torch.equal(shard, x) and torch.equal(back, x)
+    assert lib.pb_comm_destroy(comm) == 0

@@ -18,5 +18,5 @@ for o in "$OBJ"/*.o; do
   OBJS="$OBJS $use"
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/lib_$NAME.so" $OBJS
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/lib_$NAME.so" $OBJS -ldl
 echo "$OUT/lib_$NAME.so"
