@@ -105,7 +105,8 @@ typedef struct pb_options {
                                    reach 9x the image range, where an fp16 ulp is 7.8e-3 -- measured 2e-3 .. 4.4e-3 from
                                    the fp32-temporary result; default 0 = fp32 temporaries             */
     int32_t ker_size;           /* support of the estimated Gaussian and, halved, the replicate pad (deblurring.py:23,
-                                   blur_estimation.py:211-232, utils.py:48-53): odd, 3 .. 25 (default 25; 0 means 25) */
+                                   blur_estimation.py:211-232, utils.py:48-53): 2 .. 25 (default 25; 0 means 25); even sizes are
+                                   off-centre as in the reference and keep the stencil bodies */
 } pb_options;
 
 /* Per-image, per-iteration estimation record (device or host copy). Mirrors the values the

@@ -377,8 +377,9 @@ def correlate_same_zero(x: np.ndarray, kernel: np.ndarray) -> np.ndarray:
     b, ch, h, w = x.shape
     k = _per_image_kernel(kernel, b)
     kh, kw = k.shape[-2:]
-    ry, rx = kh // 2, kw // 2
-    xp = np.pad(x, [(0, 0), (0, 0), (ry, ry), (rx, rx)])
+    # padding='same': kh - 1 rows in all, (kh - 1) // 2 of them in front -- for an even kernel one fewer than behind
+    ty, tx = (kh - 1) // 2, (kw - 1) // 2
+    xp = np.pad(x, [(0, 0), (0, 0), (ty, kh - 1 - ty), (tx, kw - 1 - tx)])
     out = np.zeros_like(x)
     for i in range(kh):
         for j in range(kw):

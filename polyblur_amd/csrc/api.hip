@@ -416,7 +416,7 @@ int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, 
     pb_default_options(&o);
     o.ker_size = ker_size;
     const int ksize = pb_kernel_size(&o);
-    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", ker_size, PB_KSIZE);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", ker_size, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
     pb_forget_records(ctx, dev_sep, 2 * B);
     return pb_make_sep_records(ctx, B, dev_info, dev_sep, support, ksize);
@@ -558,7 +558,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (opt->n_iter < 0) return pb_fail(ctx, PB_ERR_BADARG, "n_iter < 0");
     if (opt->boundary != PB_WRAP && opt->boundary != PB_ZERO) return pb_fail(ctx, PB_ERR_BADARG, "bad boundary");
     const int ksize = pb_kernel_size(opt);
-    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", opt->ker_size, PB_KSIZE);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE);
     if (opt->separable_approx && opt->edgetaping)
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "edgetaping is not defined for the separable approximation");
     PB_HIP(hipSetDevice(ctx->device));

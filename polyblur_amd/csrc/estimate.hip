@@ -776,8 +776,9 @@ __device__ float block_sum(float v, float *red) {
 
 // Fills kernel (unless from_taps), marginals, autocorrelations, separability and radius of one
 // record.  Called by all NT threads of a block.
+// shift: an EVEN ker_size under the wrap boundary ('fft') -- see the tap formula below.
 __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red, int ksize,
-                              const float *par = nullptr) {
+                              const float *par = nullptr, int shift = 0) {
     // Everything is derived in LDS from the taps; the record in global memory is only written (a dependent chain of
     // global round trips made this single-workgroup kernel the longest latency of small calls).
     __shared__ float sk[PB_KSIZE * PB_KSIZE], skx[PB_KSIZE], sky[PB_KSIZE];
@@ -802,10 +803,17 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
             e[q] = 0.f;
             if (idx < PB_KSIZE * PB_KSIZE) {
                 const int iy = idx / PB_KSIZE - PB_KRAD, ix = idx % PB_KSIZE - PB_KRAD;
-                const float Y = (float)iy, X = (float)ix;
+                // A ker_size x ker_size kernel (blur_estimation.py:222) sits in the 25 x 25 record whose tap (iy, ix)
+                // multiplies the sample (iy, ix) away from the output.  Odd sizes: centred, |offset| <= ker_size / 2.
+                // EVEN sizes: the reference's grid arange(k) - (k - 1) // 2 = -k/2+1 .. k/2 is off-centre, and where the
+                // taps land differs by method -- F.conv2d's 'same' padding (filters.py:46) puts k/2 - 1 samples in front
+                // and k/2 behind and correlates: tap G(u) at offset u = -k/2+1 .. k/2; 'fft' rolls the kernel array by
+                // k // 2 and convolves (filters.py:268-273): the same offsets, but entry i sits at offset k/2 - i, i.e.
+                // tap G(1 - u) = G(u - 1) at offset u -- the Gaussian centred on offset +1 (shift).
+                const int lo = (ksize & 1) ? -(ksize / 2) : -(ksize / 2) + 1, hi = ksize / 2;
+                const float Y = (float)(iy - shift), X = (float)(ix - shift);
                 const float quad = (X * a00 + Y * a01) * X + (X * a01 + Y * a11) * Y;
-                // a ker_size x ker_size kernel (blur_estimation.py:222) sits in the centre of the 25 x 25 record
-                e[q] = (abs(iy) <= ksize / 2 && abs(ix) <= ksize / 2) ? expf(-0.5f * quad) : 0.f;
+                e[q] = (iy >= lo && iy <= hi && ix >= lo && ix <= hi) ? expf(-0.5f * quad) : 0.f;
                 part += e[q];
             }
         }
@@ -875,7 +883,8 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     if (tid < PB_KSIZE) live_t = thr > 0.f ? (fabsf(skx[tid]) >= thr || fabsf(sky[tid]) >= thr) : (nz[tid] != 0);
     const unsigned long long live_mask = __ballot(live_t);          // thread 0 reads wave 0's: lanes 0..24
     if (tid == 0) {
-        info->separable = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL)) ? 1 : 0;
+        // (an even-sized kernel is never taken for rank-1: that body keeps symmetrised halves of the marginals)
+        info->separable = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL) && (from_taps || (ksize & 1))) ? 1 : 0;
         int rad = 0;
         if (live_mask) {
             const int lo = __ffsll((long long)live_mask) - 1, hi = 63 - __clzll((long long)live_mask);
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
                                                          const unsigned *__restrict__ mags_u,
                                                          const float *__restrict__ wts, int n_angles, int n_interp,
                                                          float c, float b, int support, float force_theta_deg,
-                                                         int tiles_per_image, int ksize) {
+                                                         int tiles_per_image, int ksize, int shift) {
     __shared__ float red[NT / 64];
     __shared__ float s_mags[PB_MAX_ANGLES], s_interp[PB_MAX_INTERP];
     pb_blur_info *info = infos + blockIdx.x;
@@ -1024,7 +1033,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
         }
     }
     __syncthreads();
-    finish_record(info, support, false, red, ksize, s_par);
+    finish_record(info, support, false, red, ksize, s_par, shift);
 }
 
 // method='direct_separable': the two correlation kernels of the x-t separable approximation of the image's Gaussian
@@ -1238,7 +1247,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                      pb_blur_info *dev_info) {
     if (opt->q < 0.f || opt->q >= 0.5f) return pb_fail(ctx, PB_ERR_BADARG, "q must be in [0, 0.5)");
     const int ksize = pb_kernel_size(opt);
-    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: odd sizes from 3 to %d are built", opt->ker_size, PB_KSIZE);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE);
     if (opt->n_angles < 1 || opt->n_angles + 1 > PB_MAX_ANGLES || opt->n_interpolated_angles < 1 ||
         opt->n_interpolated_angles > PB_MAX_INTERP)
         return pb_fail(ctx, PB_ERR_BADARG, "n_angles / n_interpolated_angles out of range");
@@ -1304,14 +1313,15 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (rc) return rc;
     ProfScope prof(ctx, PB_PROF_PARAMS);
     hipLaunchKernelGGL(blur_params_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
-                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles, ksize);
+                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles, ksize,
+                       (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
 
 int pb_kernel_size(const pb_options *opt) {
     const int k = opt->ker_size == 0 ? PB_KSIZE : opt->ker_size;
-    return (k >= 3 && k <= PB_KSIZE && (k & 1)) ? k : 0;
+    return (k >= 2 && k <= PB_KSIZE) ? k : 0;
 }
 
 int pb_make_sep_records(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *sep, int support, int ksize) {

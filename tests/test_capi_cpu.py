@@ -62,7 +62,7 @@ def test_argument_validation_before_any_device_work():
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=31)
     with pytest.raises(NotImplementedError):
-        polyblur_deblurring(x, ker_size=12)
+        polyblur_deblurring(x, ker_size=12, edgetaping=True)
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, method="direct_separable", edgetaping=True)
     with pytest.raises(ValueError):

@@ -782,7 +782,7 @@ def test_streams_and_threads_do_not_share_scratch(eng):
     assert all(torch.equal(a, b) for a, b in zip(other, want[1:]))
 
 
-@pytest.mark.parametrize("k", [5, 13, 21])
+@pytest.mark.parametrize("k", [5, 13, 21, 4, 12, 24])
 @pytest.mark.parametrize("method", ["fft", "direct"])
 def test_kernel_sizes_against_reference_goldens(golden, k, method):
     """ker_size != 25 (deblurring.py:23): the estimated Gaussian is k x k and the replicate pad k // 2, so the wrap /
@@ -798,7 +798,7 @@ def test_kernel_sizes_against_reference_goldens(golden, k, method):
         assert maxabs(out, g["k13_fft_taper_halo"]) < 2e-5
 
 
-@pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64))])
+@pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64)), (2, (1, 3, 20, 17)), (8, (2, 1, 33, 40)), (22, (1, 3, 64, 70))])
 def test_kernel_sizes_against_oracle(k, shape):
     import torch
     from polyblur_amd import polyblur_deblurring
