@@ -454,7 +454,7 @@ struct RowsIO {
 // FUSED: the fused transform (direct plans of two or more stages), with 128 threads for lines of up to 4096 samples;
 // otherwise the general one (Bluestein, one stage)
 template <int NTH, bool FUSED>
-__global__ __launch_bounds__(NTH) void grad_rows_kernel(const float *__restrict__ planes, float *__restrict__ gx,
+__global__ __launch_bounds__(NTH, (NTH == 256 && FUSED) ? 5 : 1) void grad_rows_kernel(const float *__restrict__ planes, float *__restrict__ gx,
                                                        int H, int W, int normalize, const unsigned *__restrict__ mm,
                                                        int planes_per_image, pbfft::DevPlan plan) {
     extern __shared__ __attribute__((aligned(16))) float2 sfft[];
@@ -1145,9 +1145,9 @@ int pick_lognb(const FftPlan *pl, int W, int P, bool wide_ok, int *threads) {
 }
 
 // Rows: a workgroup's transform is a chain of dependent stages, so the kernel is as fast as the number of chains in
-// flight.  Lines of up to 4096 samples (32 KB of LDS per two rows) fit five workgroups per CU, which the registers of
-// 256-thread workgroups do not allow (three): those run with 128 threads.  Longer lines are limited by LDS to two or
-// three workgroups per CU and keep 256 threads (measured at 7680: 241 us per 8K image against 339 us with 128).
+// flight.  Lines of up to 4096 samples (32 KB of LDS per two rows) fit five workgroups per CU; with many more
+// workgroups than that they run 128 threads.  Longer lines are limited by LDS to two or three workgroups per CU and
+// keep 256 threads (measured at 7680: 241 us per 8K image against 339 us with 128).
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
                 const unsigned *mm, int planes_per_image) {
     const FftPlan *pl = pb_get_plan(ctx, W);
@@ -1165,8 +1165,14 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
         hipLaunchKernelGGL((grad_rows_kernel<NTH, FUSED>), dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream,  \
                            planes, gx, H, W, normalize ? 1 : 0, mm, planes_per_image, dp);                       \
     } while (0)
+    // A grid that fits the chip in ONE round of five workgroups per CU (a single 4K image: 1080) is a race of dependent
+    // chains, and 256 threads -- one butterfly per thread and stage, held to 96 registers so that five such workgroups
+    // still fit a CU -- shorten every chain: 41.0 -> 33.4 us at 4K, 17.4 -> 15.8 us at 700 x 500.  Larger grids are
+    // throughput-bound and keep 128 threads (8 x 1080p: 63.7 us against 70.0 with 256).
+    static const int force_nt = [] { const char *e = getenv("PB_ROWS_NT"); return e ? atoi(e) : 0; }();
+    const bool one_round = blocks <= 256L * 5;
     if (!fused) PB_ROWS(256, false);
-    else if (lds <= 32 * 1024) PB_ROWS(128, true);
+    else if (lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_ROWS(128, true);
     else PB_ROWS(256, true);
 #undef PB_ROWS
     PB_LAUNCH_CHECK();
