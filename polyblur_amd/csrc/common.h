@@ -69,6 +69,7 @@ struct pb_ctx {
     std::map<const void *, RecFlags> rec_cache;
     const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)
     const void *khat_buf = nullptr;
+    bool khat_by_estimate = false;       // ... written by the estimation's own parameter kernel (device-built records)
 };
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);
@@ -155,6 +156,7 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps);
 int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // conv_xt.hip
 int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch);
+int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel);   // the scratch alone (the estimation fills it itself)
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // conv.hip: after the host (re)built these records
 void pb_forget_records(pb_ctx *ctx, const void *info, int B);                 // B records at info are about to be rewritten; nullptr: all
 void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory

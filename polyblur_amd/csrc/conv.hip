@@ -343,7 +343,7 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     if (fft) {
         float *k = nullptr; pb_fft_sel *s = nullptr;
         // (spectra an earlier pass built count only while the scratch still holds them for these records)
-        const bool built = (p.khat_ready || have) && ctx->khat_owner == p.info;
+        const bool built = (p.khat_ready || have || ctx->khat_by_estimate) && ctx->khat_owner == p.info;
         const int rc = pb_build_khat(ctx, p.info, B, &k, &s, !built);
         if (rc) return rc;
         p.khat = k; p.fsel = s;
@@ -388,7 +388,8 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
         return PB_OK;
     }
     float *k = nullptr; pb_fft_sel *sel = nullptr;
-    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, true);
+    // (records the estimation has just built bring their spectra with them: blur_params_kernel ends with them)
+    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !(ctx->khat_by_estimate && ctx->khat_owner == steps[0].info));
     if (rc) return rc;
     PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
@@ -435,15 +436,22 @@ void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes) {
     for (auto it = ctx->rec_cache.begin(); it != ctx->rec_cache.end();) {
         const char *a = static_cast<const char *>(it->first), *b = a + sizeof(pb_blur_info) * (size_t)it->second.B;
         if (a < hi && lo < b) {
-            if (ctx->khat_owner == it->first) ctx->khat_owner = nullptr;
+            if (ctx->khat_owner == it->first) { ctx->khat_owner = nullptr; ctx->khat_by_estimate = false; }
             it = ctx->rec_cache.erase(it);
         } else ++it;
     }
 }
 void pb_forget_records(pb_ctx *ctx, const void *info, int B) {
-    if (info) { pb_forget_range(ctx, info, sizeof(pb_blur_info) * (size_t)B); return; }
+    if (info) {
+        pb_forget_range(ctx, info, sizeof(pb_blur_info) * (size_t)B);
+        // (device-built records are not in the cache, but the spectra scratch may be theirs)
+        const char *a = static_cast<const char *>(info), *b = a + sizeof(pb_blur_info) * (size_t)B, *o = static_cast<const char *>(ctx->khat_owner);
+        if (o && o >= a && o < b) { ctx->khat_owner = nullptr; ctx->khat_by_estimate = false; }
+        return;
+    }
     ctx->rec_cache.clear();
     ctx->khat_owner = nullptr;
+    ctx->khat_by_estimate = false;
 }
 
 static int launch_stencil(pb_ctx *ctx, const ConvPass &p) {

@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "fft.h"
+#include "khat.h"
 
 namespace {
 
@@ -945,11 +946,28 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
                                                          const unsigned *__restrict__ mags_u,
                                                          const float *__restrict__ wts, int n_angles, int n_interp,
                                                          float c, float b, int support, float force_theta_deg,
-                                                         int tiles_per_image, int ksize, int shift) {
+                                                         int tiles_per_image, int ksize, int shift,
+                                                         const float2 *__restrict__ part, int blocks_per_image, unsigned *mm_out,
+                                                         float *khat, pb_fft_sel *fsel, int min_phases) {
     __shared__ float red[NT / 64];
     __shared__ float s_mags[PB_MAX_ANGLES], s_interp[PB_MAX_INTERP];
+    __shared__ float s_lo[NT / 64], s_hi[NT / 64];
     pb_blur_info *info = infos + blockIdx.x;
     const int na = n_angles + 1;
+    // q == 0 (part != nullptr): the transforms ran on the UN-normalised gray image -- the derivative is linear and kills
+    // the offset, and without quantiles the clip of normalize() never acts (blur_estimation.py:92-109) -- so the
+    // gray kernel's per-workgroup (min, max) are folded here, off the transforms' critical path, and the maxima are
+    // divided by the range below.
+    float rng_lo = 0.f, rng_hi = 0.f, rng_inv = 1.f;
+    float plo = INFINITY, phi = -INFINITY;
+    if (part) {
+        // (requested here, folded behind the maxima's barrier below: one exposed memory latency for both)
+        for (int i = threadIdx.x; i < blocks_per_image; i += NT) {
+            const float2 p = part[(long)blockIdx.x * blocks_per_image + i];
+            plo = fminf(plo, p.x);
+            phi = fmaxf(phi, p.y);
+        }
+    }
     {
         // fold the per-tile partial maxima of this image: 16 lanes per direction, every lane's loads in flight together
         __shared__ float s_part[NT];
@@ -979,9 +997,25 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         s_part[threadIdx.x] = m;
+        if (part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                plo = fminf(plo, __shfl_xor(plo, o));
+                phi = fmaxf(phi, __shfl_xor(phi, o));
+            }
+            if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = plo; s_hi[threadIdx.x >> 6] = phi; }
+        }
         __syncthreads();
+        if (part) {
+            float lo = s_lo[0], hi = s_hi[0];
+            for (int w = 1; w < NT / 64; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+            rng_lo = lo; rng_hi = hi;
+            // (a constant image: the reference's 0 / 0 makes every sample NaN; the maxima of NaN samples are 0 here as there)
+            rng_inv = hi > lo ? 1.f / (hi - lo) : 0.f;
+            if (threadIdx.x == 0) { mm_out[2 * blockIdx.x] = pb_f2ord(lo); mm_out[2 * blockIdx.x + 1] = pb_f2ord(hi); }
+        }
         if (threadIdx.x < PB_MAX_ANGLES) {
-            const float v = (int)threadIdx.x < na ? s_part[threadIdx.x * 16] : 0.f;
+            const float v = (int)threadIdx.x < na ? s_part[threadIdx.x * 16] * rng_inv : 0.f;
             s_mags[threadIdx.x] = v;
             info->mags[threadIdx.x] = v;
         }
@@ -1028,12 +1062,20 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
             info->sigma = s_par[1];
             info->rho = s_par[2];
             info->i_min = i_min;
-            info->gray_min = pb_ord2f(mm[2 * blockIdx.x]);
-            info->gray_max = pb_ord2f(mm[2 * blockIdx.x + 1]);
+            info->gray_min = part ? rng_lo : pb_ord2f(mm[2 * blockIdx.x]);
+            info->gray_max = part ? rng_hi : pb_ord2f(mm[2 * blockIdx.x + 1]);
         }
     }
     __syncthreads();
     finish_record(info, support, false, red, ksize, s_par, shift);
+    // The spectrum of the kernel just built and the image's choice of body for the reblurring passes (khat.h): the grid is
+    // KH_SLICES workgroups per image, every one of which has formed the whole record above (a few microseconds of
+    // redundant latency-bound work, identical values) and now forms its slice -- one launch less on every iteration's
+    // critical path than a kernel of its own behind this one.
+    if (khat) {
+        __syncthreads();                                  // (this workgroup's own writes of the record are visible to its reads)
+        khat_body(info, khat + (long)blockIdx.x * (KH_FT_N * KH_FT_N), fsel + blockIdx.x, min_phases, (int)blockIdx.y);
+    }
 }
 
 // method='direct_separable': the two correlation kernels of the x-t separable approximation of the image's Gaussian
@@ -1269,6 +1311,8 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (!gray || !gx || !mm || !mags) return PB_ERR_NOMEM;
     const float *wts = pb_get_interp_weights(ctx, opt->n_angles, opt->n_interpolated_angles);
     if (!wts) return PB_ERR_NOMEM;
+    const float2 *part_q0 = nullptr;
+    int bpi_q0 = 0;
     {
     ProfScope prof(ctx, PB_PROF_GRAY);
     const bool vec = (HW & 3) == 0;
@@ -1287,7 +1331,9 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     else { if (vec) PB_GRAY_C(unsigned char, true); else PB_GRAY_C(unsigned char, false); }
 #undef PB_GRAY_C
 #undef PB_GRAY
-    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(B), dim3(NT), 0, ctx->stream, part, mm, bpi);
+    part_q0 = part; bpi_q0 = bpi;
+    // (q == 0: the parameter kernel folds the partials itself -- see there -- and nothing below waits for the range)
+    if (opt->q > 0.f) hipLaunchKernelGGL(minmax_reduce_kernel, dim3(B), dim3(NT), 0, ctx->stream, part, mm, bpi);
     if (opt->q > 0.f) {
         // replace (min, max) by the (q, 1-q) quantiles: three histogram + scan rounds
         const size_t hbytes = sizeof(unsigned) * (size_t)B * 4 * 4096;
@@ -1313,15 +1359,24 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     }
     PB_LAUNCH_CHECK();
     }
-    int rc = launch_rows(ctx, gray, gx, B, H, W, true, mm, 1);
+    const bool norm = opt->q > 0.f;                  // q == 0: transforms of the un-normalised image, maxima rescaled afterwards
+    int rc = launch_rows(ctx, gray, gx, B, H, W, norm, mm, 1);
     if (rc) return rc;
-    rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, true, mm, 1, mags, opt->n_angles, opt->discard_saturation);
+    rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, norm, mm, 1, mags, opt->n_angles, opt->discard_saturation);
     if (rc) return rc;
+    float *khat = nullptr;
+    pb_fft_sel *fsel = nullptr;
+    if (ctx->fft_min_phases >= 0) {
+        rc = pb_khat_buffers(ctx, B, &khat, &fsel);
+        if (rc) return rc;
+    }
     ProfScope prof(ctx, PB_PROF_PARAMS);
-    hipLaunchKernelGGL(blur_params_kernel, dim3(B), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
+    hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? KH_SLICES : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles, ksize,
-                       (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0);
+                       (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
+                       ctx->fft_min_phases);
     PB_LAUNCH_CHECK();
+    if (khat) { ctx->khat_owner = dev_info; ctx->khat_by_estimate = true; }
     return PB_OK;
 }
 

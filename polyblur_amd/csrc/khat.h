@@ -1,0 +1,101 @@
+// The spectrum of an image's kernel and the choice of body for its reblurring passes (shared by conv_fft.hip, whose
+// khat_kernel serves records the host built, and estimate.hip, whose parameter kernel ends with it: one launch less on
+// the critical path of every iteration).
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int KH_FT_N = 64, KH_THREADS = 256;
+// cos / sin (2 pi m / 64) in double, for the spectra
+static __device__ const double kCos64[64] = {
+    1, 0.99518472667219693, 0.98078528040323043, 0.95694033573220882,
+    0.92387953251128674, 0.88192126434835505, 0.83146961230254524, 0.77301045336273699,
+    0.70710678118654757, 0.63439328416364549, 0.55557023301960229, 0.47139673682599781,
+    0.38268343236508984, 0.29028467725446233, 0.19509032201612833, 0.09801714032956077,
+    0, -0.098017140329560645, -0.19509032201612819, -0.29028467725446216,
+    -0.38268343236508973, -0.4713967368259977, -0.55557023301960196, -0.63439328416364538,
+    -0.70710678118654746, -0.77301045336273699, -0.83146961230254535, -0.88192126434835494,
+    -0.92387953251128674, -0.95694033573220882, -0.98078528040323043, -0.99518472667219682,
+    -1, -0.99518472667219693, -0.98078528040323043, -0.95694033573220894,
+    -0.92387953251128685, -0.88192126434835505, -0.83146961230254546, -0.7730104533627371,
+    -0.70710678118654768, -0.63439328416364593, -0.55557023301960218, -0.47139673682599786,
+    -0.38268343236509034, -0.29028467725446244, -0.19509032201612866, -0.098017140329560451,
+    0, 0.09801714032956009, 0.1950903220161283, 0.29028467725446205,
+    0.38268343236509, 0.47139673682599759, 0.55557023301960184, 0.6343932841636456,
+    0.70710678118654735, 0.77301045336273666, 0.83146961230254524, 0.88192126434835483,
+    0.92387953251128652, 0.95694033573220882, 0.98078528040323032, 0.99518472667219693
+};
+static __device__ const double kSin64[64] = {
+    0, 0.098017140329560604, 0.19509032201612825, 0.29028467725446233,
+    0.38268343236508978, 0.47139673682599764, 0.55557023301960218, 0.63439328416364549,
+    0.70710678118654746, 0.77301045336273699, 0.83146961230254524, 0.88192126434835494,
+    0.92387953251128674, 0.95694033573220894, 0.98078528040323043, 0.99518472667219682,
+    1, 0.99518472667219693, 0.98078528040323043, 0.95694033573220894,
+    0.92387953251128674, 0.88192126434835505, 0.83146961230254546, 0.7730104533627371,
+    0.70710678118654757, 0.63439328416364549, 0.55557023301960218, 0.47139673682599786,
+    0.38268343236508989, 0.29028467725446239, 0.19509032201612861, 0.098017140329560826,
+    0, -0.09801714032956059, -0.19509032201612836, -0.29028467725446211,
+    -0.38268343236508967, -0.47139673682599764, -0.55557023301960196, -0.63439328416364527,
+    -0.70710678118654746, -0.77301045336273666, -0.83146961230254524, -0.88192126434835494,
+    -0.92387953251128652, -0.95694033573220882, -0.98078528040323032, -0.99518472667219693,
+    -1, -0.99518472667219693, -0.98078528040323043, -0.95694033573220894,
+    -0.92387953251128663, -0.88192126434835505, -0.83146961230254546, -0.77301045336273688,
+    -0.70710678118654768, -0.63439328416364593, -0.55557023301960218, -0.47139673682599792,
+    -0.38268343236509039, -0.2902846772544625, -0.19509032201612872, -0.098017140329560506
+};
+constexpr int KH_SLICES = 8;          // workgroups per image: each forms the spectrum at 8 of the 64 x positions
+
+// Called by all KH_THREADS threads of a workgroup: slice `slice` (0 .. KH_SLICES - 1) of the spectrum of `info`'s taps,
+// and (slice 0) the image's choice of body.  The record may have been written by this same workgroup just before (global
+// memory, then a barrier): it is read through the vector path.
+__device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, pb_fft_sel *sel, int min_phases, int slice) {
+    constexpr int NR = PB_KRAD + 1, PXS = KH_FT_N / KH_SLICES;
+    __shared__ double2 G[NR * PXS];
+    __shared__ double cs[KH_FT_N], sn[KH_FT_N];
+    __shared__ float sk[PB_KSIZE * PB_KSIZE];
+    const int tid = threadIdx.x;
+    const int nph = info->nphase[0] + info->nphase[1] + info->nphase[2];
+    const int R = info->radius;
+    if (tid < KH_FT_N) { cs[tid] = kCos64[tid]; sn[tid] = kSin64[tid]; }
+    bool sym = true;
+    for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) {
+        const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
+        const bool in = abs(u) <= R && abs(v) <= R;
+        const float k = info->kernel[i];
+        sk[i] = in ? k : 0.f;
+        sym = sym && (!in || k == info->kernel[PB_KSIZE * PB_KSIZE - 1 - i]);
+    }
+    // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
+    const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0) && min_phases >= 0;
+    if (tid == 0 && slice == 0) { sel->use_fft = use ? 1 : 0; sel->rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
+    if (!use) return;
+    // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
+    // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u}); this workgroup's x positions only
+    const int px0 = slice * PXS;
+    if (tid < NR * PXS) {
+        const int u = tid / PXS + PB_KRAD, px = px0 + tid % PXS, fx = (px >> 3) + 8 * (px & 7);
+        double ar = 0.0, ai = 0.0;
+#pragma unroll 5
+        for (int v = 0; v < PB_KSIZE; ++v) {
+            const int m = (fx * (v - PB_KRAD)) & 63;
+            const double k = (double)sk[u * PB_KSIZE + v];
+            ar += k * cs[m]; ai += k * sn[m];
+        }
+        G[tid] = make_double2(ar, ai);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < PXS * KH_FT_N; idx += KH_THREADS) {          // stored transposed: [x position][y position]
+        const int pxl = idx >> 6, py = idx & 63, fy = (py >> 3) + 8 * (py & 7);
+        double ar = 0.5 * G[pxl].x;
+#pragma unroll 4
+        for (int u = 1; u < NR; ++u) {
+            const int m = (fy * u) & 63;
+            const double2 g = G[u * PXS + pxl];
+            ar += g.x * cs[m] - g.y * sn[m];
+        }
+        out[(px0 + pxl) * KH_FT_N + py] = (float)(ar * (2.0 / 4096.0));
+    }
+}
+
+}  // namespace
