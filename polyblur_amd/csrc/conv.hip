@@ -377,7 +377,9 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     const int B = steps[0].P / steps[0].C;
     const auto known = ctx->rec_cache.find(steps[0].info);
     const bool have = known != ctx->rec_cache.end() && known->second.B == B;
-    if (!fft || have || !ctx->aux) {
+    // (per-launch profiling keeps everything on one stream: events on the side stream would time its launches' wait
+    // behind the other kernel's workgroups, not their work)
+    if (!fft || have || !ctx->aux || ctx->prof_on) {
         for (int s = 0; s < 3; ++s) {
             ConvPass p = steps[s];
             p.khat_ready = s > 0;
