@@ -264,6 +264,33 @@ __device__ __forceinline__ void st_b128(brsrc r, unsigned voffset, int soffset, 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)(voffset + (unsigned)soffset), 0, 0);
 }
 
+// four horizontally adjacent samples of the x operand / of the output as one piece: 16 bytes of fp32, 8 bytes of fp16
+template <typename T> struct Piece4;
+template <> struct Piece4<float> {
+    typedef f4v raw;
+    static __device__ __forceinline__ raw ld(brsrc r, unsigned vo, int so) { return ld_b128(r, vo, so); }
+    static __device__ __forceinline__ f4v to_f(raw v) { return v; }
+    static __device__ __forceinline__ void st(brsrc r, unsigned vo, int so, f4v v) { st_b128(r, vo, so, v); }
+};
+template <> struct Piece4<__half> {
+    typedef uint2 raw;
+    static __device__ __forceinline__ raw ld(brsrc r, unsigned vo, int so) {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        const u2v t = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(r, (int)vo, so, 0));
+        return make_uint2(t[0], t[1]);
+    }
+    static __device__ __forceinline__ f4v to_f(raw v) {
+        const float2 a = __half22float2(__builtin_bit_cast(__half2, v.x)), b = __half22float2(__builtin_bit_cast(__half2, v.y));
+        return (f4v){a.x, a.y, b.x, b.y};
+    }
+    static __device__ __forceinline__ void st(brsrc r, unsigned vo, int so, f4v v) {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+        const u2v t = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+        __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)vo, so, 0);
+    }
+};
+
 // One window pair.  zb: the wave's LDS region (kWfLdsWave bytes); kp: the image's spectrum, [x position][y position].
 template <int R, bool FAST, typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, char *zb,
@@ -409,17 +436,18 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         constexpr int NR = T / NRND, C = 2 * T / 4, NK = (NR * C + 63) / 64;
         constexpr int PT = 2 * T;
         static_assert(NR * NRND == T, "rounds must tile the rows");
-        f4v xq[2][NK];
-        const int xso = (int)((unsigned)(oy0 - xsh) * xpitchb + (unsigned)(oxA - xsh) * 4u);
-        const int oso = (int)((unsigned)(oy0 - oo) * opitchb + (unsigned)(oxA - oo) * 4u);
+        typename Piece4<TX>::raw xq[2][NK];
+        constexpr unsigned XP = 4 * sizeof(TX), OP = 4 * sizeof(TOut);                 // bytes per piece of x / of the output
+        const int xso = (int)((unsigned)(oy0 - xsh) * xpitchb + (unsigned)(oxA - xsh) * (unsigned)sizeof(TX));
+        const int oso = (int)((unsigned)(oy0 - oo) * opitchb + (unsigned)(oxA - oo) * (unsigned)sizeof(TOut));
         auto request = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if constexpr (q < NRND) {
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
                     const int e = 64 * k + lane, rl = e / C, ch = e - rl * C;
-                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * xpitchb + (unsigned)ch * 16u : kNoAccess;
-                    if constexpr (PB_ABL & 4) xq[q & 1][k] = (f4v){1.f, 2.f, 3.f, (float)lane}; else xq[q & 1][k] = ld_b128(rx, vo, xso);
+                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * xpitchb + (unsigned)ch * XP : kNoAccess;
+                    xq[q & 1][k] = Piece4<TX>::ld(rx, vo, xso);
                 }
             }
         };
@@ -437,7 +465,7 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                 for (int k = 0; k < NK; ++k) {
                     const int e = 64 * k + lane, rl = e / C, ch = e - rl * C;
                     const f4v acc = *reinterpret_cast<const f4v *>(Zf + min(rl, NR - 1) * PT + 4 * ch);
-                    const f4v x4 = xq[q & 1][k];
+                    const f4v x4 = Piece4<TX>::to_f(xq[q & 1][k]);
                     f4v o;
                     o.x = fmaf(sc, acc.x, cfx * x4.x); o.y = fmaf(sc, acc.y, cfx * x4.y);
                     o.z = fmaf(sc, acc.z, cfx * x4.z); o.w = fmaf(sc, acc.w, cfx * x4.w);
@@ -445,8 +473,8 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                         o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
                         o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
                     }
-                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * opitchb + (unsigned)ch * 16u : kNoAccess;
-                    if constexpr (PB_ABL & 4) { if (o.x == 123.456f) st_b128(ro, vo, oso, o); } else st_b128(ro, vo, oso, o);
+                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * opitchb + (unsigned)ch * OP : kNoAccess;
+                    Piece4<TOut>::st(ro, vo, oso, o);
                 }
                 wave_lds_fence();
             }
@@ -543,7 +571,9 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
 // rows / origins on 16-byte boundaries.
 template <int R, typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi) {
-    if (sizeof(TIn) != 4 || sizeof(TX) != 4 || sizeof(TOut) != 4 || a.epilogue != EPI_HORNER) return false;
+    // (the window must be fp32 -- the planes between the steps always are; the x operand and the output may be fp16: four
+    // samples are then an 8-byte piece)
+    if (sizeof(TIn) != 4 || sizeof(TX) < 2 || sizeof(TOut) < 2 || a.epilogue != EPI_HORNER) return false;
     constexpr int T = FT_N - 2 * R;
     const OutRegion rg = out_region(a);
     const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
@@ -686,6 +716,12 @@ extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
 // PB_ERR_UNSUPPORTED: dtype combination not built (the caller falls back to the workgroup body).
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
     ProfScope prof(ctx, PB_PROF_CONV_FFT);
-    if (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype != 0) return PB_ERR_UNSUPPORTED;
-    return launch_wfft_typed<float, float, float>(ctx, p);
+    // fp32 planes, and the second and third Horner step of fp16 images (fp32 temporaries in, fp16 x operand, fp32 or fp16
+    // out); the first step of an fp16 image -- its window is fp16 -- stays with the workgroup form
+    switch (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype) {
+        case 0: return launch_wfft_typed<float, float, float>(ctx, p);
+        case 3: return launch_wfft_typed<float, __half, float>(ctx, p);
+        case 4: return launch_wfft_typed<float, __half, __half>(ctx, p);
+        default: return PB_ERR_UNSUPPORTED;
+    }
 }
