@@ -37,6 +37,7 @@
 // No MFMA, no library FFT.
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_fft_common.h"
@@ -713,8 +714,17 @@ extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
 }
 #endif
 
-// PB_ERR_UNSUPPORTED: dtype combination not built (the caller falls back to the workgroup body).
+// PB_ERR_UNSUPPORTED: dtype combination not built, or a pass so small that the workgroup form is the faster one (the caller
+// falls back to it).  A wave takes ~19 us for its pair whatever the size of the launch, a 512-thread workgroup ~8 us: a pass
+// whose pairs do not even fill the chip's 2048 wave slots once is a race of single pairs (700 x 500: 420 pairs, 0.31 ms per
+// call through the workgroup form against 0.38 ms), from about one and a half rounds on the wave form wins.
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
+    static const long min_jobs = [] { const char *e = getenv("PB_WAVE_MIN_JOBS"); return e ? atol(e) : 3000L; }();
+    {
+        WGeom g;
+        long total_max = 0;
+        if (wfft_geometry(p, g, total_max) && total_max < min_jobs) return PB_ERR_UNSUPPORTED;
+    }
     ProfScope prof(ctx, PB_PROF_CONV_FFT);
     // fp32 planes, and the second and third Horner step of fp16 images (fp32 temporaries in, fp16 x operand, fp32 or fp16
     // out); the first step of an fp16 image -- its window is fp16 -- stays with the workgroup form
