@@ -161,7 +161,8 @@ void pb_default_options(pb_options *opt);        /* the functional API's default
  * stencil would run at least `min_phases` live (kernel row, 4-tap segment) phases (8 more when the support fits a
  * 4-sample halo; min_phases = 0: every dense point-symmetric kernel) are evaluated per 64 x 64 window in
  * the frequency domain inside LDS (overlap-save; same taps, same boundary models, results agree to fp32 rounding);
- * the others, rank-1 kernels and 8-bit images keep the stencil bodies.  Replaces nothing in the reference: both are
+ * the others and rank-1 kernels keep the stencil bodies (fp32 planes: one wave per window pair, conv_wfft.hip; fp16 and
+ * 8-bit planes, and passes too small to fill the chip: one workgroup per pair, conv_fft.hip).  Replaces nothing in the reference: both are
  * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>. */
 typedef enum pb_dense_eval { PB_DENSE_STENCIL = 0, PB_DENSE_AUTO = 1 } pb_dense_eval;
 int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases);

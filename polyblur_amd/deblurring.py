@@ -141,9 +141,12 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
         eng.set_stream(0)                                   # host arrays: the device's default stream
         if verbose:
             eng.profile_begin()
-        res = eng.polyblur(x, opts, want_info=return_info)
+        try:
+            res = eng.polyblur(x, opts, want_info=return_info)
+        finally:                                            # (a failed call must not leave the thread's context profiling)
+            prof = eng.profile_end() if verbose else None
         if verbose:
-            _print_stage_times(eng.profile_end(), time() - start)
+            _print_stage_times(prof, time() - start)
         out, info = res if return_info else (res, None)
         # utils.to_array (utils.py:24-31): squeeze, CHW -> HWC
         out = np.squeeze(out)
@@ -174,18 +177,24 @@ def polyblur_deblurring(img, n_iter=1, c=0.352, b=0.768, alpha=2, beta=3, sigma_
             eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
             if verbose:
                 eng.profile_begin()
-            info = eng.polyblur_ptr(xin.data_ptr(), out.data_ptr(), dtype, xin.shape, opts, want_info=return_info)
+            try:
+                info = eng.polyblur_ptr(xin.data_ptr(), out.data_ptr(), dtype, xin.shape, opts, want_info=return_info)
+            finally:                                        # (a failed call must not leave the thread's context profiling)
+                prof = eng.profile_end() if verbose else None
     else:
         eng = get_engine(0 if device is None else int(device))
         eng.set_stream(0)
         if verbose:
             eng.profile_begin()
         arr = img.detach().contiguous().numpy()
-        res = eng.polyblur(arr, opts, want_info=return_info)
+        try:
+            res = eng.polyblur(arr, opts, want_info=return_info)
+        finally:
+            prof = eng.profile_end() if verbose else None
         o, info = res if return_info else (res, None)
         out = torch.from_numpy(o)
     if verbose:
-        _print_stage_times(eng.profile_end(), time() - start)
+        _print_stage_times(prof, time() - start)
     return (out, _info_to_dicts(info, n_angles, n_interpolated_angles)) if return_info else out
 
 

@@ -296,18 +296,34 @@ class Engine:
         return float(ms.value)
 
 
-_engines = {}
-_elock = threading.Lock()
+_tls = threading.local()
+
+
+class _ThreadEngines:
+    """The engines of one host thread; closed (contexts destroyed, scratch freed) when the thread ends."""
+
+    def __init__(self):
+        self.by_device = {}
+
+    def __del__(self):
+        for e in self.by_device.values():
+            try:
+                e.close()
+            except Exception:
+                pass
 
 
 def get_engine(device: int = 0) -> Engine:
     """The calling thread's Engine for a GPU (created on first use).  A pb_ctx is not thread-safe and owns its
-    scratch buffers, so every host thread gets its own; within a thread, calls on different streams are ordered
-    by pb_set_stream (the new stream waits for the work queued on the previous one)."""
-    key = (int(device), threading.get_ident())
-    with _elock:
-        e = _engines.get(key)
-        if e is None or e.ctx is None:
-            e = Engine(device)
-            _engines[key] = e
-        return e
+    scratch buffers, so every host thread gets its own -- kept in thread-local storage, so that a thread that ends takes
+    its contexts (and their HBM) with it and a recycled thread id never inherits another thread's engine; within a
+    thread, calls on different streams are ordered by pb_set_stream (the new stream waits for the work queued on the
+    previous one)."""
+    box = getattr(_tls, "engines", None)
+    if box is None:
+        box = _tls.engines = _ThreadEngines()
+    e = box.by_device.get(int(device))
+    if e is None or e.ctx is None:
+        e = Engine(device)
+        box.by_device[int(device)] = e
+    return e

@@ -158,3 +158,29 @@ def test_full_size_pass_is_deterministic(eng):
             first = out
         else:
             assert int((out != first).sum().item()) == 0
+
+
+def test_rewriting_one_record_of_a_cached_set(eng):
+    """Record facts are forgotten by RANGE: a B = 4 all-dense set is cached (the host knows that no image needs the
+    stencil launch), then record 2 alone is rewritten as a rank-1 kernel through pb_make_kernels -- the whole set must
+    forget, or the next pass would skip the stencil launch and leave image 2's output unwritten."""
+    import ctypes as C
+    B = 4
+    x, _ = synthetic_blurry_batch(B, 3, 70, 90, seed0=21)
+    eng.set_dense_eval("auto", 0)
+    th = np.deg2rad(np.float32([30.0, 40.0, 50.0, 60.0]))
+    buf = eng.make_kernels([2.0] * B, [1.0] * B, th, name="np.rewrite")
+    first = eng.inverse_filter(x, buf, 6.0, 1.0, capi.PB_WRAP)
+    # one record in the middle of the set, rewritten in place as an axis-aligned (rank-1) Gaussian
+    fp = C.POINTER(C.c_float)
+    one = lambda v: np.ascontiguousarray([v], np.float32).ctypes.data_as(fp)
+    eng._check(eng.lib.pb_make_kernels(eng.ctx, 1, one(2.5), one(1.0), one(0.0), capi.PB_SUPPORT_FULL,
+                                       C.c_void_p(buf.ptr + 2 * capi.INFO_DTYPE.itemsize)))
+    info = eng.read_info(buf, B)
+    assert list(info["separable"]) == [0, 0, 1, 0]
+    eng.buffer("np.out", x.nbytes).upload(np.full(x.shape, 7.0, np.float32))          # poison: an unwritten image would show
+    out = eng.inverse_filter(x, buf, 6.0, 1.0, capi.PB_WRAP)
+    k = ref.gaussian_kernel_2d(np.float32([th[0], th[1], 0.0, th[3]]), [2.0, 2.0, 2.5, 2.0], [1.0] * B)
+    want = ref.inverse_filtering_rank3(x, k[:, None], 6.0, 1.0, method="fft")
+    assert maxabs(out, want) < 1e-5
+    assert maxabs(out[[0, 1, 3]], first[[0, 1, 3]]) == 0.0
