@@ -163,7 +163,9 @@ void pb_default_options(pb_options *opt);        /* the functional API's default
  * the frequency domain inside LDS (overlap-save; same taps, same boundary models, results agree to fp32 rounding);
  * the others and rank-1 kernels keep the stencil bodies (fp32 planes: one wave per window pair, conv_wfft.hip; fp16 and
  * 8-bit planes, and passes too small to fill the chip: one workgroup per pair, conv_fft.hip).  Replaces nothing in the reference: both are
- * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>. */
+ * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>.
+ * (PB_STRIP=1 in the environment sends rank-1 kernels of full support on fp32 planes through the streaming strip body,
+ * conv_strip.hip: an experiment measured slower than the tile body; same results to fp32 rounding.) */
 typedef enum pb_dense_eval { PB_DENSE_STENCIL = 0, PB_DENSE_AUTO = 1 } pb_dense_eval;
 int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases);
 /* bytes of scratch the context currently holds (for the HBM-footprint report) */

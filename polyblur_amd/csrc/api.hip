@@ -86,6 +86,7 @@ int pb_create(pb_ctx **out, int device, void *stream) {
         else if (e[0] >= '0' && e[0] <= '9') ctx->fft_min_phases = atoi(e);
     }
     if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
+    if (const char *e = getenv("PB_STRIP")) ctx->strip_mode = atoi(e);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     const char *side = getenv("PB_SIDE_STREAM");

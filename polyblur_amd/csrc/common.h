@@ -65,11 +65,12 @@ struct pb_ctx {
     // anyway): whether any image takes the tile-spectrum body, whether any takes a stencil body -- a reblurring pass then
     // skips the launch nobody needs -- and whose spectra the context's scratch currently holds.  Records estimated on the
     // device (the pipeline) are never in here: their passes issue both launches.
-    struct RecFlags { int B; bool any_fft, any_other; };
+    struct RecFlags { int B; bool any_fft, any_other, any_strip, any_tile; };   // any_other = any_strip || any_tile (by body of the fp32 pass)
     std::map<const void *, RecFlags> rec_cache;
     const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)
     const void *khat_buf = nullptr;
-    bool khat_by_estimate = false;       // ... written by the estimation's own parameter kernel (device-built records)
+    bool khat_by_estimate = false;
+    int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
 };
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);
@@ -126,7 +127,7 @@ enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
        EPI_TAPER = 1 };   // out = a * x + (1-a) * (K*in),  a = v1[py] * v2[px]
 
 // per image: which body evaluates a dense kernel (written on the device by khat_kernel, conv_fft.hip)
-struct pb_fft_sel { int use_fft; int rf; };       // rf = window halo of the tile-spectrum body: 4, 8 or 12
+struct pb_fft_sel { int use_fft; int rf; int strip; int pad_; };   // rf = window halo of the tile-spectrum body: 4, 8 or 12; strip: rank-1 kernel of full support (conv_strip.hip may take it)
 
 struct ConvPass {
     const void *in;  int in_kind;  int in_dtype;  int in_pitch;  long in_plane;
@@ -148,6 +149,7 @@ struct ConvPass {
     const pb_fft_sel *fsel;
     const float *khat;
     int khat_ready;
+    int strip;           // rank-1 images of full support are done by conv_strip.hip's launch of this step: their tiles exit at once
     int no_fft;          // this pass keeps the stencil bodies (pb_launch_conv_poly: some step of the polynomial does not suit the other)
 };
 
@@ -161,6 +163,7 @@ int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // co
 void pb_forget_records(pb_ctx *ctx, const void *info, int B);                 // B records at info are about to be rewritten; nullptr: all
 void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
+int pb_launch_conv_strip(pb_ctx *ctx, const ConvPass &p);                    // conv_strip.hip; PB_ERR_UNSUPPORTED: not an all-fp32 plain Horner pass
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p);                     // conv_wfft.hip; PB_ERR_UNSUPPORTED: dtype combination not built
 bool pb_conv_fft_feasible(const ConvPass &p);                                // window counts within the kernel's index arithmetic
 

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int 
     const PB_CONSTANT pb_blur_info *cinfo = as_constant(info);
     const bool sep = cinfo->separable != 0;
     if (sep ? a.skip_sep : a.skip_general) return;                 // another launch of this step does this image
+    if (sep && a.strip && cinfo->radius > 8) return;               // the streaming strip body (conv_strip.hip) does this image
     if (!sep && a.fsel && as_constant(a.fsel + plane / a.C)->use_fft) return;     // the tile-spectrum body (conv_fft.hip) does this image
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
@@ -350,7 +351,20 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     } else if (!p.khat_ready && !have) {
         ctx->khat_owner = nullptr;      // device-built records took a pass without spectra: whatever the scratch holds is not theirs
     }
-    if (!(fft && have && !known->second.any_other)) {
+    // rank-1 kernels of full support on fp32 planes: the streaming strip body (host-built records only: with device-built
+    // ones it would be one more launch that usually finds no work)
+    const bool strip = ctx->strip_mode && have && known->second.any_strip && p.in_dtype == PB_F32 && p.x_dtype == PB_F32 &&
+                       p.out_dtype == PB_F32 && p.epilogue == EPI_HORNER && p.pad == PB_KRAD && !p.skip_sep;
+    bool strip_done = false;
+    if (strip) {
+        p.strip = 1;
+        const int rc = pb_launch_conv_strip(ctx, p);
+        if (rc == PB_OK) strip_done = true;
+        else if (rc != PB_ERR_UNSUPPORTED) return rc;
+        else p.strip = 0;
+    }
+    const bool tile_needed = !have || (strip_done ? known->second.any_tile : known->second.any_other);
+    if (tile_needed && !(fft && have && !known->second.any_other)) {
         const int rc = launch_stencil(ctx, p);
         if (rc) return rc;
     }
@@ -427,8 +441,11 @@ int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B) {
     std::vector<pb_fft_sel> h(B);
     PB_HIP(hipMemcpyAsync(h.data(), s, sizeof(pb_fft_sel) * B, hipMemcpyDeviceToHost, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
-    pb_ctx::RecFlags f{B, false, false};
-    for (const pb_fft_sel &e : h) { if (e.use_fft) f.any_fft = true; else f.any_other = true; }
+    pb_ctx::RecFlags f{B, false, false, false, false};
+    for (const pb_fft_sel &e : h) {
+        if (e.use_fft) f.any_fft = true;
+        else { f.any_other = true; if (e.strip) f.any_strip = true; else f.any_tile = true; }
+    }
     ctx->rec_cache[info] = f;
     return PB_OK;
 }

@@ -68,7 +68,10 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     }
     // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
     const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0) && min_phases >= 0;
-    if (tid == 0 && slice == 0) { sel->use_fft = use ? 1 : 0; sel->rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12); }
+    if (tid == 0 && slice == 0) {
+        sel->use_fft = use ? 1 : 0; sel->rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12);
+        sel->strip = (info->separable != 0 && R > 8) ? 1 : 0; sel->pad_ = 0;
+    }
     if (!use) return;
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
     // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u}); this workgroup's x positions only
