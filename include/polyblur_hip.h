@@ -215,11 +215,13 @@ int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, 
                               int ker_size);
 
 /* filters.fourier_gradients (filters.py:159-186) on P = B*C planes of H x W float32.
- * gx or gy may be NULL.  The transform keeps whole image lines in LDS: each of H and W must
- * satisfy pb_fft_length_supported() -- up to 20480 when every prime factor is <= 7, up to
- * 8192 otherwise (the reference's torch.fft takes any size).  The same limit applies to every
- * entry point that estimates blur or removes halos; they return PB_ERR_UNSUPPORTED beyond it. */
-int pb_fft_length_supported(int n);                 /* 1 or 0; needs no context */
+ * gx or gy may be NULL.  The transform keeps whole image lines in LDS when they fit -- up to 20480
+ * samples when every prime factor is <= 7, up to 8192 otherwise: pb_fft_length_supported() == 1 --
+ * and runs the same stages on a line buffer in device memory (context scratch, at most 256 MB; several
+ * times slower per sample) for longer lines up to 65536 samples: == 2.  Beyond that: 0, and every
+ * entry point that estimates blur or removes halos returns PB_ERR_UNSUPPORTED (the reference's
+ * torch.fft takes any size). */
+int pb_fft_length_supported(int n);                 /* 0, 1 or 2 (see above); needs no context */
 int pb_fourier_gradients(pb_ctx *ctx, const float *planes, int P, int H, int W,
                          float *gx, float *gy);
 

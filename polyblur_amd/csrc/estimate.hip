@@ -66,9 +66,11 @@ template <typename T> static T *upload(pb_ctx *ctx, const std::vector<T> &h) {
 }  // namespace
 
 // The spectral derivative keeps whole lines in LDS (160 KB): lengths up to 20480 when every prime factor is <= 7,
-// up to 8192 otherwise (Bluestein with a power-of-two core of at least 2n-1 points).
+// up to 8192 otherwise (Bluestein with a power-of-two core of at least 2n-1 points) -> 1.  Longer lines, up to 65536
+// samples, take the same stages on a line buffer in global memory (grad_*_long_kernel) -> 2.  Beyond that -> 0.
+constexpr int kMaxLineLength = 65536;
 extern "C" int pb_fft_length_supported(int n) {
-    if (n < 2) return 0;
+    if (n < 2 || n > kMaxLineLength) return 0;
     std::vector<int> radix;
     int rest = 1;
     factorize(n, radix, rest);
@@ -77,7 +79,7 @@ extern "C" int pb_fft_length_supported(int n) {
         core = 1;
         while (core < 2L * n - 1) core *= 2;
     }
-    return core * (long)sizeof(float2) <= 160 * 1024;
+    return core * (long)sizeof(float2) <= 160 * 1024 ? 1 : 2;
 }
 
 const FftPlan *pb_get_plan(pb_ctx *ctx, int n) {
@@ -762,6 +764,130 @@ __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
+// Lines that do not fit LDS (sides above 20480, or above 8192 with a prime factor > 7; the reference's torch.fft takes
+// any length, filters.py:172-184): the same transform, stage by stage, on a line buffer in GLOBAL memory.  A workgroup
+// owns one slot of the context's scratch (plan.n complex values per line: a few hundred KB, which stays in its XCD's L2
+// between the stages), walks over its share of the lines, and a stage's barrier orders its global accesses like its LDS
+// ones (all waves of a workgroup share the CU's L1, which is write-through).  Ten or so L2 round trips per line instead
+// of LDS ones: a fallback, several times slower per sample than the in-LDS kernels, for sizes that used to raise.
+// ------------------------------------------------------------------------------------
+constexpr int LONG_NT = 1024;
+
+__global__ __launch_bounds__(LONG_NT) void grad_rows_long_kernel(const float *__restrict__ planes, float *__restrict__ gx, int H, int W,
+                                                                int normalize, const unsigned *__restrict__ mm, int planes_per_image,
+                                                                pbfft::DevPlan plan, float2 *scratch, long items) {
+    float2 *s = scratch + (size_t)blockIdx.x * (size_t)plan.n;
+    const int pairs = (H + 1) / 2;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int plane = (int)(item / pairs);
+        const int r0 = 2 * (int)(item - (long)plane * pairs);
+        const bool has1 = r0 + 1 < H;
+        const float *row0 = planes + ((long)plane * H + r0) * W;
+        const float *row1 = row0 + W;
+        float lo = 0.f, scale = 1.f;
+        if (normalize) {
+            const int img = plane / planes_per_image;
+            lo = pb_ord2f(mm[2 * img]);
+            scale = pb_ord2f(mm[2 * img + 1]) - lo;
+        }
+        const float inv = 1.f / scale;
+        for (int n = threadIdx.x; n < W; n += LONG_NT) {
+            float a = row0[n], b = has1 ? row1[n] : 0.f;
+            if (normalize) {
+                a = norm01(a, lo, scale, inv);
+                b = has1 ? norm01(b, lo, scale, inv) : 0.f;
+            }
+            s[n] = make_float2(a, b);
+        }
+        __syncthreads();
+        pbfft::spectral_derivative(s, plan, 0);
+        float *o0 = gx + ((long)plane * H + r0) * W;
+        for (int n = threadIdx.x; n < W; n += LONG_NT) {
+            const float2 v = s[n];
+            o0[n] = v.x;
+            if (has1) o0[W + n] = -v.y;
+        }
+        __syncthreads();                                       // the slot is free for the next pair of rows
+    }
+}
+
+// MODE as grad_cols_kernel: 0 writes gy, 1 folds (gx, gy) into the directional maxima of the tile
+template <int MODE>
+__global__ __launch_bounds__(LONG_NT) void grad_cols_long_kernel(const float *__restrict__ planes, const float *__restrict__ gx,
+                                                                float *__restrict__ gy, int H, int W, int lognb, int normalize,
+                                                                const unsigned *__restrict__ mm, int planes_per_image,
+                                                                unsigned *__restrict__ mags, int n_angles, int discard_sat,
+                                                                float sat_threshold, int total_tiles, pbfft::DevPlan plan,
+                                                                AngleTable ang, float2 *scratch) {
+    __shared__ float red[LONG_NT / 64 * PB_MAX_ANGLES];
+    float2 *s = scratch + (size_t)blockIdx.x * ((size_t)plan.n << lognb);
+    const int nb = 1 << lognb;
+    const int tc = 2 * nb;
+    const int tiles = (W + tc - 1) / tc;
+    const int tiles_pad = (tiles + 3) & ~3;
+    const int work = H << lognb;                               // element e = p * nb + j  <->  row p, columns c0 + 2j, c0 + 2j + 1
+    for (int tile_id = blockIdx.x; tile_id < total_tiles; tile_id += gridDim.x) {
+        const int plane = tile_id / tiles;
+        const int c0 = (tile_id - plane * tiles) * tc;
+        const float *src = planes + (long)plane * H * W;
+        float lo = 0.f, scale = 1.f;
+        if (normalize) {
+            const int img = plane / planes_per_image;
+            lo = pb_ord2f(mm[2 * img]);
+            scale = pb_ord2f(mm[2 * img + 1]) - lo;
+        }
+        const float inv = 1.f / scale;
+        for (int e = threadIdx.x; e < work; e += LONG_NT) {
+            const int p = e >> lognb, c = c0 + 2 * (e & (nb - 1));
+            float a = c < W ? src[(long)p * W + c] : 0.f, b = c + 1 < W ? src[(long)p * W + c + 1] : 0.f;
+            if (normalize) {
+                a = norm01(a, lo, scale, inv);
+                b = norm01(b, lo, scale, inv);
+            }
+            s[e] = make_float2(a, b);
+        }
+        __syncthreads();
+        pbfft::spectral_derivative(s, plan, lognb);
+        if (MODE == 0) {
+            float *dst = gy + (long)plane * H * W;
+            for (int e = threadIdx.x; e < work; e += LONG_NT) {
+                const int p = e >> lognb, c = c0 + 2 * (e & (nb - 1));
+                const float2 v = s[e];
+                if (c < W) dst[(long)p * W + c] = v.x;
+                if (c + 1 < W) dst[(long)p * W + c + 1] = -v.y;
+            }
+            __syncthreads();
+        } else {
+            // m_k = max |cos(t_k) gx - sin(t_k) gy|, t_k = k pi / n_angles  (blur_estimation.py:129-133); gradients are
+            // zeroed under the saturation mask (blur_estimation.py:117-118): they cannot raise a maximum
+            float best[PB_MAX_ANGLES];
+#pragma unroll
+            for (int k = 0; k < PB_MAX_ANGLES; ++k) best[k] = 0.f;
+            const float *gxp = gx + (long)plane * H * W;
+            for (int e = threadIdx.x; e < work; e += LONG_NT) {
+                const int p = e >> lognb, c = c0 + 2 * (e & (nb - 1));
+                const float2 vv = s[e];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (c + h >= W) continue;
+                    const long idx = (long)p * W + c + h;
+                    if (discard_sat && src[idx] > sat_threshold) continue;
+                    const float dx = gxp[idx];
+                    const float dy = h ? -vv.y : vv.x;
+#pragma unroll
+                    for (int k = 0; k < PB_MAX_ANGLES; ++k)
+                        if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
+                }
+            }
+            __syncthreads();
+            reduce_maxima<LONG_NT>(best, red, mags + (long)plane * PB_MAX_ANGLES * tiles_pad + (tile_id - plane * tiles), tiles_pad,
+                                   n_angles);
+            __syncthreads();                                   // red and the slot are free for the next tile
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // parameters and kernels
 // ------------------------------------------------------------------------------------
 __device__ float block_sum(float v, float *red) {
@@ -1172,6 +1298,12 @@ template <typename K> int allow_lds(pb_ctx *ctx, K kernel, size_t bytes) {
 int pick_lognb(const FftPlan *pl, int W, int P, bool wide_ok, int *threads) {
     static int forced = -2;
     if (forced == -2) { const char *e = getenv("PB_FFT_LOGNB"); forced = e ? atoi(e) : -1; }
+    if (fft_lds_bytes(pl, 1) > kMaxLds) {          // lines through global memory (grad_cols_long_kernel): 8-column tiles
+        int lognb = 2;
+        while (lognb > 0 && (2 << (lognb - 1)) >= W * 2) --lognb;
+        if (threads) *threads = LONG_NT;
+        return lognb;
+    }
     int lognb = forced >= 0 ? forced : 3;
     while (lognb > 0 && fft_lds_bytes(pl, 1 << lognb) > 80 * 1024) --lognb;
     while (lognb > 0 && (2 << (lognb - 1)) >= W * 2) --lognb;
@@ -1186,6 +1318,13 @@ int pick_lognb(const FftPlan *pl, int W, int P, bool wide_ok, int *threads) {
     return lognb;
 }
 
+// Workgroups of a through-memory transform: one per work item up to what keeps the slots within 256 MB (at least 64)
+long long_grid(long items, size_t slot_bytes) {
+    long g = (long)((256UL << 20) / slot_bytes);
+    g = std::max(64L, std::min(1024L, g));
+    return std::max(1L, std::min(items, g));
+}
+
 // Rows: a workgroup's transform is a chain of dependent stages, so the kernel is as fast as the number of chains in
 // flight.  Lines of up to 4096 samples (32 KB of LDS per two rows) fit five workgroups per CU; with many more
 // workgroups than that they run 128 threads.  Longer lines are limited by LDS to two or three workgroups per CU and
@@ -1195,9 +1334,19 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     const FftPlan *pl = pb_get_plan(ctx, W);
     if (!pl) return PB_ERR_NOMEM;
     const size_t lds = fft_lds_bytes(pl, 1);
-    if (lds > kMaxLds) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image width %d too large for the in-LDS FFT", W);
     const long blocks = (long)P * ((H + 1) / 2);
     const pbfft::DevPlan dp = dev_plan(pl);
+    if (lds > kMaxLds) {                            // the line buffer in global memory, one slot per workgroup
+        if (!pb_fft_length_supported(W)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image width %d: lines of up to %d samples are supported", W, kMaxLineLength);
+        const long grid = long_grid(blocks, lds);
+        float2 *slots = static_cast<float2 *>(pb_scratch(ctx, "fft.long", (size_t)grid * lds));
+        if (!slots) return PB_ERR_NOMEM;
+        ProfScope prof(ctx, PB_PROF_GRAD_ROWS);
+        hipLaunchKernelGGL(grad_rows_long_kernel, dim3((unsigned)grid), dim3(LONG_NT), 0, ctx->stream, planes, gx, H, W,
+                           normalize ? 1 : 0, mm, planes_per_image, dp, slots, blocks);
+        PB_LAUNCH_CHECK();
+        return PB_OK;
+    }
     const bool fused = !pl->bluestein_m && pl->nstage >= 2;          // as pbfft::fused_plan
     ProfScope prof(ctx, PB_PROF_GRAD_ROWS);
 #define PB_ROWS(NTH, FUSED)                                                                                      \
@@ -1229,18 +1378,35 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     int nt = NT;
     const int lognb = pick_lognb(pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt);
     const size_t lds = fft_lds_bytes(pl, 1 << lognb);
-    if (lds > kMaxLds) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image height %d too large for the in-LDS FFT", H);
+    const bool through_memory = fft_lds_bytes(pl, 1) > kMaxLds;
+    if (through_memory && !pb_fft_length_supported(H))
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image height %d: lines of up to %d samples are supported", H, kMaxLineLength);
     const int tc = 2 << lognb;
     const long blocks = (long)P * ((W + tc - 1) / tc);
+    if (blocks > 0x7fffffffL) return pb_fail(ctx, PB_ERR_BADARG, "column transform: bad grid");
     const pbfft::DevPlan dp = dev_plan(pl);
     const float thr = 0.99f;
-    ProfScope prof(ctx, PB_PROF_GRAD_COLS);
     AngleTable ang;
     for (int k = 0; k < PB_MAX_ANGLES; ++k) {
         const float t = n_angles > 0 ? 3.14159265358979323846f * (float)k / (float)n_angles : 0.f;
         ang.cs[k] = std::cos(t);
         ang.sn[k] = std::sin(t);
     }
+    if (through_memory) {                           // as launch_rows: a slot of 2 << lognb columns per workgroup
+        const long grid = long_grid(blocks, lds);
+        float2 *slots = static_cast<float2 *>(pb_scratch(ctx, "fft.long", (size_t)grid * lds));
+        if (!slots) return PB_ERR_NOMEM;
+        ProfScope prof(ctx, PB_PROF_GRAD_COLS);
+        if (mode == 0)
+            hipLaunchKernelGGL(grad_cols_long_kernel<0>, dim3((unsigned)grid), dim3(LONG_NT), 0, ctx->stream, planes, gx, gy, H, W, lognb,
+                               normalize ? 1 : 0, mm, planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang, slots);
+        else
+            hipLaunchKernelGGL(grad_cols_long_kernel<1>, dim3((unsigned)grid), dim3(LONG_NT), 0, ctx->stream, planes, gx, gy, H, W, lognb,
+                               normalize ? 1 : 0, mm, planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang, slots);
+        PB_LAUNCH_CHECK();
+        return PB_OK;
+    }
+    ProfScope prof(ctx, PB_PROF_GRAD_COLS);
 #define PB_COLS(MODE, NA)                                                                                        \
     do {                                                                                                         \
         int rc = allow_lds(ctx, grad_cols_kernel<MODE, NA, NT>, lds);                                            \

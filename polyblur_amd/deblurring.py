@@ -43,12 +43,12 @@ _PREFILTER = {"bilateral": capi.PB_PREFILTER_BILATERAL, "domain_transform": capi
 
 
 def _check_image_size(h, w):
-    """The spectral derivative keeps whole image lines in LDS (include/polyblur_hip.h: pb_fft_length_supported)."""
+    """Line lengths the spectral derivative takes (include/polyblur_hip.h: pb_fft_length_supported): whole lines in LDS up
+    to 20480 samples (8192 when a prime factor exceeds 7), through a line buffer in device memory up to 65536."""
     lib = capi.load_library()
     for n, what in ((int(h), "height"), (int(w), "width")):
         if n >= 2 and not lib.pb_fft_length_supported(n):
-            raise ValueError("image %s %d is beyond the engine's in-LDS transform: sides up to 20480 are supported when "
-                             "all their prime factors are <= 7, up to 8192 otherwise" % (what, n))
+            raise ValueError("image %s %d is beyond the engine's spectral derivative: sides up to 65536 are supported" % (what, n))
 
 
 def _is_torch_tensor(x) -> bool:

@@ -127,3 +127,10 @@ def test_comm_shards_match_the_python_layer(lib):
             assert covered == B
     first, count = ctypes.c_int(), ctypes.c_int()
     assert lib.pb_comm_shard(4, 2, 2, ctypes.byref(first), ctypes.byref(count)) != 0      # rank out of range
+
+
+def test_line_length_tiers(lib):
+    """include/polyblur_hip.h: 1 = whole lines in LDS, 2 = through a line buffer in device memory, 0 = not taken"""
+    want = {1: 0, 2: 1, 4096: 1, 8191: 1, 8192: 1, 8200: 2, 20480: 1, 20736: 2, 40001: 2, 65536: 2, 65537: 0, 9000: 1, 12000: 1, 12001: 2}
+    for n, tier in want.items():
+        assert lib.pb_fft_length_supported(n) == tier, n
