@@ -87,6 +87,7 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     }
     if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
     if (const char *e = getenv("PB_STRIP")) ctx->strip_mode = atoi(e);
+    if (const char *e = getenv("PB_POLY1")) ctx->poly_mode = atoi(e);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     const char *side = getenv("PB_SIDE_STREAM");
@@ -330,7 +331,12 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     set_in_padded(p, g, T2, tdt); set_out_interior(p, g, dst, dst_dtype);
     p.coef = beta; p.clamp01 = clamp01;
     steps[2] = p;
-    return pb_launch_conv_poly(ctx, steps);
+    // (experiment, PB_POLY1=1: under the wrap boundary the three steps are one filter, deblurring.py:139-169 -- kernels
+    // within the 4-sample halo take it as one window pass; the spectra are then the polynomial's)
+    if (ctx->poly_mode && boundary == PB_WRAP && !xpadded) ctx->poly_want = PolySpec{1, a3, a2, a1, beta};
+    const int rc = pb_launch_conv_poly(ctx, steps);
+    ctx->poly_want = PolySpec{0, 0.f, 0.f, 0.f, 0.f};
+    return rc;
 }
 
 struct InverseScratch {
@@ -643,7 +649,12 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (dtype != PB_F32 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
         const int cur_dtype = it == 0 ? dtype : work, dst_dtype = it == n_iter - 1 ? dtype : work;
         pb_blur_info *info = infos + (size_t)it * B;
+        if (ctx->poly_mode && opt->boundary == PB_WRAP && !opt->edgetaping && !sep) {   // as run_polynomial will ask for
+            const float al = opt->alpha, be = opt->beta;
+            ctx->poly_want = PolySpec{1, al / 2 - be + 2, 3 * be - al - 6, 5 - 3 * be + al / 2, be};
+        }
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
+        ctx->poly_want = PolySpec{0, 0.f, 0.f, 0.f, 0.f};
         if (rc) return rc;
         if (sep) {
             rc = pb_make_sep_records(ctx, B, info, sep, opt->support, ksize);

@@ -38,6 +38,12 @@ struct ProfRec {
     int tag;
 };
 
+// one-pass polynomial experiment: which filter the spectra in the context's scratch are those of (see pb_fft_sel.poly)
+struct PolySpec { int on; float a3, a2, a1, b; };
+inline bool same_spec(const PolySpec &x, const PolySpec &y) {
+    return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b));
+}
+
 struct pb_ctx {
     bool prof_on = false;
     std::vector<ProfRec> prof;
@@ -70,6 +76,10 @@ struct pb_ctx {
     const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)
     const void *khat_buf = nullptr;
     bool khat_by_estimate = false;
+    // one-pass polynomial experiment (env PB_POLY1=1): what the spectra in "conv.khat" were built for, and what the call
+    // in progress wants (set around the estimation / the polynomial; off for every other pass)
+    int poly_mode = 0;
+    PolySpec poly_built{0, 0.f, 0.f, 0.f, 0.f}, poly_want{0, 0.f, 0.f, 0.f, 0.f};
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
 };
 
@@ -127,7 +137,11 @@ enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
        EPI_TAPER = 1 };   // out = a * x + (1-a) * (K*in),  a = v1[py] * v2[px]
 
 // per image: which body evaluates a dense kernel (written on the device by khat_kernel, conv_fft.hip)
-struct pb_fft_sel { int use_fft; int rf; int strip; int pad_; };   // rf = window halo of the tile-spectrum body: 4, 8 or 12; strip: rank-1 kernel of full support (conv_strip.hip may take it)
+struct pb_fft_sel { int use_fft; int rf; int strip; int poly; };   // rf = window halo of the tile-spectrum body: 4, 8 or 12; strip: rank-1 kernel of full support (conv_strip.hip may take it)
+// poly (experiment, env PB_POLY1=1): the image's spectrum is that of the WHOLE polynomial a3 K^3 + a2 K^2 + a1 K + b (the
+// reference's own 'fft' form, deblurring.py:139-169) and rf the halo of that composite filter, 3 x 4 = 12: one window
+// pass (ConvPass.poly = 1) replaces the image's three Horner steps, whose launches skip it.
+
 
 struct ConvPass {
     const void *in;  int in_kind;  int in_dtype;  int in_pitch;  long in_plane;
@@ -150,6 +164,7 @@ struct ConvPass {
     const float *khat;
     int khat_ready;
     int strip;           // rank-1 images of full support are done by conv_strip.hip's launch of this step: their tiles exit at once
+    int poly;            // 1: the composite pass of a polynomial -- only images whose pb_fft_sel.poly is set; 0: those images are skipped
     int no_fft;          // this pass keeps the stencil bodies (pb_launch_conv_poly: some step of the polynomial does not suit the other)
 };
 

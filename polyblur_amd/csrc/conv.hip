@@ -344,7 +344,7 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     if (fft) {
         float *k = nullptr; pb_fft_sel *s = nullptr;
         // (spectra an earlier pass built count only while the scratch still holds them for these records)
-        const bool built = (p.khat_ready || have || ctx->khat_by_estimate) && ctx->khat_owner == p.info;
+        const bool built = (p.khat_ready || have || ctx->khat_by_estimate || ctx->poly_mode) && ctx->khat_owner == p.info;   // (pb_build_khat also rebuilds spectra of another PolySpec)
         const int rc = pb_build_khat(ctx, p.info, B, &k, &s, !built);
         if (rc) return rc;
         p.khat = k; p.fsel = s;
@@ -393,6 +393,19 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     const bool have = known != ctx->rec_cache.end() && known->second.B == B;
     // (per-launch profiling keeps everything on one stream: events on the side stream would time its launches' wait
     // behind the other kernel's workgroups, not their work)
+    // One-pass polynomial (experiment): the images whose spectrum is the polynomial's take ONE window pass from the
+    // first step's input to the last step's output; the steps' own launches skip them.
+    auto composite = [&](float *k, pb_fft_sel *sel) -> int {
+        ConvPass pc = steps[0];
+        pc.out = steps[2].out; pc.out_kind = steps[2].out_kind; pc.out_dtype = steps[2].out_dtype;
+        pc.out_pitch = steps[2].out_pitch; pc.out_plane = steps[2].out_plane;
+        pc.scale = 1.f; pc.coef = 0.f; pc.clamp01 = steps[2].clamp01; pc.poly = 1;
+        pc.khat = k; pc.fsel = sel;
+        if (!fft_pass_ok(pc)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "one-pass polynomial: composite pass not feasible");
+        int rc = ctx->fft_wave ? pb_launch_conv_wfft(ctx, pc) : PB_ERR_UNSUPPORTED;
+        if (rc == PB_ERR_UNSUPPORTED) rc = pb_launch_conv_fft(ctx, pc);
+        return rc;
+    };
     if (!fft || have || !ctx->aux || ctx->prof_on) {
         for (int s = 0; s < 3; ++s) {
             ConvPass p = steps[s];
@@ -401,12 +414,19 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
             const int rc = pb_launch_conv(ctx, p);
             if (rc) return rc;
         }
+        if (fft && ctx->poly_built.on && ctx->khat_owner == steps[0].info) {
+            float *k = nullptr; pb_fft_sel *sel = nullptr;
+            const int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, false);
+            if (rc) return rc;
+            return composite(k, sel);
+        }
         return PB_OK;
     }
     float *k = nullptr; pb_fft_sel *sel = nullptr;
     // (records the estimation has just built bring their spectra with them: blur_params_kernel ends with them)
-    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !(ctx->khat_by_estimate && ctx->khat_owner == steps[0].info));
+    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !((ctx->khat_by_estimate || ctx->poly_mode) && ctx->khat_owner == steps[0].info));
     if (rc) return rc;
+    if (ctx->poly_built.on) { rc = composite(k, sel); if (rc) return rc; }
     PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     hipStream_t main_stream = ctx->stream;
@@ -435,6 +455,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B) {
     pb_forget_records(ctx, info, B);
     if (ctx->fft_min_phases < 0) return PB_OK;
+    if (ctx->poly_mode) return PB_OK;      // (one-pass polynomial experiment: which body an image takes depends on the pass; nothing is cached)
     float *k = nullptr; pb_fft_sel *s = nullptr;
     int rc = pb_build_khat(ctx, info, B, &k, &s, true);
     if (rc) return rc;

@@ -50,8 +50,8 @@ namespace {
 // double cosine table (the spectrum is then the correctly rounded fp32 one: with fp32 table values the pass loses 1e-6 of
 // agreement with the stencil).  Caller-supplied taps that are not point-symmetric keep the stencil body.
 static_assert(KH_NT == KH_THREADS && FT_N == KH_FT_N, "khat.h is written for these");
-__global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases) {
-    khat_body(infos + blockIdx.x, khat + (long)blockIdx.x * (FT_N * FT_N), sel + blockIdx.x, min_phases, (int)blockIdx.y);
+__global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases, const PolySpec ps) {
+    khat_body(infos + blockIdx.x, khat + (long)blockIdx.x * (FT_N * FT_N), sel + blockIdx.x, min_phases, (int)blockIdx.y, ps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, co
     const int img = __builtin_amdgcn_readfirstlane(plane / a.C);
     const PB_CONSTANT pb_fft_sel *sel = as_constant(a.fsel + img);
     if (!sel->use_fft) return;                                  // a stencil body of conv_tile_kernel does this image
+    if ((sel->poly != 0) != (a.poly != 0)) return;              // (one-pass polynomial: the composite pass does these images, and only these)
     const int R = sel->rf, c = (R >> 2) - 1;
     // This XCD's run of the plane has per <= slots pairs.  They are dealt to the slots evenly -- slot i takes pair
     // floor(i per / slots) when that differs from its successor's -- so that the idle workgroups of an image with larger
@@ -344,11 +345,12 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
     float *k = nullptr; pb_fft_sel *s = nullptr;
     const int rcb = pb_khat_buffers(ctx, B, &k, &s);
     if (rcb) return rcb;
-    if (!ctx->khat_owner) launch = true;
+    if (!ctx->khat_owner || !same_spec(ctx->poly_built, ctx->poly_want)) launch = true;   // (spectra of the kernel vs of the whole polynomial)
     if (launch) {
-        ctx->khat_owner = info; ctx->khat_by_estimate = false;
+        ctx->khat_owner = info; ctx->khat_by_estimate = false; ctx->poly_built = ctx->poly_want;
         ProfScope prof(ctx, PB_PROF_PARAMS);
-        hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases);
+        hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases,
+                           ctx->poly_want);
         PB_LAUNCH_CHECK();
     }
     *khat = k; *sel = s;

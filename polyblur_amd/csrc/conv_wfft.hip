@@ -626,14 +626,14 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     if (B == 1) {
         // (one image: its record is read on the scalar side -- no trip through the vector memory queue)
         const PB_CONSTANT pb_fft_sel *s0 = as_constant(a.fsel);
-        if (!s0->use_fft) return;
+        if (!s0->use_fft || (s0->poly != 0) != (a.poly != 0)) return;
         R = s0->rf;
     } else {
         // list entries of image i: its share of every plane
         auto share_of = [&](int i) -> int {
             if (i >= B) return 0;
             const pb_fft_sel s = a.fsel[i];
-            if (!s.use_fft) return 0;
+            if (!s.use_fft || (s.poly != 0) != (a.poly != 0)) return 0;     // (poly: see pb_fft_sel)
             return (s.rf <= 4 ? g.per[0] : (s.rf <= 8 ? g.per[1] : g.per[2])) * C;
         };
         bool work = false;

@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
                                                          float c, float b, int support, float force_theta_deg,
                                                          int tiles_per_image, int ksize, int shift,
                                                          const float2 *__restrict__ part, int blocks_per_image, unsigned *mm_out,
-                                                         float *khat, pb_fft_sel *fsel, int min_phases) {
+                                                         float *khat, pb_fft_sel *fsel, int min_phases, const PolySpec ps) {
     __shared__ float red[NT / 64];
     __shared__ float s_mags[PB_MAX_ANGLES], s_interp[PB_MAX_INTERP];
     __shared__ float s_lo[NT / 64], s_hi[NT / 64];
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     // critical path than a kernel of its own behind this one.
     if (khat) {
         __syncthreads();                                  // (this workgroup's own writes of the record are visible to its reads)
-        khat_body(info, khat + (long)blockIdx.x * (KH_FT_N * KH_FT_N), fsel + blockIdx.x, min_phases, (int)blockIdx.y);
+        khat_body(info, khat + (long)blockIdx.x * (KH_FT_N * KH_FT_N), fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps);
     }
 }
 
@@ -1540,9 +1540,9 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? KH_SLICES : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles, ksize,
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
-                       ctx->fft_min_phases);
+                       ctx->fft_min_phases, ctx->poly_want);
     PB_LAUNCH_CHECK();
-    if (khat) { ctx->khat_owner = dev_info; ctx->khat_by_estimate = true; }
+    if (khat) { ctx->khat_owner = dev_info; ctx->khat_by_estimate = true; ctx->poly_built = ctx->poly_want; }
     return PB_OK;
 }
 

@@ -49,7 +49,8 @@ constexpr int KH_SLICES = 8;          // workgroups per image: each forms the sp
 // Called by all KH_THREADS threads of a workgroup: slice `slice` (0 .. KH_SLICES - 1) of the spectrum of `info`'s taps,
 // and (slice 0) the image's choice of body.  The record may have been written by this same workgroup just before (global
 // memory, then a barrier): it is read through the vector path.
-__device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, pb_fft_sel *sel, int min_phases, int slice) {
+__device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, pb_fft_sel *sel, int min_phases, int slice,
+                                          const PolySpec ps = PolySpec{0, 0.f, 0.f, 0.f, 0.f}) {
     constexpr int NR = PB_KRAD + 1, PXS = KH_FT_N / KH_SLICES;
     __shared__ double2 G[NR * PXS];
     __shared__ double cs[KH_FT_N], sn[KH_FT_N];
@@ -67,10 +68,14 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         sym = sym && (!in || k == info->kernel[PB_KSIZE * PB_KSIZE - 1 - i]);
     }
     // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
-    const bool use = __syncthreads_and(sym) && info->separable == 0 && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0) && min_phases >= 0;
+    const bool dense = __syncthreads_and(sym) && info->separable == 0 && min_phases >= 0;
+    // (one-pass polynomial: a kernel within the 4-sample halo, whatever its phase count -- one window pass against three
+    // stencil passes)
+    const bool poly = ps.on && dense && R <= 4;
+    const bool use = poly || (dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0));
     if (tid == 0 && slice == 0) {
-        sel->use_fft = use ? 1 : 0; sel->rf = R <= 4 ? 4 : (R <= 8 ? 8 : 12);
-        sel->strip = (info->separable != 0 && R > 8) ? 1 : 0; sel->pad_ = 0;
+        sel->use_fft = use ? 1 : 0; sel->rf = poly ? 12 : (R <= 4 ? 4 : (R <= 8 ? 8 : 12));
+        sel->strip = (info->separable != 0 && R > 8) ? 1 : 0; sel->poly = poly ? 1 : 0;
     }
     if (!use) return;
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
@@ -97,7 +102,9 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
             const double2 g = G[u * PXS + pxl];
             ar += g.x * cs[m] - g.y * sn[m];
         }
-        out[(px0 + pxl) * KH_FT_N + py] = (float)(ar * (2.0 / 4096.0));
+        double v = 2.0 * ar;                                              // the kernel's transform at (fx, fy): real
+        if (poly) v = (((double)ps.a3 * v + (double)ps.a2) * v + (double)ps.a1) * v + (double)ps.b;
+        out[(px0 + pxl) * KH_FT_N + py] = (float)(v * (1.0 / 4096.0));
     }
 }
 
