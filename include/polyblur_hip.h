@@ -105,8 +105,12 @@ typedef struct pb_options {
                                    reach 9x the image range, where an fp16 ulp is 7.8e-3 -- measured 2e-3 .. 4.4e-3 from
                                    the fp32-temporary result; default 0 = fp32 temporaries             */
     int32_t ker_size;           /* support of the estimated Gaussian and, halved, the replicate pad (deblurring.py:23,
-                                   blur_estimation.py:211-232, utils.py:48-53): 2 .. 25 (default 25; 0 means 25); even sizes are
-                                   off-centre as in the reference and keep the stencil bodies */
+                                   blur_estimation.py:211-232, utils.py:48-53): 2 .. 49 (default 25; 0 means 25); even sizes are
+                                   off-centre as in the reference and keep the stencil bodies.  Sizes above 25 do not fit
+                                   pb_blur_info: their taps live in the context's scratch and every reblurring step is a plain
+                                   LDS-tiled stencil (conv_big.hip: up to 2401 multiply-adds per sample -- 10 to 40 times the
+                                   time of the default size); the record's `kernel` then holds the central 25 x 25 taps
+                                   renormalised, theta / sigma / rho are exact; not with edgetaping or separable_approx */
 } pb_options;
 
 /* Per-image, per-iteration estimation record (device or host copy). Mirrors the values the

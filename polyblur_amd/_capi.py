@@ -13,6 +13,7 @@ import threading
 import numpy as np
 
 PB_KSIZE = 25
+PB_KSIZE_MAX = 49          # ker_size above PB_KSIZE: the large-kernel pass (the records stay 25 x 25)
 PB_MAX_ANGLES = 13
 PB_MAX_INTERP = 64
 PB_MAX_PHASES = 175

@@ -213,6 +213,9 @@ struct Geometry {
     float *sep_u = nullptr;
     // pb_options.half_temporaries: the two Horner temporaries are stored as fp16 (fp32 accumulation, fp32 x operand)
     void *t1h = nullptr, *t2h = nullptr;
+    // ker_size above 25: the taps on the ker_size grid (conv_big.hip), rebuilt after every estimation
+    const float *big_taps = nullptr;
+    int big_ksize = 0;
 };
 
 Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
@@ -331,6 +334,13 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     set_in_padded(p, g, T2, tdt); set_out_interior(p, g, dst, dst_dtype);
     p.coef = beta; p.clamp01 = clamp01;
     steps[2] = p;
+    if (g.big_taps) {
+        for (int s = 0; s < 3; ++s) {
+            const int rc = pb_launch_conv_big(ctx, steps[s], g.big_taps, g.big_ksize);
+            if (rc) return rc;
+        }
+        return PB_OK;
+    }
     // (experiment, PB_POLY1=1: under the wrap boundary the three steps are one filter, deblurring.py:139-169 -- kernels
     // within the 4-sample halo take it as one window pass; the spectra are then the polynomial's)
     if (ctx->poly_mode && boundary == PB_WRAP && !xpadded) ctx->poly_want = PolySpec{1, a3, a2, a1, beta};
@@ -423,7 +433,7 @@ int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, 
     pb_default_options(&o);
     o.ker_size = ker_size;
     const int ksize = pb_kernel_size(&o);
-    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", ker_size, PB_KSIZE);
+    if (!ksize || ksize > PB_KSIZE) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: the separable approximation is built for sizes from 2 to %d", ker_size, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
     pb_forget_records(ctx, dev_sep, 2 * B);
     return pb_make_sep_records(ctx, B, dev_info, dev_sep, support, ksize);
@@ -565,9 +575,12 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (opt->n_iter < 0) return pb_fail(ctx, PB_ERR_BADARG, "n_iter < 0");
     if (opt->boundary != PB_WRAP && opt->boundary != PB_ZERO) return pb_fail(ctx, PB_ERR_BADARG, "bad boundary");
     const int ksize = pb_kernel_size(opt);
-    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE_MAX);
     if (opt->separable_approx && opt->edgetaping)
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "edgetaping is not defined for the separable approximation");
+    // (kernels beyond the 25 x 25 record take conv_big.hip's pass: no edgetaper weights, no separable approximation there)
+    if (ksize > PB_KSIZE && (opt->edgetaping || opt->separable_approx))
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
     Geometry g = geometry(B, C, H, W, ksize / 2);
     const long n = (long)g.P * g.HW;
@@ -656,6 +669,11 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
         ctx->poly_want = PolySpec{0, 0.f, 0.f, 0.f, 0.f};
         if (rc) return rc;
+        if (ksize > PB_KSIZE) {
+            rc = pb_build_big_taps(ctx, info, B, ksize, (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, &g.big_taps);
+            if (rc) return rc;
+            g.big_ksize = ksize;
+        }
         if (sep) {
             rc = pb_make_sep_records(ctx, B, info, sep, opt->support, ksize);
             if (rc) return rc;

@@ -180,6 +180,10 @@ void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // 
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_strip(pb_ctx *ctx, const ConvPass &p);                    // conv_strip.hip; PB_ERR_UNSUPPORTED: not an all-fp32 plain Horner pass
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p);                     // conv_wfft.hip; PB_ERR_UNSUPPORTED: dtype combination not built
+// kernels larger than the 25 x 25 record (conv_big.hip): their taps on the ker_size grid, and one Horner step with them
+int pb_build_big_taps(pb_ctx *ctx, const pb_blur_info *dev_info, int B, int ksize, int shift, const float **taps);
+int pb_launch_conv_big(pb_ctx *ctx, const ConvPass &p, const float *taps, int ksize);
+constexpr int PB_KSIZE_MAX = 49;
 bool pb_conv_fft_feasible(const ConvPass &p);                                // window counts within the kernel's index arithmetic
 
 // ------------------------------------------------------------------------------------
@@ -188,7 +192,7 @@ bool pb_conv_fft_feasible(const ConvPass &p);                                // 
 int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W,
                      const pb_options *opt, pb_blur_info *dev_info);
 int pb_make_sep_records(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *sep, int support, int ksize);
-int pb_kernel_size(const pb_options *opt);      // validated ker_size (odd, 3..25); 0 if unsupported
+int pb_kernel_size(const pb_options *opt);      // validated ker_size (2 .. PB_KSIZE_MAX; above PB_KSIZE: conv_big.hip's path); 0 if unsupported
 int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy);
 int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps, int ksize = PB_KSIZE);
 

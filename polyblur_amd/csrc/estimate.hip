@@ -1461,7 +1461,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                      pb_blur_info *dev_info) {
     if (opt->q < 0.f || opt->q >= 0.5f) return pb_fail(ctx, PB_ERR_BADARG, "q must be in [0, 0.5)");
     const int ksize = pb_kernel_size(opt);
-    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE);
+    if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE_MAX);
     if (opt->n_angles < 1 || opt->n_angles + 1 > PB_MAX_ANGLES || opt->n_interpolated_angles < 1 ||
         opt->n_interpolated_angles > PB_MAX_INTERP)
         return pb_fail(ctx, PB_ERR_BADARG, "n_angles / n_interpolated_angles out of range");
@@ -1548,7 +1548,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 
 int pb_kernel_size(const pb_options *opt) {
     const int k = opt->ker_size == 0 ? PB_KSIZE : opt->ker_size;
-    return (k >= 2 && k <= PB_KSIZE) ? k : 0;
+    return (k >= 2 && k <= PB_KSIZE_MAX) ? k : 0;
 }
 
 int pb_make_sep_records(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *sep, int support, int ksize) {

@@ -68,13 +68,15 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
         raise ValueError("support must be 'full' or 'adaptive'")
     if prefilter not in _PREFILTER:
         raise ValueError("prefilter must be 'bilateral', 'domain_transform' or 'normalized_convolution'")
-    if not (isinstance(ker_size, (int, np.integer)) and 2 <= ker_size <= capi.PB_KSIZE):
-        # the kernel lives in a 25 x 25 record and the replicate pad is ker_size // 2 (even sizes: off-centre, as the
-        # reference's grid arange(k) - (k - 1) // 2 and its two convolution paths place them); nothing beyond the default 25 is
-        # built (sigma is clamped to 4, so 25 already holds +-3 sigma)
-        raise NotImplementedError("ker_size must be between 2 and 25 (the reference default)")
+    if not (isinstance(ker_size, (int, np.integer)) and 2 <= ker_size <= capi.PB_KSIZE_MAX):
+        # up to 25 the kernel lives in a 25 x 25 record; 26 .. 49 take the large-kernel pass (csrc/conv_big.hip); the replicate
+        # pad is ker_size // 2 (even sizes: off-centre, as the reference's grid arange(k) - (k - 1) // 2 and its two convolution
+        # paths place them).  sigma is clamped to 4, so 49 holds +-6 sigma: nothing beyond it is built
+        raise NotImplementedError("ker_size must be between 2 and 49")
     if ker_size % 2 == 0 and (edgetaping or method == "direct_separable"):
         raise NotImplementedError("an even ker_size is built for the plain 'fft' / 'direct' methods only (not with edgetaping or 'direct_separable')")
+    if ker_size > capi.PB_KSIZE and (edgetaping or method == "direct_separable"):
+        raise NotImplementedError("a ker_size above 25 is built for the plain 'fft' / 'direct' methods only (not with edgetaping or 'direct_separable')")
     if not (0 <= q < 0.5):
         raise ValueError("q must be in [0, 0.5)")
     if multichannel_kernel and C not in (1, 3):

@@ -31,7 +31,8 @@ x, _ = synthetic_blurry_batch(1, 3, 90, 122, seed0=5151)
 d = {"x": x}
 # odd sizes, and even ones: their grid arange(k) - (k - 1) // 2 is off-centre (blur_estimation.py:222), 'fft' rolls the kernel
 # by k // 2 (filters.py:268-273) and F.conv2d's 'same' padding puts one row / column fewer in front than behind
-for k in (5, 13, 21, 4, 12, 24):
+# ... and sizes beyond the default 25 (the engine's large-kernel pass): odd, even, the largest built
+for k in (5, 13, 21, 4, 12, 24, 31, 36, 49):
     for method in ("fft", "direct"):
         d["k%d_%s" % (k, method)] = polyblur_deblurring(torch.from_numpy(x.copy()), n_iter=2, ker_size=k, method=method, **KW).numpy()
 d["k13_fft_taper_halo"] = polyblur_deblurring(torch.from_numpy(x.copy()), n_iter=2, ker_size=13, edgetaping=True,

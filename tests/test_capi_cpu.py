@@ -60,7 +60,9 @@ def test_argument_validation_before_any_device_work():
     with pytest.raises(ValueError):
         polyblur_deblurring(x, q=0.5)
     with pytest.raises(NotImplementedError):
-        polyblur_deblurring(x, ker_size=31)
+        polyblur_deblurring(x, ker_size=51)
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(x, ker_size=31, edgetaping=True)
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=12, edgetaping=True)
     with pytest.raises(NotImplementedError):

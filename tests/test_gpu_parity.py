@@ -782,11 +782,12 @@ def test_streams_and_threads_do_not_share_scratch(eng):
     assert all(torch.equal(a, b) for a, b in zip(other, want[1:]))
 
 
-@pytest.mark.parametrize("k", [5, 13, 21, 4, 12, 24])
+@pytest.mark.parametrize("k", [5, 13, 21, 4, 12, 24, 31, 36, 49])
 @pytest.mark.parametrize("method", ["fft", "direct"])
 def test_kernel_sizes_against_reference_goldens(golden, k, method):
     """ker_size != 25 (deblurring.py:23): the estimated Gaussian is k x k and the replicate pad k // 2, so the wrap /
-    zero boundary of the three reblurring passes sits closer to the image"""
+    zero boundary of the three reblurring passes sits closer to the image (or further: sizes above 25 take the
+    large-kernel pass, csrc/conv_big.hip)"""
     import torch
     from polyblur_amd import polyblur_deblurring
     g = golden("pipeline_kersize.npz")
@@ -798,7 +799,8 @@ def test_kernel_sizes_against_reference_goldens(golden, k, method):
         assert maxabs(out, g["k13_fft_taper_halo"]) < 2e-5
 
 
-@pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64)), (2, (1, 3, 20, 17)), (8, (2, 1, 33, 40)), (22, (1, 3, 64, 70))])
+@pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64)), (2, (1, 3, 20, 17)), (8, (2, 1, 33, 40)), (22, (1, 3, 64, 70)),
+                                     (27, (2, 3, 70, 133)), (26, (1, 1, 40, 33)), (48, (1, 3, 150, 97)), (49, (2, 1, 20, 30)), (35, (1, 3, 300, 517))])
 def test_kernel_sizes_against_oracle(k, shape):
     import torch
     from polyblur_amd import polyblur_deblurring
@@ -885,3 +887,32 @@ def test_direct_separable_fp16_and_kernel_size():
     out = polyblur_deblurring(torch.from_numpy(xs).cuda(), n_iter=2, method="direct_separable", **KW)
     want = ref.polyblur_deblurring(xs, n_iter=2, method="direct_separable", **KW)
     assert maxabs(out.cpu().numpy(), want) < 3e-5
+
+
+def test_large_kernel_size_with_options_and_dtypes():
+    """ker_size above 25 with halo removal, a prefilter, quantiles, fp16 and 8-bit images (every dtype combination of the
+    large-kernel pass); edgetaping and 'direct_separable' are not built for it"""
+    import torch
+    from polyblur_amd import polyblur_deblurring, polyblur_deblurring_uint8
+    x, _ = synthetic_blurry_batch(2, 3, 120, 176, seed0=62)
+    kw = dict(n_iter=2, ker_size=33, remove_halo=True, prefiltering=True, q=1e-3, **KW)
+    out = polyblur_deblurring(torch.from_numpy(x).cuda(), **kw).cpu().numpy()
+    assert maxabs(out, ref.polyblur_deblurring(x, **kw)) < 3e-5
+    kw = dict(n_iter=2, ker_size=29, **KW)
+    want = ref.polyblur_deblurring(x, **kw)
+    out16 = polyblur_deblurring(torch.from_numpy(x).cuda().half(), **kw).float().cpu().numpy()
+    assert maxabs(out16, ref.polyblur_deblurring(x.astype(np.float16).astype(np.float32), **kw)) < 1e-3
+    outh = polyblur_deblurring(torch.from_numpy(x).cuda().half(), temporaries="fp16", **kw).float().cpu().numpy()
+    assert maxabs(outh, want) < 8e-3
+    u8 = np.ascontiguousarray((x[0].transpose(1, 2, 0) * 255).round().astype(np.uint8))
+    got = polyblur_deblurring_uint8(u8, **kw)
+    wantu = ref.polyblur_deblurring_uint8(u8, **kw)
+    assert np.mean(got != wantu) < 2e-3 and np.abs(got.astype(int) - wantu.astype(int)).max() <= 1
+    hwc = np.ascontiguousarray(x[0].transpose(1, 2, 0))
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(hwc, ker_size=31, edgetaping=True)
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(hwc, ker_size=31, method="direct_separable")
+    with pytest.raises(NotImplementedError):
+        polyblur_deblurring(hwc, ker_size=51)
+

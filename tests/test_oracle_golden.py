@@ -203,7 +203,7 @@ def test_pipeline_extra_defaults_and_odd_batch(golden):
     assert np.max(np.abs(out - g["functional_defaults_n2"])) < 3e-5
 
 
-@pytest.mark.parametrize("k", [5, 13, 21, 4, 12, 24])
+@pytest.mark.parametrize("k", [5, 13, 21, 4, 12, 24, 31, 36, 49])
 @pytest.mark.parametrize("method", ["fft", "direct"])
 def test_pipeline_kernel_sizes(golden, k, method):
     """ker_size sets the Gaussian's support AND the replicate pad (blur_estimation.py:211-232, utils.py:48-53)"""
