@@ -14,6 +14,15 @@
 
 #include "common.h"
 #include "fft.h"
+// Debug build only (tools/build_variant.sh ... "-DPB_PARAMS_TRACE" estimate.hip): shader-clock stamps of the parameter
+// kernel's phases, first workgroup (tools/params_trace.py)
+#ifdef PB_PARAMS_TRACE
+__device__ unsigned long long g_params_trace[32];
+#define PB_PT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_params_trace[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int pb_debug_params_trace(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_params_trace), sizeof(unsigned long long) * 32);
+}
+#endif
 #include "khat.h"
 
 namespace {
@@ -905,11 +914,11 @@ __device__ float block_sum(float v, float *red) {
 // record.  Called by all NT threads of a block.
 // shift: an EVEN ker_size under the wrap boundary ('fft') -- see the tap formula below.
 __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, float *red, int ksize,
-                              const float *par = nullptr, int shift = 0) {
+                              const float *par = nullptr, int shift = 0, RecLds *rl = nullptr) {
     // Everything is derived in LDS from the taps; the record in global memory is only written (a dependent chain of
     // global round trips made this single-workgroup kernel the longest latency of small calls).
     __shared__ float sk[PB_KSIZE * PB_KSIZE], skx[PB_KSIZE], sky[PB_KSIZE];
-    __shared__ int nz[PB_KSIZE], s_radius, s_first;
+    __shared__ int nz[PB_KSIZE], s_radius, s_first, s_sep;
     const int tid = threadIdx.x;
     __syncthreads();                                    // (a previous call's readers of the shared arrays are done)
     if (!from_taps) {
@@ -954,6 +963,7 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT) sk[idx] = info->kernel[idx];
     }
     __syncthreads();
+    PB_PT(4);
     float sx = 0.f, sy = 0.f;
     if (tid < PB_KSIZE) {
         int any = 0;
@@ -979,6 +989,7 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     __syncthreads();
     if (tid < PB_KSIZE) { skx[tid] = sxm; sky[tid] = sym; info->kx[tid] = sxm; info->ky[tid] = sym; }
     __syncthreads();
+    PB_PT(5);
     if (tid < PB_KSIZE) {
         float ax = 0.f, ay = 0.f;
 #pragma unroll
@@ -1001,7 +1012,9 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     float res = 0.f;
     for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT)
         res += fabsf(sk[idx] - sky[idx / PB_KSIZE] * skx[idx % PB_KSIZE]);
+    PB_PT(6);
     const float resid = block_sum(res, red);
+    PB_PT(7);
     // FULL: every tap that is not exactly 0.0f is evaluated (rows / columns whose taps all underflowed to
     // zero -- sigma below ~0.9 -- are skipped: bit-identical to evaluating them).  ADAPTIVE: the smallest
     // radius outside which both marginals carry < 1e-8 of the mass.
@@ -1011,7 +1024,8 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     const unsigned long long live_mask = __ballot(live_t);          // thread 0 reads wave 0's: lanes 0..24
     if (tid == 0) {
         // (an even-sized kernel is never taken for rank-1: that body keeps symmetrised halves of the marginals)
-        info->separable = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL) && (from_taps || (ksize & 1))) ? 1 : 0;
+        s_sep = (resid < 1e-6f && !(support & PB_SUPPORT_FORCE_GENERAL) && (from_taps || (ksize & 1))) ? 1 : 0;
+        info->separable = s_sep;
         int rad = 0;
         if (live_mask) {
             const int lo = __ffsll((long long)live_mask) - 1, hi = 63 - __clzll((long long)live_mask);
@@ -1065,6 +1079,8 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         if (live && before == 0) s_first = desc;         // phase[0] is always a live phase (fillers come after their group)
         __syncthreads();
         if (tid < 3) info->phase[total + tid] = total ? s_first : 0;     // harmless targets for the prefetches
+        PB_PT(8);
+        if (rl) { rl->taps = sk; rl->radius = s_radius; rl->nph = total; rl->separable = s_sep; }      // (uniform; the taps stay in LDS)
     }
 }
 
@@ -1080,18 +1096,32 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     __shared__ float s_lo[NT / 64], s_hi[NT / 64];
     pb_blur_info *info = infos + blockIdx.x;
     const int na = n_angles + 1;
+    PB_PT(0);
     // q == 0 (part != nullptr): the transforms ran on the UN-normalised gray image -- the derivative is linear and kills
     // the offset, and without quantiles the clip of normalize() never acts (blur_estimation.py:92-109) -- so the
     // gray kernel's per-workgroup (min, max) are folded here, off the transforms' critical path, and the maxima are
     // divided by the range below.
     float rng_lo = 0.f, rng_hi = 0.f, rng_inv = 1.f;
     float plo = INFINITY, phi = -INFINITY;
+    // (the interpolation weights of this lane's angle: requested with everything else, used two barriers later)
+    float wreg[PB_MAX_ANGLES];
+#pragma unroll
+    for (int k = 0; k < PB_MAX_ANGLES; ++k)
+        wreg[k] = ((int)threadIdx.x < n_interp && k < na) ? wts[threadIdx.x * na + k] : 0.f;
     if (part) {
         // (requested here, folded behind the maxima's barrier below: one exposed memory latency for both)
-        for (int i = threadIdx.x; i < blocks_per_image; i += NT) {
-            const float2 p = part[(long)blockIdx.x * blocks_per_image + i];
-            plo = fminf(plo, p.x);
-            phi = fmaxf(phi, p.y);
+        // (batches of eight loads in flight per thread: the gray kernel leaves up to 2048 partials per image, and one load
+        // per loop trip made this the longest phase of the kernel -- 10.8 k of its 39 k cycles, tools/params_trace.py)
+        const float2 *mine = part + (long)blockIdx.x * blocks_per_image;
+        for (int base = 0; base < blocks_per_image; base += 8 * NT) {
+            float2 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * NT + (int)threadIdx.x;
+                p[u] = i < blocks_per_image ? mine[i] : make_float2(INFINITY, -INFINITY);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { plo = fminf(plo, p[u].x); phi = fmaxf(phi, p[u].y); }
         }
     }
     {
@@ -1147,15 +1177,20 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
         }
     }
     __syncthreads();
+    PB_PT(1);
     // cubic interpolation to n_interp angles (blur_estimation.py:156-157): one lane per angle
     if (threadIdx.x < PB_MAX_INTERP) {
         float v = 0.f;
-        if ((int)threadIdx.x < n_interp)
-            for (int k = 0; k < na; ++k) v += wts[threadIdx.x * na + k] * s_mags[k];
+        if ((int)threadIdx.x < n_interp) {
+#pragma unroll
+            for (int k = 0; k < PB_MAX_ANGLES; ++k)
+                if (k < na) v += wreg[k] * s_mags[k];
+        }
         s_interp[threadIdx.x] = v;
         info->interp[threadIdx.x] = v;
     }
     __syncthreads();
+    PB_PT(2);
     __shared__ float s_par[3];
     if (threadIdx.x < 64) {
         // argmin, first minimum (:160), over the lanes of one wave: (value, index) pairs, NaN never selected
@@ -1193,15 +1228,15 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
         }
     }
     __syncthreads();
-    finish_record(info, support, false, red, ksize, s_par, shift);
+    PB_PT(3);
+    RecLds rl;
+    finish_record(info, support, false, red, ksize, s_par, shift, &rl);
     // The spectrum of the kernel just built and the image's choice of body for the reblurring passes (khat.h): the grid is
     // KH_SLICES workgroups per image, every one of which has formed the whole record above (a few microseconds of
     // redundant latency-bound work, identical values) and now forms its slice -- one launch less on every iteration's
     // critical path than a kernel of its own behind this one.
-    if (khat) {
-        __syncthreads();                                  // (this workgroup's own writes of the record are visible to its reads)
-        khat_body(info, khat + (long)blockIdx.x * (KH_FT_N * KH_FT_N), fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps);
-    }
+    if (khat)      // (the record as finish_record left it in LDS: no wait for its stores, no read back)
+        khat_body(info, khat + (long)blockIdx.x * (KH_FT_N * KH_FT_N), fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps, &rl);
 }
 
 // method='direct_separable': the two correlation kernels of the x-t separable approximation of the image's Gaussian

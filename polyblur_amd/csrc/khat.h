@@ -3,6 +3,9 @@
 // the critical path of every iteration).
 #pragma once
 #include "common.h"
+#ifndef PB_PT
+#define PB_PT(i)
+#endif
 
 namespace {
 
@@ -46,36 +49,43 @@ static __device__ const double kSin64[64] = {
 };
 constexpr int KH_SLICES = 8;          // workgroups per image: each forms the spectrum at 8 of the 64 x positions
 
+// What khat_body needs of a record, for a caller that has just formed it and still holds it in LDS (estimate.hip's
+// parameter kernel): no wait for the record's stores to land, no read back.
+struct RecLds { const float *taps; int radius, nph, separable; };
+
 // Called by all KH_THREADS threads of a workgroup: slice `slice` (0 .. KH_SLICES - 1) of the spectrum of `info`'s taps,
 // and (slice 0) the image's choice of body.  The record may have been written by this same workgroup just before (global
 // memory, then a barrier): it is read through the vector path.
 __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, pb_fft_sel *sel, int min_phases, int slice,
-                                          const PolySpec ps = PolySpec{0, 0.f, 0.f, 0.f, 0.f}) {
+                                          const PolySpec ps = PolySpec{0, 0.f, 0.f, 0.f, 0.f}, const RecLds *rl = nullptr) {
     constexpr int NR = PB_KRAD + 1, PXS = KH_FT_N / KH_SLICES;
     __shared__ double2 G[NR * PXS];
     __shared__ double cs[KH_FT_N], sn[KH_FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
     const int tid = threadIdx.x;
-    const int nph = info->nphase[0] + info->nphase[1] + info->nphase[2];
-    const int R = info->radius;
+    const int nph = rl ? rl->nph : info->nphase[0] + info->nphase[1] + info->nphase[2];
+    const int R = rl ? rl->radius : info->radius;
+    const int separable = rl ? rl->separable : info->separable;
     if (tid < KH_FT_N) { cs[tid] = kCos64[tid]; sn[tid] = kSin64[tid]; }
     bool sym = true;
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
         const bool in = abs(u) <= R && abs(v) <= R;
-        const float k = info->kernel[i];
+        const float k = rl ? rl->taps[i] : info->kernel[i];
+        const float km = rl ? rl->taps[PB_KSIZE * PB_KSIZE - 1 - i] : info->kernel[PB_KSIZE * PB_KSIZE - 1 - i];
         sk[i] = in ? k : 0.f;
-        sym = sym && (!in || k == info->kernel[PB_KSIZE * PB_KSIZE - 1 - i]);
+        sym = sym && (!in || k == km);
     }
     // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
-    const bool dense = __syncthreads_and(sym) && info->separable == 0 && min_phases >= 0;
+    PB_PT(20);
+    const bool dense = __syncthreads_and(sym) && separable == 0 && min_phases >= 0;
     // (one-pass polynomial: a kernel within the 4-sample halo, whatever its phase count -- one window pass against three
     // stencil passes)
     const bool poly = ps.on && dense && R <= 4;
     const bool use = poly || (dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0));
     if (tid == 0 && slice == 0) {
         sel->use_fft = use ? 1 : 0; sel->rf = poly ? 12 : (R <= 4 ? 4 : (R <= 8 ? 8 : 12));
-        sel->strip = (info->separable != 0 && R > 8) ? 1 : 0; sel->poly = poly ? 1 : 0;
+        sel->strip = (separable != 0 && R > 8) ? 1 : 0; sel->poly = poly ? 1 : 0;
     }
     if (!use) return;
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
@@ -93,6 +103,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         G[tid] = make_double2(ar, ai);
     }
     __syncthreads();
+    PB_PT(21);
     for (int idx = tid; idx < PXS * KH_FT_N; idx += KH_THREADS) {          // stored transposed: [x position][y position]
         const int pxl = idx >> 6, py = idx & 63, fy = (py >> 3) + 8 * (py & 7);
         double ar = 0.5 * G[pxl].x;
@@ -106,6 +117,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         if (poly) v = (((double)ps.a3 * v + (double)ps.a2) * v + (double)ps.a1) * v + (double)ps.b;
         out[(px0 + pxl) * KH_FT_N + py] = (float)(v * (1.0 / 4096.0));
     }
+    PB_PT(22);
 }
 
 }  // namespace
