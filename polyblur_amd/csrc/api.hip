@@ -216,6 +216,9 @@ struct Geometry {
     // ker_size above 25: the taps on the ker_size grid (conv_big.hip), rebuilt after every estimation
     const float *big_taps = nullptr;
     int big_ksize = 0;
+    // the pipeline's polynomials may take the one-pass form (pb_fft_sel.poly): wrap boundary, no edgetaper, and either the
+    // adaptive support policy -- the only one under which kernels within a 4-sample halo occur -- or PB_POLY1=1
+    bool poly = false;
 };
 
 Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
@@ -343,7 +346,7 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     }
     // (experiment, PB_POLY1=1: under the wrap boundary the three steps are one filter, deblurring.py:139-169 -- kernels
     // within the 4-sample halo take it as one window pass; the spectra are then the polynomial's)
-    if (ctx->poly_mode && boundary == PB_WRAP && !xpadded) ctx->poly_want = PolySpec{1, a3, a2, a1, beta};
+    if ((g.poly || ctx->poly_mode == 1) && boundary == PB_WRAP && !xpadded) ctx->poly_want = PolySpec{1, a3, a2, a1, beta};
     const int rc = pb_launch_conv_poly(ctx, steps);
     ctx->poly_want = PolySpec{0, 0.f, 0.f, 0.f, 0.f};
     return rc;
@@ -583,6 +586,8 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
     Geometry g = geometry(B, C, H, W, ksize / 2);
+    g.poly = (ctx->poly_mode == 1 || (ctx->poly_mode == 2 && (opt->support & 15) == PB_SUPPORT_ADAPTIVE)) &&
+             opt->boundary == PB_WRAP && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
     const long n = (long)g.P * g.HW;
     const int n_iter = opt->n_iter;
     if (n_iter == 0) {
@@ -662,7 +667,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (dtype != PB_F32 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
         const int cur_dtype = it == 0 ? dtype : work, dst_dtype = it == n_iter - 1 ? dtype : work;
         pb_blur_info *info = infos + (size_t)it * B;
-        if (ctx->poly_mode && opt->boundary == PB_WRAP && !opt->edgetaping && !sep) {   // as run_polynomial will ask for
+        if (g.poly) {   // as run_polynomial will ask for
             const float al = opt->alpha, be = opt->beta;
             ctx->poly_want = PolySpec{1, al / 2 - be + 2, 3 * be - al - 6, 5 - 3 * be + al / 2, be};
         }

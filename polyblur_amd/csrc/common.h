@@ -78,7 +78,12 @@ struct pb_ctx {
     bool khat_by_estimate = false;
     // one-pass polynomial experiment (env PB_POLY1=1): what the spectra in "conv.khat" were built for, and what the call
     // in progress wants (set around the estimation / the polynomial; off for every other pass)
-    int poly_mode = 0;
+    // 0 never; 1 every eligible polynomial, host-built records included (those are then not cached); 2 (default) the
+    // pipeline's, under PB_SUPPORT_ADAPTIVE only: mildly blurred images -- the method's own use case -- estimate kernels like
+    // sigma 0.6 / rho 0.3 (clamped) at an oblique angle, dense and within the 4-sample halo, and their polynomial is then
+    // 1.7 x faster; when no image of a call qualifies, the composite launch that finds no work costs 1 % of a 4K call
+    // even on the side stream (1.182 -> 1.195 ms).  Full support (the default policy) never qualifies and never pays.
+    int poly_mode = 2;
     PolySpec poly_built{0, 0.f, 0.f, 0.f, 0.f}, poly_want{0, 0.f, 0.f, 0.f, 0.f};
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
 };

@@ -344,7 +344,7 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     if (fft) {
         float *k = nullptr; pb_fft_sel *s = nullptr;
         // (spectra an earlier pass built count only while the scratch still holds them for these records)
-        const bool built = (p.khat_ready || have || ctx->khat_by_estimate || ctx->poly_mode) && ctx->khat_owner == p.info;   // (pb_build_khat also rebuilds spectra of another PolySpec)
+        const bool built = (p.khat_ready || have || ctx->khat_by_estimate || ctx->poly_mode == 1) && ctx->khat_owner == p.info;   // (pb_build_khat also rebuilds spectra of another PolySpec)
         const int rc = pb_build_khat(ctx, p.info, B, &k, &s, !built);
         if (rc) return rc;
         p.khat = k; p.fsel = s;
@@ -424,13 +424,14 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     }
     float *k = nullptr; pb_fft_sel *sel = nullptr;
     // (records the estimation has just built bring their spectra with them: blur_params_kernel ends with them)
-    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !((ctx->khat_by_estimate || ctx->poly_mode) && ctx->khat_owner == steps[0].info));
+    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !((ctx->khat_by_estimate || ctx->poly_mode == 1) && ctx->khat_owner == steps[0].info));
     if (rc) return rc;
-    if (ctx->poly_built.on) { rc = composite(k, sel); if (rc) return rc; }
     PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->aux;
+    // (the composite pass touches other images than the steps' launches do: it, too, runs -- or finds no work -- beside them)
+    if (ctx->poly_built.on) rc = composite(k, sel);
     for (int s = 0; s < 3 && !rc; ++s) {
         ConvPass p = steps[s];
         p.khat = k; p.fsel = sel;
@@ -455,7 +456,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B) {
     pb_forget_records(ctx, info, B);
     if (ctx->fft_min_phases < 0) return PB_OK;
-    if (ctx->poly_mode) return PB_OK;      // (one-pass polynomial experiment: which body an image takes depends on the pass; nothing is cached)
+    if (ctx->poly_mode == 1) return PB_OK;      // (PB_POLY1=1: which body an image takes depends on the pass; nothing is cached)
     float *k = nullptr; pb_fft_sel *s = nullptr;
     int rc = pb_build_khat(ctx, info, B, &k, &s, true);
     if (rc) return rc;

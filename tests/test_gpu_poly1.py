@@ -1,4 +1,5 @@
-"""GPU parity of the one-pass polynomial (experiment, opt-in: PB_POLY1=1 when the context is created).  Under the wrap
+"""GPU parity of the one-pass polynomial (PB_POLY1 when the context is created: 1 = every eligible polynomial, 0 = never;
+by default the pipeline takes it under the adaptive support policy).  Under the wrap
 boundary the reference's deconvolution is ONE filter a3 K^3 + a2 K^2 + a1 K + b (deblurring.py:139-169); for a dense kernel
 within the 4-sample halo the composite's halo is 12, so the image's three Horner launches become one window pass with the
 polynomial's spectrum (csrc/khat.h, pb_launch_conv_poly).  It must agree with the oracle and with the three-step form, in
@@ -27,7 +28,14 @@ def engines():
             del os.environ["PB_POLY1"]
         else:
             os.environ["PB_POLY1"] = old
-    three = Engine(0)
+    os.environ["PB_POLY1"] = "0"
+    try:
+        three = Engine(0)
+    finally:
+        if old is None:
+            del os.environ["PB_POLY1"]
+        else:
+            os.environ["PB_POLY1"] = old
     yield one, three
     one.close()
     three.close()
@@ -80,16 +88,31 @@ def test_one_pass_in_a_mixed_batch_and_other_passes(engines):
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 1080, 1920), (2, 3, 240, 320)])
-def test_whole_call_with_small_kernels(engines, shape):
-    """a nearly sharp image: the later iterations estimate kernels within the 4-sample halo under the adaptive policy"""
+def test_whole_call_on_a_mildly_blurred_image(engines, shape):
+    """the whole call under the adaptive policy on a mildly, obliquely blurred image (the method's own use case): the
+    estimates are like sigma 0.6 / rho 0.3 (clamped) at 30 degrees -- dense, within the 4-sample halo.  A context created
+    without PB_POLY1 takes the one-pass form there by itself (bit-identical to PB_POLY1=1) and never under full support
+    (bit-identical to PB_POLY1=0)."""
+    from polyblur_amd.engine import Engine
     one, three = engines
     rng = np.random.default_rng(83)
     x = rng.random(shape, dtype=np.float32)
-    x = ref.convolve2d(x, ref.gaussian_kernel_2d([np.float32(0.6)] * shape[0], [0.62] * shape[0], [0.45] * shape[0]), method="fft")
+    x = ref.convolve2d(x, ref.gaussian_kernel_2d([np.float32(0.6)] * shape[0], [0.9] * shape[0], [0.5] * shape[0]), method="fft")
     x = np.clip(x, 0, 1).astype(np.float32)
-    o = one.make_options(n_iter=3, c=0.362, b=0.468, alpha=6, beta=1, support=capi.PB_SUPPORT_ADAPTIVE)
+    kw = dict(n_iter=2, c=0.4, b=0.468, alpha=6, beta=1)
+    o = one.make_options(support=capi.PB_SUPPORT_ADAPTIVE, **kw)
     got, info = one.polyblur(x, o, want_info=True)
     base, binfo = three.polyblur(x, o, want_info=True)
     assert np.array_equal(info["theta"], binfo["theta"])
-    assert (info["radius"] <= 4).any(), info["radius"]                            # (the case under test occurs)
+    took = (info["radius"] <= 4) & (info["separable"] == 0)
+    assert took.any(), (info["radius"], info["separable"], info["sigma"], info["rho"])          # (the case under test occurs)
+    assert not np.array_equal(got, base)                                          # (and was evaluated in the other form)
     assert maxabs(got, base) < 2e-5, maxabs(got, base)
+    assert maxabs(got, ref.polyblur_deblurring(x, **kw)) < 3e-5
+    auto = Engine(0)
+    try:
+        assert np.array_equal(auto.polyblur(x, o), got)
+        of = one.make_options(support=capi.PB_SUPPORT_FULL, **kw)
+        assert np.array_equal(auto.polyblur(x, of), three.polyblur(x, of))
+    finally:
+        auto.close()
