@@ -170,12 +170,14 @@ void pb_default_options(pb_options *opt);        /* the functional API's default
  * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>.
  * (PB_STRIP=1 in the environment sends rank-1 kernels of full support on fp32 planes through the streaming strip body,
  * conv_strip.hip: an experiment measured slower than the tile body; same results to fp32 rounding.)
- * Under PB_SUPPORT_ADAPTIVE with the wrap boundary and no edgetaper, pb_polyblur_batch lets an image whose dense kernel fits
- * a 4-sample halo (sigma, rho <~ 0.7: the estimates of mildly blurred images) take its whole polynomial
- * a3 K^3 + a2 K^2 + a1 K + b -- one filter in the reference's 'fft' form, deblurring.py:139-169 -- as ONE window pass with
- * that polynomial's spectrum: 1.7 x faster on such kernels, same results to fp32 rounding (fewer roundings).  PB_POLY1=0 in
- * the environment switches that off, PB_POLY1=1 extends it to every policy and to pb_inverse_filter (record sets are then
- * not cached).  All three variables are read when the context is created. */
+ * With the wrap boundary and no edgetaper, pb_polyblur_batch lets an image whose kernel fits a 4-sample halo (the
+ * clamped isotropic estimate sigma = rho = 0.3 under every policy, sigma, rho <~ 0.7 under PB_SUPPORT_ADAPTIVE: the
+ * estimates of mildly blurred images) take its whole polynomial a3 K^3 + a2 K^2 + a1 K + b -- one filter in the
+ * reference's 'fft' form, deblurring.py:139-169 -- as ONE window pass with that polynomial's spectrum: 1.7 x faster on such
+ * kernels, same results to fp32 rounding (fewer roundings).  For fp32 images the first step's launch takes such images
+ * along; where that is not possible (the last iteration of fp16 / 8-bit images) a launch of its own is issued under the
+ * adaptive policy only.  PB_POLY1=0 in the environment switches the form off, PB_POLY1=1 extends it to every case and to
+ * pb_inverse_filter (record sets are then not cached).  All three variables are read when the context is created. */
 typedef enum pb_dense_eval { PB_DENSE_STENCIL = 0, PB_DENSE_AUTO = 1 } pb_dense_eval;
 int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases);
 /* bytes of scratch the context currently holds (for the HBM-footprint report) */

@@ -216,8 +216,7 @@ struct Geometry {
     // ker_size above 25: the taps on the ker_size grid (conv_big.hip), rebuilt after every estimation
     const float *big_taps = nullptr;
     int big_ksize = 0;
-    // the pipeline's polynomials may take the one-pass form (pb_fft_sel.poly): wrap boundary, no edgetaper, and either the
-    // adaptive support policy -- the only one under which kernels within a 4-sample halo occur -- or PB_POLY1=1
+    // this iteration's polynomial may take the one-pass form (pb_fft_sel.poly); set per iteration by pb_polyblur_batch
     bool poly = false;
 };
 
@@ -586,8 +585,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
     Geometry g = geometry(B, C, H, W, ksize / 2);
-    g.poly = (ctx->poly_mode == 1 || (ctx->poly_mode == 2 && (opt->support & 15) == PB_SUPPORT_ADAPTIVE)) &&
-             opt->boundary == PB_WRAP && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
+    const bool poly_eligible = opt->boundary == PB_WRAP && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
     const long n = (long)g.P * g.HW;
     const int n_iter = opt->n_iter;
     if (n_iter == 0) {
@@ -667,6 +665,16 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (dtype != PB_F32 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
         const int cur_dtype = it == 0 ? dtype : work, dst_dtype = it == n_iter - 1 ? dtype : work;
         pb_blur_info *info = infos + (size_t)it * B;
+        {
+            // One-pass polynomial for the images whose kernel fits a 4-sample halo (pb_fft_sel.poly).  By default where it
+            // costs nothing when no image qualifies -- the first step's launch takes those images along, which needs the first
+            // and the last step to store the same type -- and under the adaptive policy, whose small kernels are worth a
+            // launch of their own (1 % of a 4K call when it finds no work).
+            const int first_out = g.t1h ? PB_F16 : PB_F32;
+            const int last_out = (opt->remove_halo || opt->prefilter != PB_PREFILTER_NONE) ? PB_F32 : dst_dtype;
+            g.poly = poly_eligible && (ctx->poly_mode == 1 ||
+                                       (ctx->poly_mode == 2 && ((opt->support & 15) == PB_SUPPORT_ADAPTIVE || first_out == last_out)));
+        }
         if (g.poly) {   // as run_polynomial will ask for
             const float al = opt->alpha, be = opt->beta;
             ctx->poly_want = PolySpec{1, al / 2 - be + 2, 3 * be - al - 6, 5 - 3 * be + al / 2, be};

@@ -79,10 +79,12 @@ struct pb_ctx {
     // one-pass polynomial experiment (env PB_POLY1=1): what the spectra in "conv.khat" were built for, and what the call
     // in progress wants (set around the estimation / the polynomial; off for every other pass)
     // 0 never; 1 every eligible polynomial, host-built records included (those are then not cached); 2 (default) the
-    // pipeline's, under PB_SUPPORT_ADAPTIVE only: mildly blurred images -- the method's own use case -- estimate kernels like
-    // sigma 0.6 / rho 0.3 (clamped) at an oblique angle, dense and within the 4-sample halo, and their polynomial is then
-    // 1.7 x faster; when no image of a call qualifies, the composite launch that finds no work costs 1 % of a 4K call
-    // even on the side stream (1.182 -> 1.195 ms).  Full support (the default policy) never qualifies and never pays.
+    // pipeline's: mildly blurred images -- the method's own use case -- estimate kernels like sigma 0.6 / rho 0.3 at an
+    // oblique angle or the clamped isotropic 0.3 / 0.3, within the 4-sample halo (under the adaptive policy; the latter
+    // under full support too, its other taps underflow), and their polynomial is then 1.7 x faster.  Where the first step's
+    // launch can take such images along (same output type as the last step's) that costs nothing when no image
+    // qualifies; otherwise a composite launch is needed, which finds no work then and costs 1 % of a 4K call even on the
+    // side stream (1.182 -> 1.195 ms): issued under the adaptive policy only.
     int poly_mode = 2;
     PolySpec poly_built{0, 0.f, 0.f, 0.f, 0.f}, poly_want{0, 0.f, 0.f, 0.f, 0.f};
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
@@ -169,7 +171,10 @@ struct ConvPass {
     const float *khat;
     int khat_ready;
     int strip;           // rank-1 images of full support are done by conv_strip.hip's launch of this step: their tiles exit at once
-    int poly;            // 1: the composite pass of a polynomial -- only images whose pb_fft_sel.poly is set; 0: those images are skipped
+    int poly;            // one-pass polynomial (pb_fft_sel.poly): 0 = those images are skipped (another launch does them); 1 = the
+                         // composite pass: only those images; 2 = the first step's launch takes them along -- for them it IS the
+                         // composite pass, written to out2 with scale 1, coef 0 and clamp2 (same output type as `out`)
+    void *out2;  int out2_kind;  int out2_pitch;  long out2_plane;  int clamp2;
     int no_fft;          // this pass keeps the stencil bodies (pb_launch_conv_poly: some step of the polynomial does not suit the other)
 };
 

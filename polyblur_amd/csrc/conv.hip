@@ -283,7 +283,10 @@ __global__ __launch_bounds__(NT, 4) void conv_tile_kernel(const ConvPass a, int 
     const bool sep = cinfo->separable != 0;
     if (sep ? a.skip_sep : a.skip_general) return;                 // another launch of this step does this image
     if (sep && a.strip && cinfo->radius > 8) return;               // the streaming strip body (conv_strip.hip) does this image
-    if (!sep && a.fsel && as_constant(a.fsel + plane / a.C)->use_fft) return;     // the tile-spectrum body (conv_fft.hip) does this image
+    if (a.fsel) {                                                  // the tile-spectrum body (conv_fft.hip) does this image:
+        const PB_CONSTANT pb_fft_sel *fs = as_constant(a.fsel + plane / a.C);
+        if (fs->poly || (!sep && fs->use_fft)) return;             // its whole polynomial in one pass, or this step (dense kernels)
+    }
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
@@ -393,8 +396,19 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     const bool have = known != ctx->rec_cache.end() && known->second.B == B;
     // (per-launch profiling keeps everything on one stream: events on the side stream would time its launches' wait
     // behind the other kernel's workgroups, not their work)
-    // One-pass polynomial (experiment): the images whose spectrum is the polynomial's take ONE window pass from the
-    // first step's input to the last step's output; the steps' own launches skip them.
+    // One-pass polynomial: the images whose spectrum is the polynomial's take ONE window pass from the first step's input
+    // to the last step's output; the later steps' launches skip them.  When the first and the last step store the same
+    // type, the first step's launch takes them along (ConvPass.poly = 2: no launch of their own, nothing to pay when no
+    // image qualifies); otherwise a composite launch does them.  (The spectra the steps meet are those ctx->poly_want
+    // asks for: pb_build_khat rebuilds any others.)
+    const bool poly_on = fft && ctx->poly_want.on;
+    const bool fold = poly_on && steps[0].out_dtype == steps[2].out_dtype;
+    auto first_step = [&](ConvPass &p) {
+        if (!fold) return;
+        p.poly = 2;
+        p.out2 = steps[2].out; p.out2_kind = steps[2].out_kind; p.out2_pitch = steps[2].out_pitch; p.out2_plane = steps[2].out_plane;
+        p.clamp2 = steps[2].clamp01;
+    };
     auto composite = [&](float *k, pb_fft_sel *sel) -> int {
         ConvPass pc = steps[0];
         pc.out = steps[2].out; pc.out_kind = steps[2].out_kind; pc.out_dtype = steps[2].out_dtype;
@@ -411,10 +425,11 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
             ConvPass p = steps[s];
             p.khat_ready = s > 0;
             if (!fft) p.no_fft = 1;
+            if (s == 0) first_step(p);
             const int rc = pb_launch_conv(ctx, p);
             if (rc) return rc;
         }
-        if (fft && ctx->poly_built.on && ctx->khat_owner == steps[0].info) {
+        if (poly_on && !fold && ctx->poly_built.on && ctx->khat_owner == steps[0].info) {
             float *k = nullptr; pb_fft_sel *sel = nullptr;
             const int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, false);
             if (rc) return rc;
@@ -431,7 +446,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->aux;
     // (the composite pass touches other images than the steps' launches do: it, too, runs -- or finds no work -- beside them)
-    if (ctx->poly_built.on) rc = composite(k, sel);
+    if (poly_on && !fold) rc = composite(k, sel);
     for (int s = 0; s < 3 && !rc; ++s) {
         ConvPass p = steps[s];
         p.khat = k; p.fsel = sel;
@@ -443,6 +458,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     for (int s = 0; s < 3; ++s) {
         ConvPass p = steps[s];
         p.khat = k; p.fsel = sel;
+        if (s == 0) first_step(p);
         rc = ctx->fft_wave ? pb_launch_conv_wfft(ctx, p) : PB_ERR_UNSUPPORTED;
         if (rc == PB_ERR_UNSUPPORTED) rc = pb_launch_conv_fft(ctx, p);
         if (rc) break;

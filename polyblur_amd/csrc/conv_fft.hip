@@ -303,7 +303,7 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, co
     const int img = __builtin_amdgcn_readfirstlane(plane / a.C);
     const PB_CONSTANT pb_fft_sel *sel = as_constant(a.fsel + img);
     if (!sel->use_fft) return;                                  // a stencil body of conv_tile_kernel does this image
-    if ((sel->poly != 0) != (a.poly != 0)) return;              // (one-pass polynomial: the composite pass does these images, and only these)
+    if (!poly_match(a.poly, sel->poly)) return;                 // (one-pass polynomial: see ConvPass.poly)
     const int R = sel->rf, c = (R >> 2) - 1;
     // This XCD's run of the plane has per <= slots pairs.  They are dealt to the slots evenly -- slot i takes pair
     // floor(i per / slots) when that differs from its successor's -- so that the idle workgroups of an image with larger
@@ -315,7 +315,8 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, co
     const int local = __builtin_amdgcn_readfirstlane(xcd * per + j0);
     if (__builtin_amdgcn_readfirstlane(j1) == local - xcd * per || local >= g.njobs[c]) return;
     const int ty = __builtin_amdgcn_readfirstlane(div_small(local, g.inv_pairs_x[c])), pxi = local - ty * g.pairs_x[c];
-    window_pair<TIn, TX, TOut>(a, a.info + img, plane, ty, pxi, R, Z, a.khat + (long)img * (FT_N * FT_N));
+    const ConvPass af = fold_pass(a, a.poly == 2 && sel->poly != 0);
+    window_pair<TIn, TX, TOut>(af, a.info + img, plane, ty, pxi, R, Z, a.khat + (long)img * (FT_N * FT_N));
 }
 
 

@@ -125,6 +125,18 @@ __device__ __forceinline__ void idft8(cf (&v)[8]) {
     t = v[3]; v[3] = v[5]; v[5] = t;
 }
 
+// ConvPass.poly == 2: what the first step's launch does for an image whose whole polynomial is one pass
+__device__ __forceinline__ ConvPass fold_pass(const ConvPass &a, bool fold) {
+    ConvPass f = a;
+    if (fold) {
+        f.out = a.out2; f.out_kind = a.out2_kind; f.out_pitch = a.out2_pitch; f.out_plane = a.out2_plane;
+        f.scale = 1.f; f.coef = 0.f; f.clamp01 = a.clamp2;
+    }
+    return f;
+}
+// whether a launch of the tile-spectrum body takes an image (per its pb_fft_sel.poly; see ConvPass.poly)
+__device__ __forceinline__ bool poly_match(int pass_poly, int sel_poly) { return pass_poly == 2 || (sel_poly != 0) == (pass_poly != 0); }
+
 // Geometry of a pass for the three window halo classes (index R / 4 - 1), computed on the host: window pairs per row, pairs
 // per plane, pairs per plane and XCD; the reciprocals turn the kernel's divisions of small integers into one multiply.
 struct FftGeom {

@@ -623,17 +623,19 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     const int q = (int)(blockIdx.x & 7u);
     int rem = (int)(blockIdx.x >> 3);                  // position in the list
     int img = 0, R = 0;
+    bool fold = false;
     if (B == 1) {
         // (one image: its record is read on the scalar side -- no trip through the vector memory queue)
         const PB_CONSTANT pb_fft_sel *s0 = as_constant(a.fsel);
-        if (!s0->use_fft || (s0->poly != 0) != (a.poly != 0)) return;
+        if (!s0->use_fft || !poly_match(a.poly, s0->poly)) return;
         R = s0->rf;
+        fold = a.poly == 2 && s0->poly != 0;
     } else {
         // list entries of image i: its share of every plane
         auto share_of = [&](int i) -> int {
             if (i >= B) return 0;
             const pb_fft_sel s = a.fsel[i];
-            if (!s.use_fft || (s.poly != 0) != (a.poly != 0)) return 0;     // (poly: see pb_fft_sel)
+            if (!s.use_fft || !poly_match(a.poly, s.poly)) return 0;
             return (s.rf <= 4 ? g.per[0] : (s.rf <= 8 ? g.per[1] : g.per[2])) * C;
         };
         bool work = false;
@@ -653,6 +655,7 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
         if (!work) return;
         img = __builtin_amdgcn_readfirstlane(img); rem = __builtin_amdgcn_readfirstlane(rem);
         R = as_constant(a.fsel + img)->rf;
+        fold = a.poly == 2 && as_constant(a.fsel + img)->poly != 0;
     }
     const int c = R <= 4 ? 0 : (R <= 8 ? 1 : 2);
     const int pl = __builtin_amdgcn_readfirstlane(div_small(rem, g.inv_per[c]));
@@ -663,9 +666,10 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     const int plane = img * C + pl;
     const float *kp = a.khat + (long)img * (FT_N * FT_N);
     const pb_blur_info *info = a.info + img;
+    const ConvPass af = fold_pass(a, fold);
 #define PB_RUN(RR)                                                                                  \
-    if (pair_is_fast<RR, TIn, TX, TOut>(a, ty, pxi)) wave_pair<RR, true, TIn, TX, TOut>(a, info, plane, ty, pxi, zb, kp, tr); \
-    else wave_pair<RR, false, TIn, TX, TOut>(a, info, plane, ty, pxi, zb, kp, tr);
+    if (pair_is_fast<RR, TIn, TX, TOut>(af, ty, pxi)) wave_pair<RR, true, TIn, TX, TOut>(af, info, plane, ty, pxi, zb, kp, tr); \
+    else wave_pair<RR, false, TIn, TX, TOut>(af, info, plane, ty, pxi, zb, kp, tr);
     if (c == 2) { PB_RUN(12) } else if (c == 1) { PB_RUN(8) } else { PB_RUN(4) }
 #undef PB_RUN
 }

@@ -78,10 +78,12 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     }
     // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
     PB_PT(20);
-    const bool dense = __syncthreads_and(sym) && separable == 0 && min_phases >= 0;
-    // (one-pass polynomial: a kernel within the 4-sample halo, whatever its phase count -- one window pass against three
-    // stencil passes)
-    const bool poly = ps.on && dense && R <= 4;
+    const bool symm = __syncthreads_and(sym) && min_phases >= 0;
+    const bool dense = symm && separable == 0;
+    // (one-pass polynomial: a kernel within the 4-sample halo, whatever its phase count and whether rank-1 or not -- the
+    // polynomial of a rank-1 kernel is not rank-1, its spectrum is as good as any: one window pass against three stencil
+    // passes, 0.17 ms per 4K polynomial for the clamped isotropic kernel sigma = rho = 0.3 that later iterations mostly find)
+    const bool poly = ps.on && symm && R <= 4;
     const bool use = poly || (dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0));
     if (tid == 0 && slice == 0) {
         sel->use_fft = use ? 1 : 0; sel->rf = poly ? 12 : (R <= 4 ? 4 : (R <= 8 ? 8 : 12));

@@ -68,14 +68,16 @@ def test_one_pass_matches_oracle_and_three_steps(engines, shape, dtype):
 
 
 def test_one_pass_in_a_mixed_batch_and_other_passes(engines):
-    """one image per body: one-pass (radius 4), dense with full halo (three tile-spectrum steps), rank-1 (stencil); then
+    """one image per body: one-pass (radius 4), dense with full halo (three tile-spectrum steps), rank-1 (stencil), rank-1
+    within the 4-sample halo (one pass); then
     passes that need the kernel's own spectrum again (zero boundary: three steps; edgetaper blends)"""
     one, three = engines
-    x, _ = synthetic_blurry_batch(3, 3, 420, 660, seed0=82)
-    sg, rh, th = [0.6, 2.5, 2.0], [0.4, 1.2, 1.0], [np.float32(0.5), np.float32(1.0), np.float32(0.0)]
+    x, _ = synthetic_blurry_batch(4, 3, 420, 660, seed0=82)
+    # ... and the clamped isotropic kernel later iterations mostly find: rank-1, within the 4-sample halo -- one pass as well
+    sg, rh, th = [0.6, 2.5, 2.0, 0.3], [0.4, 1.2, 1.0, 0.3], [np.float32(0.5), np.float32(1.0), np.float32(0.0), np.float32(0.9)]
     buf = one.make_kernels(sg, rh, th, support=capi.PB_SUPPORT_ADAPTIVE)
-    info = one.read_info(buf, 3)
-    assert list(info["separable"]) == [0, 0, 1] and info["radius"][0] == 4 and info["radius"][1] > 8
+    info = one.read_info(buf, 4)
+    assert list(info["separable"]) == [0, 0, 1, 1] and info["radius"][0] == 4 and info["radius"][1] > 8 and info["radius"][3] == 4
     k = info["kernel"][:, None]
     got = one.inverse_filter(x, buf, 6.0, 1.0, capi.PB_WRAP)
     assert maxabs(got, ref.inverse_filtering_rank3(x, k, 6.0, 1.0, method="fft")) < 8e-6
@@ -112,7 +114,21 @@ def test_whole_call_on_a_mildly_blurred_image(engines, shape):
     auto = Engine(0)
     try:
         assert np.array_equal(auto.polyblur(x, o), got)
+        # full support: these kernels have radius 8 / 6 there (taps count until they underflow) -- three steps
         of = one.make_options(support=capi.PB_SUPPORT_FULL, **kw)
         assert np.array_equal(auto.polyblur(x, of), three.polyblur(x, of))
+        # ... but the clamped isotropic estimate sigma = rho = 0.3 (c = 0.2 here) has radius 4 under full support too, and
+        # fp32 images let the first step's launch take it along: one pass by default
+        kw2 = dict(kw, c=0.2)
+        of2 = one.make_options(support=capi.PB_SUPPORT_FULL, **kw2)
+        a2, i2 = auto.polyblur(x, of2, want_info=True)
+        t2 = three.polyblur(x, of2)
+        assert (i2["sigma"] == np.float32(0.3)).all() and (i2["radius"] == 4).all() and (i2["separable"] == 1).all()
+        assert not np.array_equal(a2, t2) and maxabs(a2, t2) < 2e-5
+        assert maxabs(a2, ref.polyblur_deblurring(x, **kw2)) < 2e-5
+        # fp16 images: the last iteration stores fp16, its first step fp32 -- no launch to ride on, three steps under full support
+        xh = x.astype(np.float16)
+        assert np.array_equal(auto.polyblur(xh, of2)[..., :8, :8], auto.polyblur(xh, of2)[..., :8, :8])
+        assert maxabs(auto.polyblur(xh, of2).astype(np.float32), ref.polyblur_deblurring(xh.astype(np.float32), **kw2)) < 1e-3
     finally:
         auto.close()

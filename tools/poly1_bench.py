@@ -61,8 +61,8 @@ rng = np.random.default_rng(83)
 x = rng.random((1, 3, 2160, 3840), dtype=np.float32)
 x = np.clip(ref.convolve2d(x, ref.gaussian_kernel_2d([np.float32(0.6)], [0.9], [0.5]), method="fft"), 0, 1).astype(np.float32)
 d = torch.from_numpy(x).cuda()
-for support in ("adaptive", "full"):
-    kw = dict(n_iter=3, c=0.4, b=0.468, alpha=6, beta=1, support=support)
+for support, c in (("adaptive", 0.4), ("full", 0.4), ("adaptive", 0.2), ("full", 0.2)):   # c = 0.2: the clamped isotropic estimate, rank-1
+    kw = dict(n_iter=3, c=c, b=0.468, alpha=6, beta=1, support=support)
     out, infos = polyblur_deblurring(d, return_info=True, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
