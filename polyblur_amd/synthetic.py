@@ -70,8 +70,8 @@ def blur_circular(img: np.ndarray, psf: np.ndarray) -> np.ndarray:
 
 
 def synthetic_blurry_image(c: int, h: int, w: int, seed: int, noise_std: float = 0.01,
-                           force_theta_deg=None):
-    """Returns (blurry (C,H,W) float32, (sigma, rho, theta_deg))."""
+                           force_theta_deg=None, blur=None):
+    """Returns (blurry (C,H,W) float32, (sigma, rho, theta_deg)).  blur = (sigma, rho, theta_deg) instead of the drawn one."""
     rng = np.random.default_rng(seed)
     sharp = synthetic_image(c, h, w, rng)
     sigma = rng.uniform(0.6, 3.5)
@@ -79,6 +79,8 @@ def synthetic_blurry_image(c: int, h: int, w: int, seed: int, noise_std: float =
     theta = 6.0 * int(rng.integers(0, 30))
     if force_theta_deg is not None:
         theta = float(force_theta_deg)
+    if blur is not None:
+        sigma, rho, theta = (float(v) for v in blur)
     blurry = blur_circular(sharp, gaussian_psf(sigma, rho, theta))
     blurry = blurry + rng.normal(0.0, noise_std, size=blurry.shape).astype(np.float32)
     return np.clip(blurry, 0.0, 1.0).astype(np.float32), (float(sigma), float(rho), float(theta))
