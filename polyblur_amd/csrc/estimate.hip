@@ -1080,7 +1080,7 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         __syncthreads();
         if (tid < 3) info->phase[total + tid] = total ? s_first : 0;     // harmless targets for the prefetches
         PB_PT(8);
-        if (rl) { rl->taps = sk; rl->kx = skx; rl->ky = sky; rl->radius = s_radius; rl->nph = total; rl->separable = s_sep; }      // (uniform; the taps stay in LDS)
+        if (rl) { rl->taps = sk; rl->radius = s_radius; rl->nph = total; rl->separable = s_sep; }      // (uniform; the taps stay in LDS)
     }
 }
 

@@ -51,7 +51,7 @@ constexpr int KH_SLICES = 8;          // workgroups per image: each forms the sp
 
 // What khat_body needs of a record, for a caller that has just formed it and still holds it in LDS (estimate.hip's
 // parameter kernel): no wait for the record's stores to land, no read back.
-struct RecLds { const float *taps, *kx, *ky; int radius, nph, separable; };
+struct RecLds { const float *taps; int radius, nph, separable; };
 
 // Called by all KH_THREADS threads of a workgroup: slice `slice` (0 .. KH_SLICES - 1) of the spectrum of `info`'s taps,
 // and (slice 0) the image's choice of body.  The record may have been written by this same workgroup just before (global
@@ -62,13 +62,14 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     __shared__ double2 G[NR * PXS];
     __shared__ double cs[KH_FT_N], sn[KH_FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
-    __shared__ int s_halo;
+    __shared__ float s_out[2 * (KH_THREADS / 64)];
     const int tid = threadIdx.x;
     const int nph = rl ? rl->nph : info->nphase[0] + info->nphase[1] + info->nphase[2];
     const int R = rl ? rl->radius : info->radius;
     const int separable = rl ? rl->separable : info->separable;
     if (tid < KH_FT_N) { cs[tid] = kCos64[tid]; sn[tid] = kSin64[tid]; }
     bool sym = true;
+    float o4 = 0.f, o8 = 0.f;                         // |taps| outside the +-4 / +-8 box (inside the record's own)
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
         const bool in = abs(u) <= R && abs(v) <= R;
@@ -76,31 +77,32 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         const float km = rl ? rl->taps[PB_KSIZE * PB_KSIZE - 1 - i] : info->kernel[PB_KSIZE * PB_KSIZE - 1 - i];
         sk[i] = in ? k : 0.f;
         sym = sym && (!in || k == km);
+        const int d = max(abs(u), abs(v));
+        if (in && d > 4) o4 += fabsf(k);
+        if (in && d > 8) o8 += fabsf(k);
     }
-    // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
     // The window halo of the tile-spectrum body.  The spectrum below holds EVERY tap of the record's box; the halo only has
     // to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error of at
-    // most that mass times the image range.  The record's radius counts taps until they underflow to zero (full support)
-    // -- 8 for sigma 0.6 whose taps beyond +-4 carry 1e-13 of the mass --, so the halo is the smaller of its class and the
-    // radius outside which the marginals carry < 1e-10 (an aliasing term three orders below fp32 rounding; sigma <= 0.69
-    // -> 4, sigma <= 1.31 -> 8).
-    if (tid < 64) {
-        float a = 0.f;
-        if (tid < PB_KSIZE) a = fabsf(rl ? rl->kx[tid] : info->kx[tid]) + fabsf(rl ? rl->ky[tid] : info->ky[tid]);
-        const int d = abs(tid - PB_KRAD);
-        float o4 = d > 4 ? a : 0.f, o8 = d > 8 ? a : 0.f;
+    // most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero (full
+    // support) -- 8 for sigma 0.6 whose taps beyond +-4 carry 1e-13 of the mass --, so the halo is the smaller of its class
+    // and the radius outside which the taps' absolute values sum to < 1e-10 (an aliasing term three orders below fp32
+    // rounding; a Gaussian with sigma <= 0.69 along both axes -> 4, <= 1.31 -> 8; any caller-supplied taps are measured
+    // the same way).
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { o4 += __shfl_xor(o4, o); o8 += __shfl_xor(o8, o); }
-        if (tid == 0) s_halo = o4 < 1e-10f ? 4 : (o8 < 1e-10f ? 8 : 12);
-    }
+    for (int o = 32; o > 0; o >>= 1) { o4 += __shfl_xor(o4, o); o8 += __shfl_xor(o8, o); }
+    if ((tid & 63) == 0) { s_out[tid >> 6] = o4; s_out[KH_THREADS / 64 + (tid >> 6)] = o8; }
     PB_PT(20);
     const bool symm = __syncthreads_and(sym) && min_phases >= 0;
-    const int Rh = min(R <= 4 ? 4 : (R <= 8 ? 8 : 12), s_halo);
+    float m4 = 0.f, m8 = 0.f;
+#pragma unroll
+    for (int w = 0; w < KH_THREADS / 64; ++w) { m4 += s_out[w]; m8 += s_out[KH_THREADS / 64 + w]; }
+    const int Rh = min(R <= 4 ? 4 : (R <= 8 ? 8 : 12), m4 < 1e-10f ? 4 : (m8 < 1e-10f ? 8 : 12));
     const bool dense = symm && separable == 0;
     // (one-pass polynomial: a kernel within the 4-sample halo, whatever its phase count and whether rank-1 or not -- the
     // polynomial of a rank-1 kernel is not rank-1, its spectrum is as good as any: one window pass against three stencil
     // passes, 0.17 ms per 4K polynomial for the clamped isotropic kernel sigma = rho = 0.3 that later iterations mostly find)
     const bool poly = ps.on && symm && Rh <= 4;
+    // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
     const bool use = poly || (dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0));
     if (tid == 0 && slice == 0) {
         sel->use_fft = use ? 1 : 0; sel->rf = poly ? 12 : Rh;

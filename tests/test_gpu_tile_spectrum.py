@@ -75,6 +75,30 @@ def test_caller_supplied_taps(eng, symmetric):
     assert maxabs(a, want) < 2e-6
 
 
+def test_window_halo_follows_the_taps_not_the_marginals(eng):
+    """The windows' halo is the radius outside which the taps' ABSOLUTE values are negligible (csrc/khat.h).  A point-symmetric
+    kernel whose far taps cancel in both marginals -- +a at (-10, +10) and (+10, -10), -a at (+10, +10) and (-10, -10) -- around
+    a narrow Gaussian must still get the full halo; and a narrow Gaussian alone, whose radius under full support is 8 (taps
+    count until they underflow), runs on the windows of the 4-sample halo with the same result."""
+    rng = np.random.default_rng(10)
+    g = ref.gaussian_kernel_2d(np.float32([0.5]), [0.6], [0.4])[0]
+    k = g.copy()
+    for (u, v, sgn) in ((-10, 10, 1), (10, -10, 1), (10, 10, -1), (-10, -10, -1)):
+        k[12 + u, 12 + v] += sgn * 0.05
+    assert abs(k.sum(0)[22]) < 1e-9 and abs(k.sum(1)[22]) < 1e-9                       # the marginals do not see them
+    xp = rng.random((1, 2, 200 + 24, 330 + 24), dtype=np.float32)
+    for taps in (k, g):
+        buf = eng.set_kernels(taps[None])
+        eng.set_dense_eval("auto", 0)                        # every dense point-symmetric kernel through the tile-spectrum body
+        try:
+            a = eng.convolve2d(xp, buf, capi.PB_ZERO)
+            w = eng.convolve2d(xp, buf, capi.PB_WRAP)
+        finally:
+            eng.set_dense_eval("auto", capi.PB_DENSE_MIN_PHASES)
+        assert maxabs(a, ref.convolve2d(xp, taps[None, None], method="direct")) < 2e-6
+        assert maxabs(w, ref.convolve2d(xp, taps[None, None], method="fft")) < 2e-6
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float16, 1e-3)])
 @pytest.mark.parametrize("extra", [dict(), dict(edgetaping=True), dict(method="direct", remove_halo=True)])
 def test_pipeline_both_ways(eng, dtype, tol, extra):
