@@ -36,6 +36,7 @@ SYMBOLS = [
     "pb_bilateral5", "pb_time_inner_loop", "pb_profile_begin", "pb_profile_end", "pb_extract_patches",
     "pb_overlap_add", "pb_u8_deinterleave", "pb_u8_interleave", "pb_dt_normalized_convolution",
     "pb_fft_length_supported", "pb_make_separable_kernels", "pb_set_dense_eval",
+    "pb_body_selection",
     "pb_comm_shard", "pb_comm_unique_id", "pb_comm_init", "pb_comm_destroy", "pb_comm_scatter", "pb_comm_gather",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused", "conv_fft"]
@@ -138,6 +139,7 @@ def load_library():
             "pb_overlap_add": (ci, [vp, vp, vp] + [ci] * 13 + [vp, vp]),
             "pb_fft_length_supported": (ci, [ci]),
             "pb_make_separable_kernels": (ci, [vp, ci, vp, vp, ci, ci]),
+            "pb_body_selection": (ci, [vp, C.POINTER(ci), ci]),
             "pb_profile_begin": (ci, [vp]),
             "pb_profile_end": (ci, [vp, fp, C.POINTER(ci)]),
             "pb_comm_shard": (ci, [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]),

@@ -88,6 +88,8 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
     if (const char *e = getenv("PB_STRIP")) ctx->strip_mode = atoi(e);
     if (const char *e = getenv("PB_POLY1")) ctx->poly_mode = atoi(e);
+    if (const char *e = getenv("PB_POLY_GAIN")) ctx->poly_gain = (float)atof(e);
+    if (const char *e = getenv("PB_POLY_MIN_AREA")) ctx->poly_min_area = atoi(e);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     const char *side = getenv("PB_SIDE_STREAM");
@@ -216,8 +218,6 @@ struct Geometry {
     // ker_size above 25: the taps on the ker_size grid (conv_big.hip), rebuilt after every estimation
     const float *big_taps = nullptr;
     int big_ksize = 0;
-    // this iteration's polynomial may take the one-pass form (pb_fft_sel.poly); set per iteration by pb_polyblur_batch
-    bool poly = false;
 };
 
 Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
@@ -275,6 +275,36 @@ int run_edgetaper(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype
     return rc;
 }
 
+// The three Horner steps of y = a3 K^3 x + a2 K^2 x + a1 K x + beta x (deblurring.py:122-138).
+void make_steps(const Geometry &g, const void *xsrc, int x_dtype, const float *xpadded, const pb_blur_info *info, float alpha,
+                float beta, int boundary, float *t1, float *t2, void *dst, int dst_dtype, int clamp01, ConvPass *steps) {
+    const float a3 = alpha / 2 - beta + 2, a2 = 3 * beta - alpha - 6, a1 = 5 - 3 * beta + alpha / 2;
+    ConvPass p = base_pass(g, info, boundary);
+    auto set_x = [&](ConvPass &q) { if (xpadded) set_x_padded(q, g, xpadded); else set_x_virtual(q, g, xsrc, x_dtype); };
+    const int tdt = g.t1h ? PB_F16 : PB_F32;
+    void *T1 = g.t1h ? g.t1h : static_cast<void *>(t1), *T2 = g.t2h ? g.t2h : static_cast<void *>(t2);
+    // t1 = K * (a3 x) + a2 x
+    if (xpadded) set_in_padded(p, g, xpadded); else set_in_virtual(p, g, xsrc, x_dtype);
+    set_x(p); set_out_padded(p, g, T1, tdt);
+    p.scale = a3; p.coef = a2;
+    steps[0] = p;
+    // t2 = K * t1 + a1 x
+    set_in_padded(p, g, T1, tdt); set_out_padded(p, g, T2, tdt);
+    p.scale = 1.f; p.coef = a1;
+    steps[1] = p;
+    // y = K * t2 + beta x   (only the crop is needed)
+    set_in_padded(p, g, T2, tdt); set_out_interior(p, g, dst, dst_dtype);
+    p.coef = beta; p.clamp01 = clamp01;
+    steps[2] = p;
+}
+
+// what the spectra of a polynomial with these steps should be those of (PolySpec; conv.hip: pb_poly_spec_mode)
+PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta) {
+    const int mode = pb_poly_spec_mode(ctx, steps);
+    if (!mode) return no_poly();
+    return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area};
+}
+
 // y = a3 K^3 x + a2 K^2 x + a1 K x + beta x by Horner, three stencil passes (deblurring.py:122-138).
 // X is either the un-padded image (virtual pad) or a padded fp32 image (after edgetaper).
 int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype, const float *xpadded,
@@ -318,24 +348,8 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
         }
         return PB_OK;
     }
-    ConvPass p = base_pass(g, info, boundary);
-    auto set_x = [&](ConvPass &q) { if (xpadded) set_x_padded(q, g, xpadded); else set_x_virtual(q, g, xsrc, x_dtype); };
-    const int tdt = g.t1h ? PB_F16 : PB_F32;
-    void *T1 = g.t1h ? g.t1h : static_cast<void *>(t1), *T2 = g.t2h ? g.t2h : static_cast<void *>(t2);
     ConvPass steps[3];
-    // t1 = K * (a3 x) + a2 x
-    if (xpadded) set_in_padded(p, g, xpadded); else set_in_virtual(p, g, xsrc, x_dtype);
-    set_x(p); set_out_padded(p, g, T1, tdt);
-    p.scale = a3; p.coef = a2;
-    steps[0] = p;
-    // t2 = K * t1 + a1 x
-    set_in_padded(p, g, T1, tdt); set_out_padded(p, g, T2, tdt);
-    p.scale = 1.f; p.coef = a1;
-    steps[1] = p;
-    // y = K * t2 + beta x   (only the crop is needed)
-    set_in_padded(p, g, T2, tdt); set_out_interior(p, g, dst, dst_dtype);
-    p.coef = beta; p.clamp01 = clamp01;
-    steps[2] = p;
+    make_steps(g, xsrc, x_dtype, xpadded, info, alpha, beta, boundary, t1, t2, dst, dst_dtype, clamp01, steps);
     if (g.big_taps) {
         for (int s = 0; s < 3; ++s) {
             const int rc = pb_launch_conv_big(ctx, steps[s], g.big_taps, g.big_ksize);
@@ -343,11 +357,11 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
         }
         return PB_OK;
     }
-    // (experiment, PB_POLY1=1: under the wrap boundary the three steps are one filter, deblurring.py:139-169 -- kernels
-    // within the 4-sample halo take it as one window pass; the spectra are then the polynomial's)
-    if ((g.poly || ctx->poly_mode == 1) && boundary == PB_WRAP && !xpadded) ctx->poly_want = PolySpec{1, a3, a2, a1, beta};
+    // (under the wrap boundary the three steps are one filter, deblurring.py:139-169: images for which one window pass
+    // with that filter's spectrum is the cheaper form take it, pb_fft_sel.poly; the spectra are then the polynomial's)
+    ctx->poly_want = poly_spec(ctx, steps, alpha, beta);
     const int rc = pb_launch_conv_poly(ctx, steps);
-    ctx->poly_want = PolySpec{0, 0.f, 0.f, 0.f, 0.f};
+    ctx->poly_want = no_poly();
     return rc;
 }
 
@@ -665,22 +679,17 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (dtype != PB_F32 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
         const int cur_dtype = it == 0 ? dtype : work, dst_dtype = it == n_iter - 1 ? dtype : work;
         pb_blur_info *info = infos + (size_t)it * B;
-        {
-            // One-pass polynomial for the images whose kernel fits a 4-sample halo (pb_fft_sel.poly).  By default where it
-            // costs nothing when no image qualifies -- the first step's launch takes those images along, which needs the first
-            // and the last step to store the same type -- and under the adaptive policy, whose small kernels are worth a
-            // launch of their own (1 % of a 4K call when it finds no work).
-            const int first_out = g.t1h ? PB_F16 : PB_F32;
+        // The estimation ends with the kernels' spectra and the images' choice of body: it has to know whether this
+        // iteration's polynomial may take the one-pass form (pb_fft_sel.poly) -- exactly what run_polynomial will ask for.
+        if (poly_eligible) {
+            const int src_dtype = opt->prefilter != PB_PREFILTER_NONE ? PB_F32 : cur_dtype;
             const int last_out = (opt->remove_halo || opt->prefilter != PB_PREFILTER_NONE) ? PB_F32 : dst_dtype;
-            g.poly = poly_eligible && (ctx->poly_mode == 1 ||
-                                       (ctx->poly_mode == 2 && ((opt->support & 15) == PB_SUPPORT_ADAPTIVE || first_out == last_out)));
-        }
-        if (g.poly) {   // as run_polynomial will ask for
-            const float al = opt->alpha, be = opt->beta;
-            ctx->poly_want = PolySpec{1, al / 2 - be + 2, 3 * be - al - 6, 5 - 3 * be + al / 2, be};
+            ConvPass steps[3];
+            make_steps(g, cur, src_dtype, nullptr, info, opt->alpha, opt->beta, opt->boundary, nullptr, nullptr, dst, last_out, 1, steps);
+            ctx->poly_want = poly_spec(ctx, steps, opt->alpha, opt->beta);
         }
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
-        ctx->poly_want = PolySpec{0, 0.f, 0.f, 0.f, 0.f};
+        ctx->poly_want = no_poly();
         if (rc) return rc;
         if (ksize > PB_KSIZE) {
             rc = pb_build_big_taps(ctx, info, B, ksize, (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, &g.big_taps);
@@ -757,6 +766,22 @@ int pb_overlap_add(pb_ctx *ctx, const void *patches, void *out, int dtype, int B
     PB_HIP(hipSetDevice(ctx->device));
     return pb_overlap_add_impl(ctx, patches, out, dtype, B, C, H, W, ph, pw, step_h, step_w, n_i, n_j, pad_top, pad_left,
                                dev_win_y, dev_win_x);
+}
+
+int pb_body_selection(pb_ctx *ctx, int *host, int B) {
+    if (!ctx || !host || B < 1) return PB_ERR_BADARG;
+    PB_HIP(hipSetDevice(ctx->device));
+    const auto it = ctx->scratch.find("conv.fftsel");
+    if (it == ctx->scratch.end() || it->second.bytes < sizeof(pb_fft_sel) * (size_t)B || ctx->khat_B < B)
+        return pb_fail(ctx, PB_ERR_BADARG, "pb_body_selection: no selection for %d images on this context", B);
+    std::vector<pb_fft_sel> h((size_t)B);
+    PB_HIP(hipMemcpyAsync(h.data(), it->second.p, sizeof(pb_fft_sel) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b) {
+        host[6 * b] = h[b].use_fft; host[6 * b + 1] = h[b].rf; host[6 * b + 2] = h[b].strip;
+        host[6 * b + 3] = h[b].poly; host[6 * b + 4] = h[b].hx; host[6 * b + 5] = h[b].hy;
+    }
+    return PB_OK;
 }
 
 int pb_profile_begin(pb_ctx *ctx) {

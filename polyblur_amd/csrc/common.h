@@ -38,11 +38,24 @@ struct ProfRec {
     int tag;
 };
 
-// one-pass polynomial experiment: which filter the spectra in the context's scratch are those of (see pb_fft_sel.poly)
-struct PolySpec { int on; float a3, a2, a1, b; };
+// One-pass polynomial: which filter the spectra in the context's scratch are those of (see pb_fft_sel.poly).
+// on: 0 = the kernel's own spectrum (three Horner steps); 1 = the polynomial's for kernels within the 4-sample halo class
+// (composite halo class 12: either tile-spectrum body can run it); 2 = the polynomial's wherever one window pass with
+// the composite filter's own per-axis halos is cheaper than the three steps (wave body only: conv_wfft.hip).
+// gain, min_area: the cost model of mode 2 (khat.h).
+struct PolySpec { int on; float a3, a2, a1, b; float gain; int min_area; };
+inline PolySpec no_poly() { return PolySpec{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0}; }
 inline bool same_spec(const PolySpec &x, const PolySpec &y) {
     return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b));
 }
+
+// rf = window halo class of the workgroup form (conv_fft.hip): 4, 8 or 12 -- 0 when only the wave form can run the image
+// (a composite halo beyond 12); hx, hy = the wave form's window halo per axis (conv_wfft.hip): hx a multiple of 4 (windows stay
+// on 16-byte boundaries), hy even; strip: rank-1 kernel of full support (conv_strip.hip may take it).
+// poly: the image's spectrum is that of the WHOLE polynomial a3 K^3 + a2 K^2 + a1 K + b (the reference's own 'fft' form,
+// deblurring.py:139-169) and the halos those of that composite filter: one window pass (ConvPass.poly = 1 or 2) replaces
+// the image's three Horner steps, whose launches skip it.
+struct pb_fft_sel { int use_fft; int rf; int strip; int poly; int hx; int hy; int pad_[2]; };
 
 struct pb_ctx {
     bool prof_on = false;
@@ -71,9 +84,15 @@ struct pb_ctx {
     // anyway): whether any image takes the tile-spectrum body, whether any takes a stencil body -- a reblurring pass then
     // skips the launch nobody needs -- and whose spectra the context's scratch currently holds.  Records estimated on the
     // device (the pipeline) are never in here: their passes issue both launches.
-    struct RecFlags { int B; bool any_fft, any_other, any_strip, any_tile; };   // any_other = any_strip || any_tile (by body of the fp32 pass)
+    // any_other = any_strip || any_tile (by body of the fp32 pass); any_fft3 = some image takes the tile-spectrum body step by step.
+    // The first set is the choice of body without the one-pass polynomial (every single pass); `poly` = the choice under the
+    // PolySpec `spec` (read back the first time a polynomial with that spec meets these records; sel = the device's records)
+    struct BodyFlags { bool any_fft = false, any_other = false, any_strip = false, any_tile = false, any_fft3 = false; };
+    struct RecFlags { int B; BodyFlags plain; bool poly_valid; PolySpec spec; BodyFlags poly; std::vector<pb_fft_sel> sel; };
     std::map<const void *, RecFlags> rec_cache;
+    const std::vector<pb_fft_sel> *known_sel = nullptr;   // the records of the pass being launched, where the host has them (sizes its job grid)
     const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)
+    int khat_B = 0;                      // ... and how many of its records they cover (a longer run at the same address has stale tails)
     const void *khat_buf = nullptr;
     bool khat_by_estimate = false;
     // one-pass polynomial experiment (env PB_POLY1=1): what the spectra in "conv.khat" were built for, and what the call
@@ -86,7 +105,12 @@ struct pb_ctx {
     // qualifies; otherwise a composite launch is needed, which finds no work then and costs 1 % of a 4K call even on the
     // side stream (1.182 -> 1.195 ms): issued under the adaptive policy only.
     int poly_mode = 2;
-    PolySpec poly_built{0, 0.f, 0.f, 0.f, 0.f}, poly_want{0, 0.f, 0.f, 0.f, 0.f};
+    PolySpec poly_built = no_poly(), poly_want = no_poly();
+    // cost model of the general one-pass form (PolySpec.on == 2; env PB_POLY_GAIN, PB_POLY_MIN_AREA): an image takes it when
+    // its composite tile area x 3 x poly_gain is at least the tile area of its three-step windows, or -- an image the
+    // stencil bodies would take -- at least poly_min_area samples
+    float poly_gain = 1.0f;
+    int poly_min_area = 768;
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
 };
 
@@ -144,10 +168,7 @@ enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
        EPI_TAPER = 1 };   // out = a * x + (1-a) * (K*in),  a = v1[py] * v2[px]
 
 // per image: which body evaluates a dense kernel (written on the device by khat_kernel, conv_fft.hip)
-struct pb_fft_sel { int use_fft; int rf; int strip; int poly; };   // rf = window halo of the tile-spectrum body: 4, 8 or 12; strip: rank-1 kernel of full support (conv_strip.hip may take it)
-// poly (experiment, env PB_POLY1=1): the image's spectrum is that of the WHOLE polynomial a3 K^3 + a2 K^2 + a1 K + b (the
-// reference's own 'fft' form, deblurring.py:139-169) and rf the halo of that composite filter, 3 x 4 = 12: one window
-// pass (ConvPass.poly = 1) replaces the image's three Horner steps, whose launches skip it.
+constexpr int PB_POLY_MIN_TX = 24, PB_POLY_MIN_TY = 16;     // smallest tile of a one-pass window (bounds the job grid)
 
 
 struct ConvPass {
@@ -190,6 +211,9 @@ void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // 
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_strip(pb_ctx *ctx, const ConvPass &p);                    // conv_strip.hip; PB_ERR_UNSUPPORTED: not an all-fp32 plain Horner pass
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p);                     // conv_wfft.hip; PB_ERR_UNSUPPORTED: dtype combination not built
+bool pb_conv_fft_types(const ConvPass &p);                                   // conv_fft.hip: whether the workgroup form is built for the pass's types
+bool pb_conv_wfft_types(const ConvPass &p);                                  // ... whether it is built for the pass's types
+int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps);                   // conv.hip: the PolySpec.on a polynomial with these steps may ask for
 // kernels larger than the 25 x 25 record (conv_big.hip): their taps on the ker_size grid, and one Horner step with them
 int pb_build_big_taps(pb_ctx *ctx, const pb_blur_info *dev_info, int B, int ksize, int shift, const float **taps);
 int pb_launch_conv_big(pb_ctx *ctx, const ConvPass &p, const float *taps, int ksize);

@@ -324,6 +324,7 @@ int launch_typed(pb_ctx *ctx, const ConvPass &p) {
 // One launch per pass: each image's record decides on the device which body evaluates its tiles, so a batch
 // may mix rank-1 and general kernels and the host never has to read the estimates back.
 static int launch_stencil(pb_ctx *ctx, const ConvPass &p);
+static int launch_tile_spectrum(pb_ctx *ctx, const ConvPass &p);
 
 // Dense kernels above the context's phase threshold take the tile-spectrum body: a second launch of the same step, in
 // which -- as in the first -- every image's tiles exit at once unless the image's record selects that body.  For record
@@ -336,27 +337,48 @@ static bool fft_pass_ok(const ConvPass &p) {
            pb_conv_fft_feasible(p);
 }
 
+// What the host knows about the B records at `info` under the spec the pass in progress wants (ctx->poly_want): nullptr =
+// nothing -- records built on the device, or a one-pass spec these records have not met yet.
+static const pb_ctx::BodyFlags *known_flags(pb_ctx *ctx, const void *info, int B, const std::vector<pb_fft_sel> **sel = nullptr) {
+    const auto it = ctx->rec_cache.find(info);
+    if (it == ctx->rec_cache.end() || it->second.B != B) return nullptr;
+    if (!ctx->poly_want.on) { if (sel) *sel = nullptr; return &it->second.plain; }
+    if (!it->second.poly_valid || !same_spec(it->second.spec, ctx->poly_want)) return nullptr;
+    if (sel) *sel = &it->second.sel;
+    return &it->second.poly;
+}
+static pb_ctx::BodyFlags flags_of(const std::vector<pb_fft_sel> &h) {
+    pb_ctx::BodyFlags f;
+    for (const pb_fft_sel &e : h) {
+        if (e.use_fft) { f.any_fft = true; if (!e.poly) f.any_fft3 = true; }
+        else { f.any_other = true; if (e.strip) f.any_strip = true; else f.any_tile = true; }
+    }
+    return f;
+}
+
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     ConvPass p = p0;
     bool fft = ctx->fft_min_phases >= 0 && !p.no_fft && fft_pass_ok(p);
     const int B = p.P / p.C;
-    const auto known = ctx->rec_cache.find(p.info);
-    const bool have = known != ctx->rec_cache.end() && known->second.B == B;
-    if (fft && have && !known->second.any_fft) fft = false;
+    const std::vector<pb_fft_sel> *ksel = nullptr;
+    const pb_ctx::BodyFlags *kf = known_flags(ctx, p.info, B, &ksel);
+    const bool have = kf != nullptr;
+    // (a step of a polynomial whose one-pass images another launch does: only the images that go step by step count)
+    if (fft && have && !(ctx->poly_want.on && p.poly == 0 ? kf->any_fft3 : kf->any_fft)) fft = false;
     p.fsel = nullptr; p.khat = nullptr;
-    if (fft) {
+    if (fft || (have && ctx->poly_want.on)) {
         float *k = nullptr; pb_fft_sel *s = nullptr;
         // (spectra an earlier pass built count only while the scratch still holds them for these records)
-        const bool built = (p.khat_ready || have || ctx->khat_by_estimate || ctx->poly_mode == 1) && ctx->khat_owner == p.info;   // (pb_build_khat also rebuilds spectra of another PolySpec)
+        const bool built = (p.khat_ready || have || ctx->khat_by_estimate) && ctx->khat_owner == p.info && ctx->khat_B == B;   // (pb_build_khat also rebuilds spectra of another PolySpec)
         const int rc = pb_build_khat(ctx, p.info, B, &k, &s, !built);
         if (rc) return rc;
-        p.khat = k; p.fsel = s;
+        p.khat = k; p.fsel = s;      // (the stencil bodies read the selection too: they skip the one-pass images)
     } else if (!p.khat_ready && !have) {
-        ctx->khat_owner = nullptr;      // device-built records took a pass without spectra: whatever the scratch holds is not theirs
+        ctx->khat_owner = nullptr; ctx->khat_B = 0;     // device-built records took a pass without spectra: whatever the scratch holds is not theirs
     }
     // rank-1 kernels of full support on fp32 planes: the streaming strip body (host-built records only: with device-built
     // ones it would be one more launch that usually finds no work)
-    const bool strip = ctx->strip_mode && have && known->second.any_strip && p.in_dtype == PB_F32 && p.x_dtype == PB_F32 &&
+    const bool strip = ctx->strip_mode && have && kf->any_strip && p.in_dtype == PB_F32 && p.x_dtype == PB_F32 &&
                        p.out_dtype == PB_F32 && p.epilogue == EPI_HORNER && p.pad == PB_KRAD && !p.skip_sep;
     bool strip_done = false;
     if (strip) {
@@ -366,17 +388,48 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
         else if (rc != PB_ERR_UNSUPPORTED) return rc;
         else p.strip = 0;
     }
-    const bool tile_needed = !have || (strip_done ? known->second.any_tile : known->second.any_other);
-    if (tile_needed && !(fft && have && !known->second.any_other)) {
+    const bool tile_needed = !have || (strip_done ? kf->any_tile : kf->any_other);
+    if (tile_needed) {
         const int rc = launch_stencil(ctx, p);
         if (rc) return rc;
     }
     if (!fft) return PB_OK;
+    ctx->known_sel = ksel;
+    const int rc = launch_tile_spectrum(ctx, p);
+    ctx->known_sel = nullptr;
+    return rc;
+}
+
+// the tile-spectrum launch of a pass: the wave form where it is built and worth it, else the workgroup form -- which cannot
+// run one-pass images whose composite halo is beyond its classes (PolySpec.on == 2 is only asked for where the wave form
+// takes every launch, pb_poly_spec)
+static int launch_tile_spectrum(pb_ctx *ctx, const ConvPass &p) {
     if (ctx->fft_wave) {
         const int rc = pb_launch_conv_wfft(ctx, p);
         if (rc != PB_ERR_UNSUPPORTED) return rc;
     }
+    if (p.poly != 0 && ctx->poly_built.on == 2)
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "one-pass polynomial with per-axis halos: the wave form does not take this pass");
     return pb_launch_conv_fft(ctx, p);
+}
+
+// Which one-pass form a polynomial with these steps may ask for (PolySpec.on): 2 = the composite filter's own halos, where
+// every tile-spectrum launch of the polynomial goes to the wave form (conv_wfft.hip: fp32 / fp16 planes); 1 = kernels
+// within the 4-sample halo class only (either form); 0 = never (ctx->poly_mode == 0, or a step the form does not suit).
+int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
+    if (ctx->poly_mode == 0 || ctx->fft_min_phases < 0) return 0;
+    for (int s = 0; s < 3; ++s)
+        if (steps[s].boundary != PB_WRAP || steps[s].epilogue != EPI_HORNER || !fft_pass_ok(steps[s])) return 0;
+    if (steps[0].in_kind != SRC_VIRTUAL) return 0;      // (after an edgetaper the x operand is a padded plane: three steps)
+    // who runs the one pass: the first step's launch where it stores the type the last step stores (ConvPass.poly = 2), else
+    // a composite launch from the first step's input to the last step's output -- whose types must be built
+    ConvPass pc = steps[0];
+    pc.out_dtype = steps[2].out_dtype;
+    const bool fold = steps[0].out_dtype == steps[2].out_dtype;
+    bool wave = ctx->poly_mode != 1 && ctx->fft_wave && (fold || pb_conv_wfft_types(pc));
+    for (int s = 0; s < 3; ++s) wave = wave && pb_conv_wfft_types(steps[s]);
+    if (wave) return 2;
+    return (fold || pb_conv_fft_types(pc)) ? 1 : 0;
 }
 
 // The three Horner steps of one polynomial.  Whether the tile-spectrum body may be used is decided ONCE, from all three
@@ -392,8 +445,24 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     bool fft = ctx->fft_min_phases >= 0;
     for (int s = 0; s < 3; ++s) fft = fft && fft_pass_ok(steps[s]);
     const int B = steps[0].P / steps[0].C;
-    const auto known = ctx->rec_cache.find(steps[0].info);
-    const bool have = known != ctx->rec_cache.end() && known->second.B == B;
+    // Records the host built (pb_make_kernels / pb_set_kernels) meeting a one-pass spec for the first time: the spectra of
+    // that spec are built and the device's choice read back now -- one synchronisation per record set and spec -- so that
+    // every later polynomial on them issues exactly the launches it needs, with job grids of exactly the size it needs.
+    {
+        const auto known = ctx->rec_cache.find(steps[0].info);
+        if (fft && ctx->poly_want.on && known != ctx->rec_cache.end() && known->second.B == B &&
+            !(known->second.poly_valid && same_spec(known->second.spec, ctx->poly_want))) {
+            float *k0 = nullptr; pb_fft_sel *s0 = nullptr;
+            int rc0 = pb_build_khat(ctx, steps[0].info, B, &k0, &s0, true);
+            if (rc0) return rc0;
+            std::vector<pb_fft_sel> h((size_t)B);
+            PB_HIP(hipMemcpyAsync(h.data(), s0, sizeof(pb_fft_sel) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+            PB_HIP(hipStreamSynchronize(ctx->stream));
+            pb_ctx::RecFlags &rf = known->second;
+            rf.poly_valid = true; rf.spec = ctx->poly_want; rf.poly = flags_of(h); rf.sel = h;
+        }
+    }
+    const bool have = known_flags(ctx, steps[0].info, B) != nullptr;
     // (per-launch profiling keeps everything on one stream: events on the side stream would time its launches' wait
     // behind the other kernel's workgroups, not their work)
     // One-pass polynomial: the images whose spectrum is the polynomial's take ONE window pass from the first step's input
@@ -416,9 +485,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
         pc.scale = 1.f; pc.coef = 0.f; pc.clamp01 = steps[2].clamp01; pc.poly = 1;
         pc.khat = k; pc.fsel = sel;
         if (!fft_pass_ok(pc)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "one-pass polynomial: composite pass not feasible");
-        int rc = ctx->fft_wave ? pb_launch_conv_wfft(ctx, pc) : PB_ERR_UNSUPPORTED;
-        if (rc == PB_ERR_UNSUPPORTED) rc = pb_launch_conv_fft(ctx, pc);
-        return rc;
+        return launch_tile_spectrum(ctx, pc);
     };
     if (!fft || have || !ctx->aux || ctx->prof_on) {
         for (int s = 0; s < 3; ++s) {
@@ -429,7 +496,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
             const int rc = pb_launch_conv(ctx, p);
             if (rc) return rc;
         }
-        if (poly_on && !fold && ctx->poly_built.on && ctx->khat_owner == steps[0].info) {
+        if (poly_on && !fold && ctx->poly_built.on && ctx->khat_owner == steps[0].info && ctx->khat_B == B) {
             float *k = nullptr; pb_fft_sel *sel = nullptr;
             const int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, false);
             if (rc) return rc;
@@ -439,7 +506,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     }
     float *k = nullptr; pb_fft_sel *sel = nullptr;
     // (records the estimation has just built bring their spectra with them: blur_params_kernel ends with them)
-    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !((ctx->khat_by_estimate || ctx->poly_mode == 1) && ctx->khat_owner == steps[0].info));
+    int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !(ctx->khat_by_estimate && ctx->khat_owner == steps[0].info && ctx->khat_B == B));
     if (rc) return rc;
     PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
@@ -453,15 +520,13 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
         rc = launch_stencil(ctx, p);
     }
     ctx->stream = main_stream;
-    if (rc) return rc;
+    // (whatever was queued on the side stream is joined on every path out of here: later calls share the scratch planes)
     PB_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 3 && !rc; ++s) {
         ConvPass p = steps[s];
         p.khat = k; p.fsel = sel;
         if (s == 0) first_step(p);
-        rc = ctx->fft_wave ? pb_launch_conv_wfft(ctx, p) : PB_ERR_UNSUPPORTED;
-        if (rc == PB_ERR_UNSUPPORTED) rc = pb_launch_conv_fft(ctx, p);
-        if (rc) break;
+        rc = launch_tile_spectrum(ctx, p);
     }
     PB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return rc;
@@ -472,18 +537,14 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B) {
     pb_forget_records(ctx, info, B);
     if (ctx->fft_min_phases < 0) return PB_OK;
-    if (ctx->poly_mode == 1) return PB_OK;      // (PB_POLY1=1: which body an image takes depends on the pass; nothing is cached)
     float *k = nullptr; pb_fft_sel *s = nullptr;
     int rc = pb_build_khat(ctx, info, B, &k, &s, true);
     if (rc) return rc;
     std::vector<pb_fft_sel> h(B);
     PB_HIP(hipMemcpyAsync(h.data(), s, sizeof(pb_fft_sel) * B, hipMemcpyDeviceToHost, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
-    pb_ctx::RecFlags f{B, false, false, false, false};
-    for (const pb_fft_sel &e : h) {
-        if (e.use_fft) f.any_fft = true;
-        else { f.any_other = true; if (e.strip) f.any_strip = true; else f.any_tile = true; }
-    }
+    pb_ctx::RecFlags f;
+    f.B = B; f.plain = flags_of(h); f.poly_valid = false; f.spec = no_poly();
     ctx->rec_cache[info] = f;
     return PB_OK;
 }
@@ -493,7 +554,7 @@ void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes) {
     for (auto it = ctx->rec_cache.begin(); it != ctx->rec_cache.end();) {
         const char *a = static_cast<const char *>(it->first), *b = a + sizeof(pb_blur_info) * (size_t)it->second.B;
         if (a < hi && lo < b) {
-            if (ctx->khat_owner == it->first) { ctx->khat_owner = nullptr; ctx->khat_by_estimate = false; }
+            if (ctx->khat_owner == it->first) { ctx->khat_owner = nullptr; ctx->khat_B = 0; ctx->khat_by_estimate = false; }
             it = ctx->rec_cache.erase(it);
         } else ++it;
     }
@@ -503,11 +564,14 @@ void pb_forget_records(pb_ctx *ctx, const void *info, int B) {
         pb_forget_range(ctx, info, sizeof(pb_blur_info) * (size_t)B);
         // (device-built records are not in the cache, but the spectra scratch may be theirs)
         const char *a = static_cast<const char *>(info), *b = a + sizeof(pb_blur_info) * (size_t)B, *o = static_cast<const char *>(ctx->khat_owner);
-        if (o && o >= a && o < b) { ctx->khat_owner = nullptr; ctx->khat_by_estimate = false; }
+        // (spectra of a run of records that overlaps the rewritten ones anywhere, not only at its first record)
+        const char *oe = o ? o + sizeof(pb_blur_info) * (size_t)ctx->khat_B : nullptr;
+        if (o && o < b && a < oe) { ctx->khat_owner = nullptr; ctx->khat_B = 0; ctx->khat_by_estimate = false; }
         return;
     }
     ctx->rec_cache.clear();
     ctx->khat_owner = nullptr;
+    ctx->khat_B = 0;
     ctx->khat_by_estimate = false;
 }
 

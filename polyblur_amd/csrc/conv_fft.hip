@@ -305,6 +305,7 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, co
     if (!sel->use_fft) return;                                  // a stencil body of conv_tile_kernel does this image
     if (!poly_match(a.poly, sel->poly)) return;                 // (one-pass polynomial: see ConvPass.poly)
     const int R = sel->rf, c = (R >> 2) - 1;
+    if (R == 0) return;                                         // (a one-pass image with halos of the wave form only: never routed here)
     // This XCD's run of the plane has per <= slots pairs.  They are dealt to the slots evenly -- slot i takes pair
     // floor(i per / slots) when that differs from its successor's -- so that the idle workgroups of an image with larger
     // tiles are sprinkled between the working ones (a run of idle workgroups in front of the next plane's would drain
@@ -337,7 +338,7 @@ int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel) {
     float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat", sizeof(float) * FT_N * FT_N * (size_t)B));
     pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel", sizeof(pb_fft_sel) * (size_t)B));
     if (!k || !s) return PB_ERR_NOMEM;
-    if (k != ctx->khat_buf) { ctx->khat_buf = k; ctx->khat_owner = nullptr; ctx->khat_by_estimate = false; }   // (the scratch buffer was reallocated)
+    if (k != ctx->khat_buf) { ctx->khat_buf = k; ctx->khat_owner = nullptr; ctx->khat_B = 0; ctx->khat_by_estimate = false; }   // (the scratch buffer was reallocated)
     *khat = k; *sel = s;
     return PB_OK;
 }
@@ -346,9 +347,10 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
     float *k = nullptr; pb_fft_sel *s = nullptr;
     const int rcb = pb_khat_buffers(ctx, B, &k, &s);
     if (rcb) return rcb;
-    if (!ctx->khat_owner || !same_spec(ctx->poly_built, ctx->poly_want)) launch = true;   // (spectra of the kernel vs of the whole polynomial)
+    // (spectra of other records, of fewer records than this pass covers, or of the kernel where the pass wants the polynomial's)
+    if (!ctx->khat_owner || ctx->khat_owner != info || ctx->khat_B != B || !same_spec(ctx->poly_built, ctx->poly_want)) launch = true;
     if (launch) {
-        ctx->khat_owner = info; ctx->khat_by_estimate = false; ctx->poly_built = ctx->poly_want;
+        ctx->khat_owner = info; ctx->khat_B = B; ctx->khat_by_estimate = false; ctx->poly_built = ctx->poly_want;
         ProfScope prof(ctx, PB_PROF_PARAMS);
         hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases,
                            ctx->poly_want);
@@ -359,6 +361,13 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
 }
 
 bool pb_conv_fft_feasible(const ConvPass &p) { FftGeom g; return fft_geometry(p, g); }
+
+bool pb_conv_fft_types(const ConvPass &p) {
+    switch (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype) {
+        case 0: case 1: case 3: case 4: case 9: case 10: case 12: case 13: case 24: case 6: case 8: case 2: return true;
+        default: return false;
+    }
+}
 
 int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p) {
     ProfScope prof(ctx, PB_PROF_CONV_FFT);

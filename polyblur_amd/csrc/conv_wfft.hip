@@ -44,12 +44,6 @@
 
 namespace {
 
-// timing-only ablations (wrong results; PB_EXTRA_FLAGS=-DPB_ABL=bits): 1 no window loads, 2 no spectrum DMA, 4 no x loads /
-// stores, 8 no transposes, 16 no butterflies
-#ifndef PB_ABL
-#define PB_ABL 0
-#endif
-
 constexpr int WF_ROWS = 32;                          // LDS tile rows per wave (half a window pair)
 constexpr size_t kWfLdsWave = sizeof(float2) * WF_ROWS * FT_P;
 
@@ -86,8 +80,8 @@ static __device__ const float kS64[64] = {
 // register 8 k1 + k2 of the transformed line holds frequency k1 + 8 k2 -- the order khat_kernel lays the spectrum out
 // in -- and the inverse runs the mirrored stages, so nothing is ever reordered.  Unnormalised (khat carries 1/4096).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bf8(cf (&v)[8]) { if constexpr (!(PB_ABL & 16)) pbfft::dft_small<8>(v); }
-__device__ __forceinline__ void ibf8(cf (&v)[8]) { if constexpr (!(PB_ABL & 16)) idft8(v); }
+__device__ __forceinline__ void bf8(cf (&v)[8]) { pbfft::dft_small<8>(v); }
+__device__ __forceinline__ void ibf8(cf (&v)[8]) { idft8(v); }
 // forward stage 1 of group n2: registers 8 n1 + n2 over n1, then x W64^(n2 k1)
 template <int N2> __device__ __forceinline__ void fwd_stage1(cf (&v)[64]) {
     cf a[8];
@@ -122,13 +116,13 @@ template <int K1> __device__ __forceinline__ void inv_stage2(cf (&v)[64]) {
     }
 }
 // the two of them around the product with the real spectrum (group k1 of a transformed row)
-template <int K1> __device__ __forceinline__ void centre_stage(cf (&v)[64], const float (&kh)[64]) {
+template <int K1> __device__ __forceinline__ void centre_stage(cf (&v)[64], const float (&kh)[8]) {
     cf b[8];
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) b[n2] = v[8 * K1 + n2];
     bf8(b);
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) b[k2] = b[k2] * kh[8 * K1 + k2];
+    for (int k2 = 0; k2 < 8; ++k2) b[k2] = b[k2] * kh[k2];
     ibf8(b);
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) {
@@ -159,11 +153,6 @@ __device__ __forceinline__ void fft64_fwd_stage1(cf (&v)[64]) {
     PB_EACH8(PB_S)
 #undef PB_S
 }
-__device__ __forceinline__ void fft64_centre(cf (&v)[64], const float (&kh)[64]) {
-#define PB_S(i) centre_stage<i>(v, kh);
-    PB_EACH8(PB_S)
-#undef PB_S
-}
 __device__ __forceinline__ void fft64_inv_stage1(cf (&v)[64]) {
 #define PB_S(i) inv_stage1<i>(v);
     PB_EACH8(PB_S)
@@ -191,7 +180,6 @@ __device__ __forceinline__ void swap_halves(cf &hi_part, cf &lo_part) {
 // (register 8 n1 + n2, n2-major).  Row pitch 65 complex values: the writes (consecutive lanes, consecutive 8-byte
 // words) and the reads (lane i reads word 65 i + c: 32 different banks pairs per half wave) are conflict-free.
 __device__ __forceinline__ void transpose64(cf (&v)[64], float2 *Z, int lane) {
-    if constexpr (PB_ABL & 8) return;
 #pragma unroll
     for (int r = 0; r < 32; ++r) swap_halves(v[r], v[32 + r]);
     const float2 *rd = Z + (lane & 31) * FT_P + (lane & 32);
@@ -206,11 +194,22 @@ __device__ __forceinline__ void transpose64(cf (&v)[64], float2 *Z, int lane) {
     }
 }
 
-// Geometry of a pass, per window halo class (index R / 4 - 1), computed on the host.
-struct WGeom {
-    int pairs_x[3], njobs[3], per[3];       // window pairs per row, per plane, per plane and XCD
-    float inv_pairs_x[3], inv_per[3];
-};
+// Output extent of a pass; the window counts follow from each image's halos on the device (the wave form's halos are per
+// axis -- hx a multiple of 4, hy even -- and the host never learns them).
+struct WGeom { int ow, oh; };
+struct WJobs { int pairs_x, njobs, per; float inv_pairs_x; };      // of one image: window pairs per row, per plane, per plane and XCD
+// n / d for 0 <= n < 2^21 with the hardware's reciprocal (1 ulp): exact -- (n + 1/2) / d is at least 1 / (2 d) away from an integer
+__device__ __forceinline__ int div_rcp(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
+__device__ __forceinline__ WJobs jobs_of(const WGeom &g, int hx, int hy) {
+    const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
+    const int tiles_x = div_rcp(g.ow + Tx - 1, __builtin_amdgcn_rcpf((float)Tx)), tiles_y = div_rcp(g.oh + Ty - 1, __builtin_amdgcn_rcpf((float)Ty));
+    WJobs j;
+    j.pairs_x = (tiles_x + 1) >> 1;
+    j.njobs = j.pairs_x * tiles_y;
+    j.per = (j.njobs + 7) >> 3;
+    j.inv_pairs_x = __builtin_amdgcn_rcpf((float)j.pairs_x);
+    return j;
+}
 
 // inclusive prefix sum over the wave
 __device__ __forceinline__ int wave_scan(int x, int lane) {
@@ -223,16 +222,13 @@ __device__ __forceinline__ int wave_scan(int x, int lane) {
 }
 
 #ifdef PB_WF_TRACE
-// Debug build only (python -m polyblur_amd.build with PB_EXTRA_FLAGS=-DPB_WF_TRACE): shader-clock stamps of the first
-// waves' phases, read back with pb_debug_wf_trace (tools/wf_trace.py).
+// Debug build only (python -m polyblur_amd.build --experimental with PB_EXTRA_FLAGS=-DPB_WF_TRACE): shader-clock stamps of the
+// first waves' phases, read back with pb_debug_wf_trace (tools/wf_trace.py).
 constexpr int kTraceWaves = 8192, kTraceStamps = 14;
 __device__ unsigned long long g_wf_trace[kTraceWaves * kTraceStamps];
 #define PB_T(i) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define PB_TWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define PB_TRT(i) do { if (tr) tr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-// per wave: up to kJobSlots jobs x {taken, done (100 MHz ticks), step << 28 | pair}
-constexpr int kJobWaves = 2048, kJobSlots = 40;
-__device__ unsigned long long g_wf_jobs[kJobWaves * kJobSlots * 3];
 #else
 #define PB_T(i)
 #define PB_TWAIT()
@@ -292,18 +288,39 @@ template <> struct Piece4<__half> {
     }
 };
 
+template <> struct Piece4<unsigned char> {
+    typedef unsigned raw;
+    static __device__ __forceinline__ raw ld(brsrc r, unsigned vo, int so) { return __builtin_amdgcn_raw_buffer_load_b32(r, (int)vo, so, 0); }
+    static __device__ __forceinline__ f4v to_f(raw u) {
+        return (f4v){pb_from_ubyte(u & 255u), pb_from_ubyte((u >> 8) & 255u), pb_from_ubyte((u >> 16) & 255u), pb_from_ubyte(u >> 24)};
+    }
+    static __device__ __forceinline__ void st(brsrc r, unsigned vo, int so, f4v v) {
+        const unsigned u = pb_to_ubyte(v.x) | (pb_to_ubyte(v.y) << 8) | (pb_to_ubyte(v.z) << 16) | (pb_to_ubyte(v.w) << 24);
+        __builtin_amdgcn_raw_buffer_store_b32(u, r, (int)vo, so, 0);
+    }
+};
+
 // One window pair.  zb: the wave's LDS region (kWfLdsWave bytes); kp: the image's spectrum, [x position][y position].
-template <int R, bool FAST, typename TIn, typename TX, typename TOut>
-__device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, char *zb,
-                                          const float *kp, unsigned long long *tr) {
-    constexpr int T = FT_N - 2 * R;
+// hx, hy: the window halo along x (a multiple of 4: windows stay on 16-byte boundaries) and along y (even); a tile is
+// Tx = 64 - 2 hx by Ty = 64 - 2 hy outputs.
+//
+// Rows are ROTATED in the registers: register r holds window row (r + hy) mod 64 -- the tile's rows sit in registers
+// 0 .. Ty - 1, the hy halo rows above it in registers 64 - hy .. 63.  A circular correlation commutes with a circular
+// shift of its input, so the transforms do not notice, and the epilogue walks registers 0 .. Ty - 1 whatever hy is: the row
+// halo is a run-time value (every row offset is scalar work); only register numbers have to be compile-time constants.
+// Columns are lanes: their halo is a per-lane predicate.
+template <bool FAST, typename TIn, typename TX, typename TOut>
+__device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, int hx, int hy,
+                                          char *zb, const float *kp, unsigned long long *tr) {
+    const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
     PB_T(1);
     float2 *Z = reinterpret_cast<float2 *>(zb);
     float *Zf = reinterpret_cast<float *>(zb);
     const OutRegion rg = out_region(a);
-    const int wy0 = rg.y_lo + ty * T - R;                       // window origin, padded coordinates
-    const int wxA = rg.x_lo + 2 * pxi * T - R, wxB = wxA + T;
-    const bool hasB = wxB + R < rg.x_hi;
+    const int oy0 = rg.y_lo + ty * Ty;                              // the tile's first row, padded coordinates
+    const int wxA = rg.x_lo + 2 * pxi * Tx - hx, wxB = wxA + Tx;    // window origins along x
+    const int wrap_r = FT_N - hy;                                   // registers wrap_r .. 63 hold the rows above the tile
+    const bool hasB = wxB + hx < rg.x_hi;
     const int lane = threadIdx.x & 63;
     const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
     const TX *xpl = static_cast<const TX *>(a.x) + (long)plane * a.x_plane;
@@ -311,66 +328,114 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
     const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
     cf v[64];
 
-    // ---- the window: lane = column, register = row ----
+    // ---- the window: lane = column, register = (rotated) row ----
     {
         const brsrc rin = plane_rsrc(ipl, a.in_plane);
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
-        const unsigned pitchb = (unsigned)a.in_pitch * (unsigned)sizeof(TIn);
-        if constexpr (FAST && (PB_ABL & 1)) {
-#pragma unroll
-            for (int y = 0; y < 64; ++y) v[y] = (cf){(float)(lane + y), (float)(lane - y)};
-        } else if constexpr (FAST) {
-            // Interior fp32 pair on 16-byte boundaries: the union of the two windows (64 + T columns) goes global -> LDS in
-            // 16-byte pieces (four-byte loads straight into the registers cost one vector memory instruction per row and
-            // tile, 128 per pair instead of 32: the pass was bound by their issue), LDS rows of 128 floats -- one wave
-            // instruction fills two of them --, sixteen rows at a time through two LDS buffers: chunk k holds the rows
-            // 8 n1 + 2k, 8 n1 + 2k + 1 of the first-stage groups n2 = 2k, 2k + 1, so the column transform starts on what
-            // has arrived while the rest is in flight, and every lane picks its column's two samples per row with one
-            // ds_read2_b32.  Two chunks are requested before the first is waited for and the next as soon as a buffer has
-            // been read: one memory latency per pair.
-            constexpr int C4 = (FT_N + T) / 4;
-            const int c = lane & 31;
-            // (lanes past the union's last piece repeat it rather than go out of range: see the note at dma16)
-            const unsigned vo = (unsigned)(lane >> 5) * pitchb + (unsigned)(wxA - lo + 4 * min(c, C4 - 1)) * 4u;
-            const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
+        const int pitchb = a.in_pitch * (int)sizeof(TIn);
+        const int wy0 = oy0 - hy;
+        // byte offset of register r's row in the source plane (windows inside the source only)
+        auto rowoff = [&](int r) -> int { return (oy0 - lo + r - (r >= wrap_r ? FT_N : 0)) * pitchb; };
+        if constexpr (FAST) {
+            // Interior fp32 pair on 16-byte boundaries: both windows go global -> LDS in 16-byte pieces (four-byte loads
+            // straight into the registers cost one vector memory instruction per row and window, 128 per pair instead of 32:
+            // the pass was bound by their issue).  An LDS row is 128 floats: pieces 0 .. 15 = window A's 64 columns, 16 .. 31
+            // = window B's (the 2 hx columns the two share in memory are fetched twice -- the same cache lines, and B's
+            // samples sit at a fixed distance from A's whatever the halo), one wave instruction fills two rows, sixteen rows at
+            // a time through two LDS buffers: chunk k holds the registers 8 n1 + 2k, 8 n1 + 2k + 1 of the first-stage groups
+            // n2 = 2k, 2k + 1, so the column transform starts on what has arrived while the rest is in flight, and every lane
+            // picks its column's two samples per row with one ds_read2_b32.  (hy is even: the two rows of an instruction
+            // never straddle the rotation's wrap.)  Two chunks are requested before the first is waited for and the next as
+            // soon as a buffer has been read: one memory latency per pair.
             lds_char *zl = lds_ptr(zb);
-            auto request = [&](int k, int buf) {
+            if constexpr (sizeof(TIn) == 4) {
+                const int c = lane & 31;
+                const unsigned vo = (unsigned)((lane >> 5) * pitchb + ((c < 16 ? wxA : wxB - FT_N) - lo + 4 * c) * 4);
+                auto request = [&](int k, int buf) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (int)(row0 + (unsigned)(8 * j + 2 * k) * pitchb));
-            };
-            // (the LDS reads are issued behind the compiler's back: it would make every read of either buffer wait for ALL
-            // outstanding LDS-DMA; the waits for the right chunk are placed by hand, and the wait that follows a chunk's
-            // reads names their destinations, so that nothing using them can be scheduled above it)
-            const unsigned la = lds_addr(zb) + (unsigned)lane * 4u;
-            auto pick = [&](int k, int buf) {
+                    for (int j = 0; j < 8; ++j) dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, rowoff(8 * j + 2 * k));
+                };
+                // (the LDS reads are issued behind the compiler's back: it would make every read of either buffer wait for ALL
+                // outstanding LDS-DMA; the waits for the right chunk are placed by hand, and the wait that follows a chunk's
+                // reads names their destinations, so that nothing using them can be scheduled above it)
+                const unsigned la = lds_addr(zb) + (unsigned)lane * 4u;
+                auto pick = [&](int k, int buf) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const unsigned ad = la + (unsigned)(buf * 8192 + j * 1024);
-                    asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(v[8 * j + 2 * k]) : "v"(ad), "n"(T));
-                    asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:%2" : "=v"(v[8 * j + 2 * k + 1]) : "v"(ad), "n"(128 + T));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[2 * k]), "+v"(v[2 * k + 1]), "+v"(v[8 + 2 * k]), "+v"(v[9 + 2 * k]), "+v"(v[16 + 2 * k]),
-                             "+v"(v[17 + 2 * k]), "+v"(v[24 + 2 * k]), "+v"(v[25 + 2 * k]), "+v"(v[32 + 2 * k]), "+v"(v[33 + 2 * k]), "+v"(v[40 + 2 * k]),
-                             "+v"(v[41 + 2 * k]), "+v"(v[48 + 2 * k]), "+v"(v[49 + 2 * k]), "+v"(v[56 + 2 * k]), "+v"(v[57 + 2 * k]) :: "memory");
-            };
-            request(0, 0); request(1, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            pick(0, 0);
-            request(2, 0);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            pick(1, 1);
-            request(3, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            pick(2, 0);
-            wait_vm0();
-            pick(3, 1);
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned ad = la + (unsigned)(buf * 8192 + j * 1024);
+                        asm volatile("ds_read2_b32 %0, %1 offset1:64" : "=v"(v[8 * j + 2 * k]) : "v"(ad));
+                        asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:192" : "=v"(v[8 * j + 2 * k + 1]) : "v"(ad));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[2 * k]), "+v"(v[2 * k + 1]), "+v"(v[8 + 2 * k]), "+v"(v[9 + 2 * k]), "+v"(v[16 + 2 * k]),
+                                 "+v"(v[17 + 2 * k]), "+v"(v[24 + 2 * k]), "+v"(v[25 + 2 * k]), "+v"(v[32 + 2 * k]), "+v"(v[33 + 2 * k]), "+v"(v[40 + 2 * k]),
+                                 "+v"(v[41 + 2 * k]), "+v"(v[48 + 2 * k]), "+v"(v[49 + 2 * k]), "+v"(v[56 + 2 * k]), "+v"(v[57 + 2 * k]) :: "memory");
+                };
+                request(0, 0); request(1, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(0, 0);
+                request(2, 0);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(1, 1);
+                request(3, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(2, 0);
+                wait_vm0();
+                pick(3, 1);
+            } else {
+                // fp16 window (the first step, or the one-pass polynomial, of an fp16 image): a 16-byte piece is eight samples
+                // and windows start on multiples of four, so each window is fetched from the 16-byte boundary at or before
+                // its first column -- nine pieces; pieces 0 .. 15 of an LDS row belong to window A, 16 .. 31 to window B, lanes
+                // past a window's ninth piece repeat it -- and every lane picks its two samples (two bytes each) at its
+                // window's offset from that boundary.  Same chunks, same waits.
+                const int c = lane & 31, cc = min(c & 15, 8);
+                const int eA = wxA - lo, eB = wxB - lo;             // first column of each window, in samples from the row start
+                const unsigned vo = (unsigned)((lane >> 5) * pitchb + (((c < 16 ? eA : eB) & ~7) + 8 * cc) * 2);
+                auto request = [&](int k, int buf) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, rowoff(8 * j + 2 * k));
+                };
+                const unsigned la = lds_addr(zb) + (unsigned)(((eA & 7) + lane) * 2), lb = lds_addr(zb) + 256u + (unsigned)(((eB & 7) + lane) * 2);
+                // (plain 16-bit reads, one register per sample: the d16 forms that fill half a register clear the other half
+                // on this hardware)
+                auto pick = [&](int k, int buf) {
+                    unsigned ra[16], rb[16];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned oa = la + (unsigned)(buf * 8192 + j * 1024), ob = lb + (unsigned)(buf * 8192 + j * 1024);
+                        asm volatile("ds_read_u16 %0, %1" : "=v"(ra[2 * j]) : "v"(oa));
+                        asm volatile("ds_read_u16 %0, %1" : "=v"(rb[2 * j]) : "v"(ob));
+                        asm volatile("ds_read_u16 %0, %1 offset:512" : "=v"(ra[2 * j + 1]) : "v"(oa));
+                        asm volatile("ds_read_u16 %0, %1 offset:512" : "=v"(rb[2 * j + 1]) : "v"(ob));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]),
+                                 "+v"(ra[7]), "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]),
+                                 "+v"(ra[15]) :: "memory");
+                    asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]), "+v"(rb[8]),
+                                 "+v"(rb[9]), "+v"(rb[10]), "+v"(rb[11]), "+v"(rb[12]), "+v"(rb[13]), "+v"(rb[14]), "+v"(rb[15]) :: "memory");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int r = 8 * (j >> 1) + 2 * k + (j & 1);
+                        v[r] = (cf){__half2float(__builtin_bit_cast(__half, (unsigned short)ra[j])), __half2float(__builtin_bit_cast(__half, (unsigned short)rb[j]))};
+                    }
+                };
+                request(0, 0); request(1, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(0, 0);
+                request(2, 0);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(1, 1);
+                request(3, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(2, 0);
+                wait_vm0();
+                pick(3, 1);
+            }
         } else if (wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB) {
-            const unsigned colA = (unsigned)(wxA - lo + lane) * (unsigned)sizeof(TIn), colB = colA + T * (unsigned)sizeof(TIn);
-            const unsigned row0 = (unsigned)(wy0 - lo) * pitchb;
+            const unsigned colA = (unsigned)(wxA - lo + lane) * (unsigned)sizeof(TIn), colB = colA + (unsigned)Tx * (unsigned)sizeof(TIn);
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
                 const int y = 8 * (q & 7) + (q >> 3);
-                const int so = (int)(row0 + (unsigned)y * pitchb);
+                const int so = rowoff(y);
                 v[y] = (cf){BufIO<TIn>::ld(rin, colA, so), BufIO<TIn>::ld(rin, colB, so)};
             }
         } else {
@@ -380,15 +445,15 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
             const unsigned colA = ixa >= 0 ? (unsigned)ixa * (unsigned)sizeof(TIn) : kNoAccess;
             const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
             const bool wrap = a.boundary == PB_WRAP;
-            const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(wy0, Hp)) : wy0;
+            const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp)) : oy0;
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
                 const int y = 8 * (q & 7) + (q >> 3);
-                int p = base + y;
-                if (wrap) { while (p >= Hp) p -= Hp; }
+                int p = base + y - (y >= wrap_r ? FT_N : 0);
+                if (wrap) { while (p < 0) p += Hp; while (p >= Hp) p -= Hp; }
                 const bool ok = wrap || (p >= 0 && p < Hp);
                 const int iy = ok ? (a.in_kind == SRC_VIRTUAL ? min(max(p - a.pad, 0), a.H - 1) : p) : 0;
-                const int so = (int)((unsigned)iy * pitchb);
+                const int so = iy * pitchb;
                 v[y] = (cf){BufIO<TIn>::ld(rin, ok ? colA : kNoAccess, so), BufIO<TIn>::ld(rin, ok ? colB : kNoAccess, so)};
             }
         }
@@ -403,127 +468,174 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         // for every px -- 64 coalesced requests that travel while the first row stage runs (through LDS they cost a
         // DMA pass, 64 LDS reads and the wait for both)
         const brsrc rk = plane_rsrc(kp, (long)FT_N * FT_N);
-        float kh[64];
+        // The 64 values travel in a ring of four groups of eight (the centre stage of group k1 multiplies by the values
+        // 8 k1 .. 8 k1 + 7): four groups are requested before the first row stage, group k1 + 4 when group k1 is done.  All 64
+        // at once -- 64 registers beside the window pair's 128 and the butterflies' -- leaves the scheduler short of
+        // registers: it then either sinks the requests into the centre stage seven at a time (every batch exposing an L2
+        // latency: 25 k cycles per pair for these two stages instead of 7 k) or spills.  The sched_barriers pin the
+        // requests (nothing is scheduled across them; with a mask that lets arithmetic pass, the requests sank all the same).
+        float kh[4][8];
+        auto khload = [&](int grp) {
 #pragma unroll
-        for (int p = 0; p < 64; ++p) {
-            if constexpr (PB_ABL & 2) kh[p] = 1.0f; else kh[p] = BufIO<float>::ld(rk, (unsigned)lane * 4u, p * (FT_N * 4));
-        }
+            for (int k2 = 0; k2 < 8; ++k2) kh[grp & 3][k2] = BufIO<float>::ld(rk, (unsigned)lane * 4u, (8 * grp + k2) * (FT_N * 4));
+        };
+        khload(0); khload(1); khload(2); khload(3);
+        __builtin_amdgcn_sched_barrier(0);
         fft64_fwd_stage1(v);                                    // rows
         PB_T(5);
-        fft64_centre(v, kh);                                    // stage 2, x spectrum, inverse stage 2
+        // stage 2, x spectrum, inverse stage 2
+        centre_stage<0>(v, kh[0]); khload(4); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<1>(v, kh[1]); khload(5); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<2>(v, kh[2]); khload(6); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<3>(v, kh[3]); khload(7); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<4>(v, kh[0]); centre_stage<5>(v, kh[1]); centre_stage<6>(v, kh[2]); centre_stage<7>(v, kh[3]);
     }
     fft64_inv_stage1(v);
     PB_T(6);
     transpose64(v, Z, lane);
     PB_T(7);
 
-    // ---- epilogue: lane = window column again ----
+    // ---- epilogue: lane = window column again, register r = tile row r ----
     const bool virt = a.x_kind == SRC_VIRTUAL;
     const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
     const int xmax = virt ? a.W - 1 : Wp - 1, ymax = virt ? a.H - 1 : Hp - 1, xsh = virt ? a.pad : 0;
-    const unsigned xpitchb = (unsigned)a.x_pitch * (unsigned)sizeof(TX), opitchb = (unsigned)a.out_pitch * (unsigned)sizeof(TOut);
+    const int xpitchb = a.x_pitch * (int)sizeof(TX), opitchb = a.out_pitch * (int)sizeof(TOut);
     const brsrc rx = plane_rsrc(xpl, a.x_plane);
     const brsrc ro = plane_rsrc(opl, a.out_plane);
-    const bool colin = lane >= R && lane < FT_N - R;
+    const bool colin = lane >= hx && lane < FT_N - hx;
     const float sc = a.scale, cfx = a.coef;
     const bool cl = a.clamp01 != 0;
-    const int oy0 = wy0 + R, oxA = wxA + R;
+    const bool taper = a.epilogue == EPI_TAPER;
+    const bool usex = taper || cfx != 0.f;                      // (the one-pass polynomial has no x operand: beta sits in its spectrum)
+    const int oxA = wxA + hx;
     if constexpr (FAST) {
-        // Complete interior pair, plain Horner epilogue, everything on 16-byte boundaries: the 2T-wide block of outputs goes
-        // through an LDS tile (written by columns, read back as 16-byte row pieces), NR rows at a time, so that the
-        // x operand arrives and the result leaves in 16-byte accesses: 2 NK vector memory instructions per NR rows instead
-        // of 4 NR.  The x operand of the round after next is requested when a round has been stored.
-                constexpr int NRND = R == 12 ? 2 : (R == 8 ? 3 : 4);
-        constexpr int NR = T / NRND, C = 2 * T / 4, NK = (NR * C + 63) / 64;
-        constexpr int PT = 2 * T;
-        static_assert(NR * NRND == T, "rounds must tile the rows");
-        typename Piece4<TX>::raw xq[2][NK];
-        constexpr unsigned XP = 4 * sizeof(TX), OP = 4 * sizeof(TOut);                 // bytes per piece of x / of the output
-        const int xso = (int)((unsigned)(oy0 - xsh) * xpitchb + (unsigned)(oxA - xsh) * (unsigned)sizeof(TX));
-        const int oso = (int)((unsigned)(oy0 - oo) * opitchb + (unsigned)(oxA - oo) * (unsigned)sizeof(TOut));
+        // Complete interior pair, plain Horner epilogue, everything on 16-byte boundaries: the 2 Tx-wide block of outputs goes
+        // through an LDS tile (written by columns, read back as 16-byte row pieces) so that the x operand arrives and the
+        // result leaves in 16-byte accesses: registers 0 .. 31 first, then 32 .. 63 (the tile holds 32 rows), each half read
+        // back in rounds of eight rows.  C pieces per row; lane -> (row of the round, piece) for each of the four vector
+        // memory instructions of a round.  The x operand travels four rounds ahead (memory latency under load is thousands
+        // of cycles).
+        //   The window pair never lives across a branch: everything up to the second half's writes is straight-line code and
+        // every vector memory operation is issued unconditionally (a piece that does not exist gets an out-of-range offset).
+        // With one branch per round the compiler shuffled forty register pairs per round between its blocks and -- it counts
+        // outstanding requests per path and assumes the fewest at a join -- waited for younger requests than the round needed;
+        // with the rounds in a switch, or a copy of the epilogue per kind of pass, it spilled a hundred registers around the
+        // last transform.  Only the rounds of the second half, when the pair is in LDS, are conditional.
+        const int C = Tx >> 1;
+        const float invC = __builtin_amdgcn_rcpf((float)C);
+        constexpr int XP = 4 * sizeof(TX), OP = 4 * sizeof(TOut);                 // bytes per piece of x / of the output
+        int rlk[4], chk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = 64 * k + lane;
+            rlk[k] = div_small(e, invC); chk[k] = e - rlk[k] * C;                 // (e < 256, C = 4 .. 28: exact)
+        }
+        const int xso = (oy0 - xsh) * xpitchb + (oxA - xsh) * (int)sizeof(TX);
+        const int oso = (oy0 - oo) * opitchb + (oxA - oo) * (int)sizeof(TOut);
+        typename Piece4<TX>::raw xq[4][4];
         auto request = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            if constexpr (q < NRND) {
+            const int left = Ty - 8 * q;                        // rows of this round inside the tile (<= 0: none)
 #pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const int e = 64 * k + lane, rl = e / C, ch = e - rl * C;
-                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * xpitchb + (unsigned)ch * XP : kNoAccess;
-                    xq[q & 1][k] = Piece4<TX>::ld(rx, vo, xso);
-                }
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = usex && rlk[k] < min(left, 8);
+                xq[q & 3][k] = Piece4<TX>::ld(rx, ok ? (unsigned)(rlk[k] * xpitchb + chk[k] * XP) : kNoAccess, xso + 8 * q * xpitchb);
             }
         };
+        // (the final clamp without a branch per piece: the bounds are infinite where the pass does not clamp)
+        const float clo = cl ? 0.f : -INFINITY, chi = cl ? 1.f : INFINITY;
         auto round = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            if constexpr (q < NRND) {
-                {
-                    // (halo lanes write to a scratch copy of the tile behind it rather than sit out under an exec mask)
-                    float *zt = Zf + (colin ? lane - R : NR * PT + lane);
+            const int left = Ty - 8 * q;
+            f4v acc[4];
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) { zt[i * PT] = v[R + q * NR + i].x; zt[i * PT + T] = v[R + q * NR + i].y; }
-                }
-                wave_lds_fence();
+            for (int k = 0; k < 4; ++k) acc[k] = *reinterpret_cast<const f4v *>(Zf + (8 * (q & 3) + min(rlk[k], 7)) * 128 + 4 * chk[k]);
 #pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const int e = 64 * k + lane, rl = e / C, ch = e - rl * C;
-                    const f4v acc = *reinterpret_cast<const f4v *>(Zf + min(rl, NR - 1) * PT + 4 * ch);
-                    const f4v x4 = Piece4<TX>::to_f(xq[q & 1][k]);
-                    f4v o;
-                    o.x = fmaf(sc, acc.x, cfx * x4.x); o.y = fmaf(sc, acc.y, cfx * x4.y);
-                    o.z = fmaf(sc, acc.z, cfx * x4.z); o.w = fmaf(sc, acc.w, cfx * x4.w);
-                    if (cl) {
-                        o.x = fminf(fmaxf(o.x, 0.f), 1.f); o.y = fminf(fmaxf(o.y, 0.f), 1.f);
-                        o.z = fminf(fmaxf(o.z, 0.f), 1.f); o.w = fminf(fmaxf(o.w, 0.f), 1.f);
-                    }
-                    const unsigned vo = rl < NR ? (unsigned)(rl + q * NR) * opitchb + (unsigned)ch * OP : kNoAccess;
-                    Piece4<TOut>::st(ro, vo, oso, o);
-                }
-                wave_lds_fence();
+            for (int k = 0; k < 4; ++k) {
+                const f4v x4 = Piece4<TX>::to_f(xq[q & 3][k]);
+                f4v o;
+                o.x = fmaf(sc, acc[k].x, cfx * x4.x); o.y = fmaf(sc, acc[k].y, cfx * x4.y);
+                o.z = fmaf(sc, acc[k].z, cfx * x4.z); o.w = fmaf(sc, acc[k].w, cfx * x4.w);
+                o.x = __builtin_amdgcn_fmed3f(o.x, clo, chi); o.y = __builtin_amdgcn_fmed3f(o.y, clo, chi);
+                o.z = __builtin_amdgcn_fmed3f(o.z, clo, chi); o.w = __builtin_amdgcn_fmed3f(o.w, clo, chi);
+                const bool ok = rlk[k] < min(left, 8);
+                Piece4<TOut>::st(ro, ok ? (unsigned)(rlk[k] * opitchb + chk[k] * OP) : kNoAccess, oso + 8 * q * opitchb, o);
+            }
+        };
+        float *zt = Zf + (lane - hx);
+        auto put_half = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            if (colin) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { zt[i * 128] = v[32 * h + i].x; zt[i * 128 + Tx] = v[32 * h + i].y; }
             }
         };
         typedef std::integral_constant<int, 0> Q0; typedef std::integral_constant<int, 1> Q1; typedef std::integral_constant<int, 2> Q2;
         typedef std::integral_constant<int, 3> Q3; typedef std::integral_constant<int, 4> Q4; typedef std::integral_constant<int, 5> Q5;
-        fft64_inv_stage2(v);                                    // columns
+        typedef std::integral_constant<int, 6> Q6; typedef std::integral_constant<int, 7> Q7;
+        // (sixteen registers a round of the x operand: one round's worth fits beside each stage of the last transform; the
+        // barriers keep the scheduler from hoisting the later requests into the transform)
         request(Q0{});
-        fft64_inv_stage1(v);
-        PB_T(8);
+        __builtin_amdgcn_sched_barrier(0);
+        fft64_inv_stage2(v);                                    // columns
+        __builtin_amdgcn_sched_barrier(0);
         request(Q1{});
-        round(Q0{}); request(Q2{});
-        round(Q1{}); request(Q3{});
-        round(Q2{}); request(Q4{});
-        round(Q3{}); request(Q5{});
+        __builtin_amdgcn_sched_barrier(0);
+        fft64_inv_stage1(v);
+        __builtin_amdgcn_sched_barrier(0);
+        PB_T(8);
+        put_half(Q0{});
+        request(Q2{}); request(Q3{});
+        wave_lds_fence();
+        round(Q0{}); request(Q4{});
+        round(Q1{}); request(Q5{});
+        round(Q2{}); request(Q6{});
+        round(Q3{}); request(Q7{});
+        wave_lds_fence();
+        put_half(Q1{});                                         // (behind the first half's reads: a wave's LDS operations execute in order)
+        wave_lds_fence();
+        if (Ty > 32) {
+            round(Q4{});
+            if (Ty > 40) {
+                round(Q5{});
+                if (Ty > 48) {
+                    round(Q6{});
+                    if (Ty > 56) round(Q7{});
+                }
+            }
+        }
         PB_T(9);
         PB_TWAIT();
         PB_T(10);
         PB_TRT(13);
         return;
     }
-    (void)oxA;
+    const int tyv = min(Ty, rg.y_hi - oy0);                     // rows of the tile inside the output region
     const int pxA = wxA + lane, pxB = wxB + lane;
     const bool okA = colin && pxA < rg.x_hi, okB = colin && hasB && pxB < rg.x_hi;
-    const unsigned xoffA = okA ? (unsigned)min(max(pxA - xsh, 0), xmax) * (unsigned)sizeof(TX) : kNoAccess;
-    const unsigned xoffB = okB ? (unsigned)min(max(pxB - xsh, 0), xmax) * (unsigned)sizeof(TX) : kNoAccess;
+    const unsigned xoffA = okA && usex ? (unsigned)min(max(pxA - xsh, 0), xmax) * (unsigned)sizeof(TX) : kNoAccess;
+    const unsigned xoffB = okB && usex ? (unsigned)min(max(pxB - xsh, 0), xmax) * (unsigned)sizeof(TX) : kNoAccess;
     const unsigned ooffA = okA ? (unsigned)(pxA - oo) * (unsigned)sizeof(TOut) : kNoAccess;
     const unsigned ooffB = okB ? (unsigned)(pxB - oo) * (unsigned)sizeof(TOut) : kNoAccess;
-    const bool taper = a.epilogue == EPI_TAPER;
     float txa = 0.f, txb = 0.f;
     if (taper) {
         txa = taper_weight(info->acorr_x, min(max(pxA, 0), Wp - 1), Wp);
         txb = taper_weight(info->acorr_x, min(max(pxB, 0), Wp - 1), Wp);
     }
-    // Border pairs, the taper blend, narrower types: the last transform's second stage finishes the window rows 8 n1 + n2
+    // Border pairs, the taper blend, narrower types: the last transform's second stage finishes the registers 8 n1 + n2
     // group by group (n2 = 0 .. 7); each group's rows go through the epilogue and to memory at once, and the x operand
-    // travels in a ring four groups deep -- the loads of group n2 + 4 are issued when group n2 has been stored.
+    // travels in a ring four groups deep -- the loads of group n2 + 4 are issued when group n2 has been stored.  (Rows
+    // outside the tile load and store at an out-of-range offset: nothing happens.)
     float xa[8][8], xb[8][8];
     auto request = [&](auto n2c) {
         constexpr int n2 = decltype(n2c)::value;
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
             const int y = 8 * n1 + n2;
-            if (y >= R && y < FT_N - R) {
-                const int xr = min(max(wy0 + y - xsh, 0), ymax);
-                const int so = (int)((unsigned)xr * xpitchb);
-                xa[n2][n1] = BufIO<TX>::ld(rx, xoffA, so); xb[n2][n1] = BufIO<TX>::ld(rx, xoffB, so);
-            }
+            const bool rok = y < tyv;
+            const int xr = min(max(oy0 + y - xsh, 0), ymax);
+            const int so = xr * xpitchb;
+            xa[n2][n1] = BufIO<TX>::ld(rx, rok ? xoffA : kNoAccess, so); xb[n2][n1] = BufIO<TX>::ld(rx, rok ? xoffB : kNoAccess, so);
         }
     };
     auto finish = [&](auto n2c) {
@@ -532,22 +644,19 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
             const int y = 8 * n1 + n2;
-            if (y >= R && y < FT_N - R) {
-                const int py = wy0 + y;
-                if (py < rg.y_hi) {
-                    float ra, rb;
-                    if (taper) {
-                        const float tyw = taper_weight(info->acorr_y, py, Hp);
-                        const float ala = tyw * txa, alb = tyw * txb;
-                        ra = ala * xa[n2][n1] + (1.f - ala) * v[y].x; rb = alb * xb[n2][n1] + (1.f - alb) * v[y].y;
-                    } else {
-                        ra = fmaf(sc, v[y].x, cfx * xa[n2][n1]); rb = fmaf(sc, v[y].y, cfx * xb[n2][n1]);
-                    }
-                    if (cl) { ra = fminf(fmaxf(ra, 0.f), 1.f); rb = fminf(fmaxf(rb, 0.f), 1.f); }
-                    const int so = (int)((unsigned)(py - oo) * opitchb);
-                    BufIO<TOut>::st(ro, ooffA, so, ra); BufIO<TOut>::st(ro, ooffB, so, rb);
-                }
+            const int py = oy0 + y;
+            const bool rok = y < tyv;
+            float ra, rb;
+            if (taper) {
+                const float tyw = taper_weight(info->acorr_y, min(py, Hp - 1), Hp);
+                const float ala = tyw * txa, alb = tyw * txb;
+                ra = ala * xa[n2][n1] + (1.f - ala) * v[y].x; rb = alb * xb[n2][n1] + (1.f - alb) * v[y].y;
+            } else {
+                ra = fmaf(sc, v[y].x, cfx * xa[n2][n1]); rb = fmaf(sc, v[y].y, cfx * xb[n2][n1]);
             }
+            if (cl) { ra = fminf(fmaxf(ra, 0.f), 1.f); rb = fminf(fmaxf(rb, 0.f), 1.f); }
+            const int so = (py - oo) * opitchb;
+            BufIO<TOut>::st(ro, rok ? ooffA : kNoAccess, so, ra); BufIO<TOut>::st(ro, rok ? ooffB : kNoAccess, so, rb);
         }
     };
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
@@ -567,48 +676,40 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
     PB_TRT(13);
 }
 
-// Whether a pair takes the all-16-byte path: fp32 everywhere, plain Horner epilogue, both windows inside the source
+// Whether a pair takes the all-16-byte path: an fp32 or fp16 window, plain Horner epilogue, both windows inside the source
 // without boundary mapping, both tiles complete inside the output region, the x operand addressed without clamping, and
 // rows / origins on 16-byte boundaries.
-template <int R, typename TIn, typename TX, typename TOut>
-__device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi) {
-    // (the window must be fp32 -- the planes between the steps always are; the x operand and the output may be fp16: four
-    // samples are then an 8-byte piece)
-    if (sizeof(TIn) != 4 || sizeof(TX) < 2 || sizeof(TOut) < 2 || a.epilogue != EPI_HORNER) return false;
-    constexpr int T = FT_N - 2 * R;
+template <typename TIn, typename TX, typename TOut>
+__device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi, int hx, int hy) {
+    // (the x operand and the output may be fp16: four samples are then an 8-byte piece)
+    if (sizeof(TIn) < 2 || a.epilogue != EPI_HORNER) return false;      // (an 8-bit window -- the first step of an 8-bit image -- is fetched sample by sample)
+    if (sizeof(TIn) == 2 && (a.in_pitch & 7) != 0) return false;      // (fp16 window: rows on 16-byte boundaries)
+    const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
     const OutRegion rg = out_region(a);
     const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
-    const int wy0 = rg.y_lo + ty * T - R, wxA = rg.x_lo + 2 * pxi * T - R, wxB = wxA + T;
+    const int oy0 = rg.y_lo + ty * Ty, wy0 = oy0 - hy, wxA = rg.x_lo + 2 * pxi * Tx - hx, wxB = wxA + Tx;
     const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
     const bool virt = a.x_kind == SRC_VIRTUAL;
     const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0, xsh = virt ? a.pad : 0;
     const int xw = virt ? a.W : Wp, xh = virt ? a.H : Hp;
-    const int oy0 = wy0 + R, oxA = wxA + R;
-    return wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && oy0 + T <= rg.y_hi && oxA + 2 * T <= rg.x_hi &&
-           oy0 - xsh >= 0 && oxA - xsh >= 0 && oy0 + T - xsh <= xh && oxA + 2 * T - xsh <= xw &&
+    const int oxA = wxA + hx;
+    return wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && oy0 + Ty <= rg.y_hi && oxA + 2 * Tx <= rg.x_hi &&
+           oy0 - xsh >= 0 && oxA - xsh >= 0 && oy0 + Ty - xsh <= xh && oxA + 2 * Tx - xsh <= xw &&
            ((a.in_pitch | a.x_pitch | a.out_pitch | (wxA - lo) | (oxA - xsh) | (oxA - oo)) & 3) == 0;
 }
 
 // One wave (= one workgroup) per window pair; the GRID is the job list.  The jobs are the window pairs of the images whose
-// record selects this body, every image with its own tile size (prefix sum over the batch's pb_fft_sel records: no host
-// read-back; the grid is sized for the smallest tile and the surplus workgroups leave at once).  Workgroup b belongs to
-// list b % 8 (the XCD it is observed to run on -- used for speed only) at position b / 8; every list owns the same eighth
-// of EVERY plane's pairs -- a contiguous run, so neighbouring windows share their halos in that XCD's L2 -- in the order
-// image, plane, pair.
+// record selects this body, every image with its own halos and therefore its own tile size (prefix sum over the batch's
+// pb_fft_sel records: no host read-back; the grid is sized for the smallest tile the records may select and the surplus
+// workgroups leave at once).  Workgroup b belongs to list b % 8 (the XCD it is observed to run on -- used for speed only)
+// at position b / 8; every list owns the same eighth of EVERY plane's pairs -- a contiguous run, so neighbouring windows
+// share their halos in that XCD's L2 -- in the order image, plane, pair.
 //
-// (Measured and dropped: the three Horner steps of a polynomial in ONE launch -- step-major lists, per-plane completion
-// counters, write-through stores for the planes a later step reads, one agent-scope acquire per pair -- once with
-// persistent waves taking pairs from queue heads in memory, once with the grid as the queue.  With every
-// synchronisation compiled out the single launch takes exactly what the three launches take, 254 us per 4K polynomial:
-// the launch tails it removes were not idle time, the waves that remain in a tail run faster; with the acquire and the
-// write-through stores in place 282 us.  The persistent form also cost 50 more spilled registers.
-//  Three waves per SIMD instead of two -- 168 registers per lane and 13 KiB of LDS per wave: the spectrum streamed from L2
-// eight values ahead, the window staged through a ring of three 8-row LDS buffers, the transposes through a 16-row tile
-// after a v_permlane16_swap level, the x operand three pieces per lane ahead -- was built, passed every test and ran at
-// 119 us per 4K pass against 85: with 40 registers beside the window pair nothing can be requested far enough ahead
-// (epilogue 30 k cycles per pair instead of 6 k, the centre stage 15.5 k instead of 4.8 k), twelve waves per CU queue
-// on the LDS (transposes 9 k cycles instead of 3.5 k) and the compiler still spilled 28 window rows per pair.  The 128
-// registers a wave has beside its window pair at two waves per SIMD are what hides this kernel's latencies.)
+// (Measured and dropped, round 3: the three Horner steps of a polynomial in ONE launch -- step-major lists, per-plane
+// completion counters, write-through stores, one agent-scope acquire per pair: with every synchronisation compiled out
+// the single launch takes exactly what the three launches take; three waves per SIMD instead of two -- 168 registers, the
+// spectrum streamed, a 16-row transpose tile: 119 us per 4K pass against 85, nothing can be requested far enough ahead.
+// NOTEBOOK.md has the records.)
 template <typename TIn, typename TX, typename TOut>
 __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
     extern __shared__ __attribute__((aligned(16))) char zb[];
@@ -622,13 +723,13 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     const int C = a.C, B = a.P / C;
     const int q = (int)(blockIdx.x & 7u);
     int rem = (int)(blockIdx.x >> 3);                  // position in the list
-    int img = 0, R = 0;
+    int img = 0, hx = 0, hy = 0;
     bool fold = false;
     if (B == 1) {
         // (one image: its record is read on the scalar side -- no trip through the vector memory queue)
         const PB_CONSTANT pb_fft_sel *s0 = as_constant(a.fsel);
         if (!s0->use_fft || !poly_match(a.poly, s0->poly)) return;
-        R = s0->rf;
+        hx = s0->hx; hy = s0->hy;
         fold = a.poly == 2 && s0->poly != 0;
     } else {
         // list entries of image i: its share of every plane
@@ -636,7 +737,7 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
             if (i >= B) return 0;
             const pb_fft_sel s = a.fsel[i];
             if (!s.use_fft || !poly_match(a.poly, s.poly)) return 0;
-            return (s.rf <= 4 ? g.per[0] : (s.rf <= 8 ? g.per[1] : g.per[2])) * C;
+            return jobs_of(g, s.hx, s.hy).per * C;
         };
         bool work = false;
         int base = 0;
@@ -654,43 +755,49 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
         }
         if (!work) return;
         img = __builtin_amdgcn_readfirstlane(img); rem = __builtin_amdgcn_readfirstlane(rem);
-        R = as_constant(a.fsel + img)->rf;
+        hx = as_constant(a.fsel + img)->hx; hy = as_constant(a.fsel + img)->hy;
         fold = a.poly == 2 && as_constant(a.fsel + img)->poly != 0;
     }
-    const int c = R <= 4 ? 0 : (R <= 8 ? 1 : 2);
-    const int pl = __builtin_amdgcn_readfirstlane(div_small(rem, g.inv_per[c]));
+    const WJobs j = jobs_of(g, hx, hy);
+    const int pl = __builtin_amdgcn_readfirstlane(div_rcp(rem, __builtin_amdgcn_rcpf((float)j.per)));
     if (pl >= C) return;                               // (one image: positions beyond its planes)
-    const int pair = q * g.per[c] + (rem - pl * g.per[c]);
-    if (pair >= g.njobs[c]) return;                    // (the ragged end of the last list's run)
-    const int ty = __builtin_amdgcn_readfirstlane(div_small(pair, g.inv_pairs_x[c])), pxi = pair - ty * g.pairs_x[c];
+    const int pair = q * j.per + (rem - pl * j.per);
+    if (pair >= j.njobs) return;                       // (the ragged end of the last list's run)
+    const int ty = __builtin_amdgcn_readfirstlane(div_rcp(pair, j.inv_pairs_x)), pxi = pair - ty * j.pairs_x;
     const int plane = img * C + pl;
     const float *kp = a.khat + (long)img * (FT_N * FT_N);
     const pb_blur_info *info = a.info + img;
     const ConvPass af = fold_pass(a, fold);
-#define PB_RUN(RR)                                                                                  \
-    if (pair_is_fast<RR, TIn, TX, TOut>(af, ty, pxi)) wave_pair<RR, true, TIn, TX, TOut>(af, info, plane, ty, pxi, zb, kp, tr); \
-    else wave_pair<RR, false, TIn, TX, TOut>(af, info, plane, ty, pxi, zb, kp, tr);
-    if (c == 2) { PB_RUN(12) } else if (c == 1) { PB_RUN(8) } else { PB_RUN(4) }
-#undef PB_RUN
+    if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<true, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
+    else wave_pair<false, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
 }
 
-bool wfft_geometry(const ConvPass &p, WGeom &g, long &total_max) {
-    FftGeom f;
-    if (!fft_geometry(p, f)) return false;
-    for (int c = 0; c < 3; ++c) {
-        g.pairs_x[c] = f.pairs_x[c]; g.njobs[c] = f.njobs[c]; g.per[c] = (f.njobs[c] + 7) / 8;
-        g.inv_pairs_x[c] = f.inv_pairs_x[c]; g.inv_per[c] = 1.0f / (float)g.per[c];
+// The output extent of a pass and the largest job list its records may ask for: `poly2` = the records may carry one-pass
+// images with the composite filter's halos (PolySpec.on == 2: tiles down to PB_POLY_MIN_TX x PB_POLY_MIN_TY, but never
+// smaller in area than the cost model of khat.h admits); otherwise halos are at most 12.  pairs12 = window pairs per plane at
+// the 12-sample halo.  (Counts stay below 2^20: the kernel divides with reciprocals.)
+bool wfft_geometry(const ConvPass &p, bool poly2, float min_area, WGeom &g, long &per_max, long &pairs12) {
+    g.oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * p.pad;
+    g.ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * p.pad;
+    per_max = 0; pairs12 = 0;
+    for (int hx = 4; hx <= 28; hx += 4) {
+        for (int hy = 2; hy <= 30; hy += 2) {
+            const int tx = FT_N - 2 * hx, ty = FT_N - 2 * hy;
+            const bool three = hx <= 12 && hy <= 12;
+            const bool one = poly2 && tx >= PB_POLY_MIN_TX && ty >= PB_POLY_MIN_TY && (float)(tx * ty) >= min_area;
+            if (!three && !one) continue;
+            const long nj = (long)(((g.ow + tx - 1) / tx + 1) / 2) * ((g.oh + ty - 1) / ty);
+            if (nj > (1L << 20)) return false;
+            per_max = std::max(per_max, (nj + 7) / 8);
+            if (hx == 12 && hy == 12) pairs12 = nj;
+        }
     }
-    total_max = (long)f.njobs[2] * p.P;
-    return total_max > 0 && total_max <= (1L << 22);
+    const long total = 8 * per_max * p.P;
+    return total > 0 && total <= (1L << 23);
 }
 
 template <typename TIn, typename TX, typename TOut>
-int launch_wfft_typed(pb_ctx *ctx, const ConvPass &p) {
-    WGeom g;
-    long total_max = 0;
-    if (!wfft_geometry(p, g, total_max)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: too many windows for the tile-spectrum body");
-    const long groups = 8L * g.per[2] * p.P;             // list entries if every image had the smallest tiles
+int launch_wfft_typed(pb_ctx *ctx, const ConvPass &p, const WGeom &g, long groups) {
     hipLaunchKernelGGL((conv_wfft_kernel<TIn, TX, TOut>), dim3((unsigned)groups), dim3(64), kWfLdsWave, ctx->stream, p, g);
     PB_LAUNCH_CHECK();
     return PB_OK;
@@ -704,40 +811,73 @@ extern "C" int pb_debug_wf_trace_clear(void) {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wf_trace)) != hipSuccess) return -1;
     return (int)hipMemset(p, 0, sizeof(unsigned long long) * kTraceStamps * kTraceWaves);
 }
-extern "C" int pb_debug_wf_jobs(unsigned long long *host, int clear) {
-    if (clear) {
-        void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wf_jobs)) != hipSuccess) return -1;
-        return (int)hipMemset(p, 0, sizeof(unsigned long long) * kJobWaves * kJobSlots * 3);
-    }
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wf_jobs), sizeof(unsigned long long) * kJobWaves * kJobSlots * 3);
-}
 extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
     if (n_waves > kTraceWaves) n_waves = kTraceWaves;
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wf_trace), sizeof(unsigned long long) * kTraceStamps * n_waves);
 }
 #endif
 
-// PB_ERR_UNSUPPORTED: dtype combination not built, or a pass so small that the workgroup form is the faster one (the caller
-// falls back to it).  A wave takes ~19 us for its pair whatever the size of the launch, a 512-thread workgroup ~8 us: a pass
-// whose pairs do not even fill the chip's 2048 wave slots once is a race of single pairs (700 x 500: 420 pairs, 0.31 ms per
-// call through the workgroup form against 0.38 ms), from about one and a half rounds on the wave form wins.
-int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
-    static const long min_jobs = [] { const char *e = getenv("PB_WAVE_MIN_JOBS"); return e ? atol(e) : 3000L; }();
-    {
-        WGeom g;
-        long total_max = 0;
-        if (wfft_geometry(p, g, total_max) && total_max < min_jobs) return PB_ERR_UNSUPPORTED;
-    }
-    ProfScope prof(ctx, PB_PROF_CONV_FFT);
-    // fp32 planes, and the second and third Horner step of fp16 images (fp32 temporaries in, fp16 x operand, fp32 or fp16
-    // out); the first step of an fp16 image -- its window is fp16 -- stays with the workgroup form (measured through this
-    // body's element-wise loader: 64 x 1080p fp16 37.96 / 37.89 ms per step against 38.03 / 38.13, 8K fp16 7.05 / 7.11
-    // against 7.03 / 7.11 -- equal, so the instantiation is not built)
+bool pb_conv_wfft_types(const ConvPass &p) {
     switch (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype) {
-        case 0: return launch_wfft_typed<float, float, float>(ctx, p);
-        case 3: return launch_wfft_typed<float, __half, float>(ctx, p);
-        case 4: return launch_wfft_typed<float, __half, __half>(ctx, p);
+        case 0: case 3: case 4: case 12: case 13: case 24: case 26: case 6: case 8: case 2: return true;
+        default: return false;
+    }
+}
+
+// PB_ERR_UNSUPPORTED: dtype combination not built (the caller falls back to the workgroup form).  Every pass whose types
+// are built comes here whatever its size, so that what an image gets does not depend on the batch it travels in (the two
+// forms round differently: this one rotates the window rows and has per-axis halos).  A wave takes ~19 us for its pair
+// whatever the size of the launch, a 512-thread workgroup ~8 us, so a three-step pass of a few hundred pairs is a race of
+// single pairs that the workgroup form used to win (700 x 500: 0.31 against 0.38 ms per call); with small images' polynomials
+// mostly one window pass now, the call is faster through this form alone (0.29 ms; 1080p 0.45 against 0.53).
+// PB_WAVE_MIN_JOBS=n in the environment sends passes of fewer than n pairs to the workgroup form again.
+int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
+    static const long min_jobs = [] { const char *e = getenv("PB_WAVE_MIN_JOBS"); return e ? atol(e) : 0L; }();
+    if (!pb_conv_wfft_types(p)) return PB_ERR_UNSUPPORTED;
+    const bool poly2 = p.poly != 0 && ctx->poly_built.on == 2;
+    // (the smallest tile area the cost model admits: three-step tiles are at least 40 x 40)
+    const float min_area = std::min(1600.f / (3.f * ctx->poly_gain), (float)ctx->poly_min_area);
+    WGeom g;
+    long per_max = 0, pairs12 = 0;
+    if (!wfft_geometry(p, poly2, min_area, g, per_max, pairs12)) {
+        if (poly2) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: too many windows for the tile-spectrum body");
+        return PB_ERR_UNSUPPORTED;
+    }
+    long jobs = pairs12 * p.P;
+    long groups = 8L * per_max * p.P;                       // list entries if every image had the smallest tiles its records may select
+    if (ctx->known_sel) {
+        // the host has the records' choices (it built them): the grid is exactly the list of this launch's jobs
+        const int B = p.P / p.C;
+        long per_sum = 0;
+        jobs = 0;
+        for (int b = 0; b < B && b < (int)ctx->known_sel->size(); ++b) {
+            const pb_fft_sel &e = (*ctx->known_sel)[(size_t)b];
+            const bool takes = e.use_fft && (p.poly == 2 || (e.poly != 0) == (p.poly != 0));      // (poly_match, conv_fft_common.h)
+            if (!takes) continue;
+            const int tx = FT_N - 2 * e.hx, ty = FT_N - 2 * e.hy;
+            const long nj = (long)(((g.ow + tx - 1) / tx + 1) / 2) * ((g.oh + ty - 1) / ty);
+            per_sum += (nj + 7) / 8; jobs += nj * p.C;
+        }
+        if (!jobs) return PB_OK;                            // nothing in this launch for any image
+        groups = 8L * per_sum * p.C;                        // (the kernel's list: the images' shares of every plane, back to back)
+    }
+    if (!poly2 && jobs < min_jobs) return PB_ERR_UNSUPPORTED;
+    ProfScope prof(ctx, PB_PROF_CONV_FFT);
+    // fp32 planes; the second and third Horner step of fp16 images (fp32 temporaries in, fp16 x operand, fp32 or fp16 out);
+    // the first step and the one-pass polynomial of fp16 images (fp16 window)
+    switch (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype) {
+        case 0: return launch_wfft_typed<float, float, float>(ctx, p, g, groups);
+        case 3: return launch_wfft_typed<float, __half, float>(ctx, p, g, groups);
+        case 4: return launch_wfft_typed<float, __half, __half>(ctx, p, g, groups);
+        case 12: return launch_wfft_typed<__half, __half, float>(ctx, p, g, groups);
+        case 13: return launch_wfft_typed<__half, __half, __half>(ctx, p, g, groups);
+        // 8-bit images: the first step (fp32 out) or the one-pass polynomial (fp32 or 8-bit out) from the 8-bit window, the
+        // later steps with the 8-bit x operand, the last store
+        case 24: return launch_wfft_typed<unsigned char, unsigned char, float>(ctx, p, g, groups);
+        case 26: return launch_wfft_typed<unsigned char, unsigned char, unsigned char>(ctx, p, g, groups);
+        case 6: return launch_wfft_typed<float, unsigned char, float>(ctx, p, g, groups);
+        case 8: return launch_wfft_typed<float, unsigned char, unsigned char>(ctx, p, g, groups);
+        case 2: return launch_wfft_typed<float, float, unsigned char>(ctx, p, g, groups);
         default: return PB_ERR_UNSUPPORTED;
     }
 }

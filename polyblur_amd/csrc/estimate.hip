@@ -1577,7 +1577,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
                        ctx->fft_min_phases, ctx->poly_want);
     PB_LAUNCH_CHECK();
-    if (khat) { ctx->khat_owner = dev_info; ctx->khat_by_estimate = true; ctx->poly_built = ctx->poly_want; }
+    if (khat) { ctx->khat_owner = dev_info; ctx->khat_B = B; ctx->khat_by_estimate = true; ctx->poly_built = ctx->poly_want; }
     return PB_OK;
 }
 

@@ -53,23 +53,38 @@ constexpr int KH_SLICES = 8;          // workgroups per image: each forms the sp
 // parameter kernel): no wait for the record's stores to land, no read back.
 struct RecLds { const float *taps; int radius, nph, separable; };
 
+// Smallest r with  sum_{|i - n| > r} m[i] < tol  for the 2n+1 non-negative values m[0 .. 2n] (n <= 63): one wave, lane l
+// holds the pair of offsets +-(63 - l), a prefix sum over the lanes is the tail beyond each offset.
+template <typename F> __device__ __forceinline__ int tail_radius(F m, int n, float tol, int lane) {
+    const int o = 63 - lane;
+    float v = (o >= 1 && o <= n) ? m(n - o) + m(n + o) : 0.f;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    const unsigned long long b = __ballot(v >= tol);
+    return b ? 63 - __builtin_ctzll(b) : 0;
+}
+
 // Called by all KH_THREADS threads of a workgroup: slice `slice` (0 .. KH_SLICES - 1) of the spectrum of `info`'s taps,
 // and (slice 0) the image's choice of body.  The record may have been written by this same workgroup just before (global
 // memory, then a barrier): it is read through the vector path.
 __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, pb_fft_sel *sel, int min_phases, int slice,
-                                          const PolySpec ps = PolySpec{0, 0.f, 0.f, 0.f, 0.f}, const RecLds *rl = nullptr) {
+                                          const PolySpec ps = no_poly(), const RecLds *rl = nullptr) {
     constexpr int NR = PB_KRAD + 1, PXS = KH_FT_N / KH_SLICES;
+    constexpr int K1 = PB_KSIZE, K2 = 2 * PB_KSIZE - 1, K3 = 3 * PB_KSIZE - 2;
     __shared__ double2 G[NR * PXS];
     __shared__ double cs[KH_FT_N], sn[KH_FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
-    __shared__ float s_out[2 * (KH_THREADS / 64)];
-    const int tid = threadIdx.x;
+    __shared__ float s_m[2][K1], s_m2[2][K2], s_m3[2][K3];     // |taps| marginals over the x / y offsets and their powers
+    __shared__ int s_h[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nph = rl ? rl->nph : info->nphase[0] + info->nphase[1] + info->nphase[2];
     const int R = rl ? rl->radius : info->radius;
     const int separable = rl ? rl->separable : info->separable;
     if (tid < KH_FT_N) { cs[tid] = kCos64[tid]; sn[tid] = kSin64[tid]; }
     bool sym = true;
-    float o4 = 0.f, o8 = 0.f;                         // |taps| outside the +-4 / +-8 box (inside the record's own)
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
         const bool in = abs(u) <= R && abs(v) <= R;
@@ -77,36 +92,96 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         const float km = rl ? rl->taps[PB_KSIZE * PB_KSIZE - 1 - i] : info->kernel[PB_KSIZE * PB_KSIZE - 1 - i];
         sk[i] = in ? k : 0.f;
         sym = sym && (!in || k == km);
-        const int d = max(abs(u), abs(v));
-        if (in && d > 4) o4 += fabsf(k);
-        if (in && d > 8) o8 += fabsf(k);
     }
-    // The window halo of the tile-spectrum body.  The spectrum below holds EVERY tap of the record's box; the halo only has
-    // to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error of at
-    // most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero (full
-    // support) -- 8 for sigma 0.6 whose taps beyond +-4 carry 1e-13 of the mass --, so the halo is the smaller of its class
-    // and the radius outside which the taps' absolute values sum to < 1e-10 (an aliasing term three orders below fp32
-    // rounding; a Gaussian with sigma <= 0.69 along both axes -> 4, <= 1.31 -> 8; any caller-supplied taps are measured
-    // the same way).
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { o4 += __shfl_xor(o4, o); o8 += __shfl_xor(o8, o); }
-    if ((tid & 63) == 0) { s_out[tid >> 6] = o4; s_out[KH_THREADS / 64 + (tid >> 6)] = o8; }
     PB_PT(20);
     const bool symm = __syncthreads_and(sym) && min_phases >= 0;
-    float m4 = 0.f, m8 = 0.f;
-#pragma unroll
-    for (int w = 0; w < KH_THREADS / 64; ++w) { m4 += s_out[w]; m8 += s_out[KH_THREADS / 64 + w]; }
-    const int Rh = min(R <= 4 ? 4 : (R <= 8 ? 8 : 12), m4 < 1e-10f ? 4 : (m8 < 1e-10f ? 8 : 12));
+    // The window halo of the tile-spectrum body, per axis.  The spectrum below holds EVERY tap of the record's box; the halo
+    // only has to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error
+    // of at most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero
+    // (full support) -- 8 for sigma 0.6 whose taps beyond +-4 carry 1e-13 of the mass --, so the halo along an axis is the
+    // radius outside which the taps' absolute values, summed over the other axis, come to < 1e-10 (an aliasing term three
+    // orders below fp32 rounding; any caller-supplied taps are measured the same way).  An oblique Gaussian's marginals
+    // differ: sigma 1.66 / rho 1.0 at 66 degrees needs 7 samples along x and 10 along y.
+    //   The one-pass polynomial's filter a3 K^3 + a2 K^2 + a1 K + b is measured the same way without being formed: the
+    // marginal of |K * K| is at most the marginal of |K| convolved with itself, so |a3| m^3 + |a2| m^2 + |a1| m (1-D
+    // convolution powers of the kernel's marginal m) bounds the composite's marginal from above -- 13 and 18 samples for the
+    // kernel above where the box of 3 x 12 would say 36: Gaussian tails compound like sqrt(3), not like 3.
+    if (tid < K1) {
+        float a = 0.f;
+#pragma unroll 5
+        for (int u = 0; u < K1; ++u) a += fabsf(sk[u * K1 + tid]);
+        s_m[0][tid] = a;
+    } else if (tid >= 64 && tid < 64 + K1) {
+        float a = 0.f;
+#pragma unroll 5
+        for (int v = 0; v < K1; ++v) a += fabsf(sk[(tid - 64) * K1 + v]);
+        s_m[1][tid - 64] = a;
+    }
+    __syncthreads();
+    if (ps.on) {
+        const int ax = tid >> 7, i = tid & 127;
+        if (i < K2) {
+            float a = 0.f;
+            for (int j = max(0, i - (K1 - 1)); j <= min(i, K1 - 1); ++j) a += s_m[ax][j] * s_m[ax][i - j];
+            s_m2[ax][i] = a;
+        }
+        __syncthreads();
+        if (i < K3) {
+            float a = 0.f;
+            for (int j = max(0, i - (K2 - 1)); j <= min(i, K1 - 1); ++j) a += s_m[ax][j] * s_m2[ax][i - j];
+            s_m3[ax][i] = a;
+        }
+        __syncthreads();
+    }
+    {
+        // wave 0 / 1: the kernel along x / y; wave 2 / 3: the composite along x / y
+        const int ax = wave & 1;
+        int r;
+        if (wave < 2) {
+            r = tail_radius([&](int i) { return s_m[ax][i]; }, PB_KRAD, 1e-10f, lane);
+        } else if (ps.on) {
+            const float c3 = fabsf(ps.a3), c2 = fabsf(ps.a2), c1 = fabsf(ps.a1);
+            r = tail_radius([&](int i) {
+                    float v = c3 * s_m3[ax][i];
+                    if (i >= PB_KRAD && i < PB_KRAD + K2) v += c2 * s_m2[ax][i - PB_KRAD];
+                    if (i >= 2 * PB_KRAD && i < 2 * PB_KRAD + K1) v += c1 * s_m[ax][i - 2 * PB_KRAD];
+                    return v;
+                }, 3 * PB_KRAD, 1e-10f, lane);
+        } else {
+            r = 3 * PB_KRAD;
+        }
+        if (lane == 0) s_h[wave] = r;
+    }
+    __syncthreads();
+    // halos: x in multiples of 4 (windows stay on 16-byte boundaries), y even (conv_wfft.hip stages two window rows at a time)
+    const int hxk = max(4, (s_h[0] + 3) & ~3), hyk = max(2, (s_h[1] + 1) & ~1);
+    const int hxp = max(4, (s_h[2] + 3) & ~3), hyp = max(2, (s_h[3] + 1) & ~1);
+    const int Rh = max(4, (max(s_h[0], s_h[1]) + 3) & ~3);          // the workgroup form's class (same halo on both axes)
     const bool dense = symm && separable == 0;
-    // (one-pass polynomial: a kernel within the 4-sample halo, whatever its phase count and whether rank-1 or not -- the
-    // polynomial of a rank-1 kernel is not rank-1, its spectrum is as good as any: one window pass against three stencil
-    // passes, 0.17 ms per 4K polynomial for the clamped isotropic kernel sigma = rho = 0.3 that later iterations mostly find)
-    const bool poly = ps.on && symm && Rh <= 4;
     // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
-    const bool use = poly || (dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0));
+    const bool use3 = dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0);
+    // One-pass polynomial.  Mode 1: a kernel within the 4-sample halo class, whatever its phase count and whether rank-1 or
+    // not -- the polynomial of a rank-1 kernel is not rank-1, its spectrum is as good as any -- (composite class 12: both
+    // bodies).  Mode 2 (wave form only): wherever one pass over windows with the composite's halos costs less than what the
+    // image would take otherwise -- three passes over windows with the kernel's halos (window counts compared; a one-pass
+    // window needs no x operand, and the pass moves 2 words per sample instead of 8: `gain`), or the stencil bodies
+    // (`min_area`: the tile area from which one window pass beats three stencil passes).
+    bool poly = false;
+    if (ps.on == 1) poly = symm && Rh <= 4 && max(hxp, hyp) <= 12;
+    if (ps.on == 2 && symm) {
+        const int txp = KH_FT_N - 2 * hxp, typ = KH_FT_N - 2 * hyp;
+        if (txp >= PB_POLY_MIN_TX && typ >= PB_POLY_MIN_TY) {
+            const float ap = (float)(txp * typ), ak = (float)((KH_FT_N - 2 * hxk) * (KH_FT_N - 2 * hyk));
+            poly = use3 ? 3.f * ps.gain * ap >= ak : ap >= (float)ps.min_area;
+        }
+    }
+    const bool use = poly || use3;
     if (tid == 0 && slice == 0) {
-        sel->use_fft = use ? 1 : 0; sel->rf = poly ? 12 : Rh;
+        sel->use_fft = use ? 1 : 0;
+        sel->rf = poly ? (ps.on == 1 ? 12 : 0) : Rh;
+        sel->hx = poly ? hxp : hxk; sel->hy = poly ? hyp : hyk;
         sel->strip = (separable != 0 && R > 8) ? 1 : 0; sel->poly = poly ? 1 : 0;
+        sel->pad_[0] = 0; sel->pad_[1] = 0;
     }
     if (!use) return;
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24

@@ -1,9 +1,10 @@
-"""GPU parity of the one-pass polynomial (PB_POLY1 when the context is created: 1 = every eligible polynomial, 0 = never;
-by default the pipeline takes it under the adaptive support policy).  Under the wrap
-boundary the reference's deconvolution is ONE filter a3 K^3 + a2 K^2 + a1 K + b (deblurring.py:139-169); for a dense kernel
-within the 4-sample halo the composite's halo is 12, so the image's three Horner launches become one window pass with the
-polynomial's spectrum (csrc/khat.h, pb_launch_conv_poly).  It must agree with the oracle and with the three-step form, in
-batches that mix it with every other body, through the wave-private and the workgroup form, and in the whole call."""
+"""GPU parity of the one-pass polynomial in its first form (PB_POLY1=1 when the context is created: kernels within the
+4-sample halo class only, either tile-spectrum form; 0 = never; the default, 2, is the general form with the composite
+filter's own halos: tests/test_gpu_onepass.py).  Under the wrap boundary the reference's deconvolution is ONE filter
+a3 K^3 + a2 K^2 + a1 K + b (deblurring.py:139-169); for a dense kernel within the 4-sample halo the composite's halo is at
+most 12, so the image's three Horner launches become one window pass with the polynomial's spectrum (csrc/khat.h,
+pb_launch_conv_poly).  It must agree with the oracle and with the three-step form, in batches that mix it with every other
+body, and in the whole call."""
 import os
 
 import numpy as np
@@ -93,8 +94,7 @@ def test_one_pass_in_a_mixed_batch_and_other_passes(engines):
 def test_whole_call_on_a_mildly_blurred_image(engines, shape):
     """the whole call under the adaptive policy on a mildly, obliquely blurred image (the method's own use case): the
     estimates are like sigma 0.6 / rho 0.3 (clamped) at 30 degrees -- dense, within the 4-sample halo.  A context created
-    without PB_POLY1 takes the one-pass form there by itself (bit-identical to PB_POLY1=1) and never under full support
-    (bit-identical to PB_POLY1=0)."""
+    without PB_POLY1 (the general form) takes one pass there as well, under either support policy."""
     from polyblur_amd.engine import Engine
     one, three = engines
     rng = np.random.default_rng(83)
@@ -113,16 +113,18 @@ def test_whole_call_on_a_mildly_blurred_image(engines, shape):
     assert maxabs(got, ref.polyblur_deblurring(x, **kw)) < 3e-5
     auto = Engine(0)
     try:
-        assert np.array_equal(auto.polyblur(x, o), got)
+        ad = auto.polyblur(x, o)
+        assert not np.array_equal(ad, base) and maxabs(ad, base) < 2e-5 and maxabs(ad, ref.polyblur_deblurring(x, **kw)) < 3e-5
+        assert (auto.body_selection(shape[0])[:, 3] == 1).all()                     # (one pass for every image, last iteration)
         # full support: these kernels have radius 8 / 6 there (taps count until they underflow), but the window halo follows
-        # the taps that matter to overlap-save (< 1e-10 of the mass beyond +-4): one pass as well, every tap in the spectrum
+        # the taps that matter to overlap-save (< 1e-10 of the mass beyond them): one pass as well, every tap in the spectrum
         of = one.make_options(support=capi.PB_SUPPORT_FULL, **kw)
         af_, if_ = auto.polyblur(x, of, want_info=True)
         tf_ = three.polyblur(x, of)
         assert (if_["radius"] > 4).all()
         assert not np.array_equal(af_, tf_) and maxabs(af_, tf_) < 2e-5 and maxabs(af_, ref.polyblur_deblurring(x, **kw)) < 3e-5
         # the clamped isotropic estimate sigma = rho = 0.3 (c = 0.2 here), rank-1: its other taps underflow, radius 4 under
-        # every policy; fp32 images let the first step's launch take it along: one pass by default
+        # every policy: one pass
         kw2 = dict(kw, c=0.2)
         of2 = one.make_options(support=capi.PB_SUPPORT_FULL, **kw2)
         a2, i2 = auto.polyblur(x, of2, want_info=True)
@@ -130,9 +132,11 @@ def test_whole_call_on_a_mildly_blurred_image(engines, shape):
         assert (i2["sigma"] == np.float32(0.3)).all() and (i2["radius"] == 4).all() and (i2["separable"] == 1).all()
         assert not np.array_equal(a2, t2) and maxabs(a2, t2) < 2e-5
         assert maxabs(a2, ref.polyblur_deblurring(x, **kw2)) < 2e-5
-        # fp16 images: the last iteration stores fp16, its first step fp32 -- no launch to ride on, three steps under full support
+        # fp16 images: the last iteration stores fp16, its first step fp32 -- a launch of its own runs the one pass
         xh = x.astype(np.float16)
-        assert np.array_equal(auto.polyblur(xh, of2)[..., :8, :8], auto.polyblur(xh, of2)[..., :8, :8])
-        assert maxabs(auto.polyblur(xh, of2).astype(np.float32), ref.polyblur_deblurring(xh.astype(np.float32), **kw2)) < 1e-3
+        h1 = auto.polyblur(xh, of2)
+        assert np.array_equal(h1, auto.polyblur(xh, of2))
+        assert (auto.body_selection(shape[0])[:, 3] == 1).all()
+        assert maxabs(h1.astype(np.float32), ref.polyblur_deblurring(xh.astype(np.float32), **kw2)) < 1e-3
     finally:
         auto.close()
