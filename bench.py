@@ -225,6 +225,17 @@ def main():
     dt_prof, _ = timed(args.steps, step)
     prof = eng.profile_end()
     ms_per_step_prof = 1e3 * dt_prof / args.steps
+    # ... and once more with one event between the steps ("median of >= 10 timed runs"): device time per step
+    step_ms = []
+    if not from_root:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(max(args.steps, 10) + 1)]
+        sync_all()
+        evs[0].record()
+        for e in evs[1:]:
+            step()
+            e.record()
+        sync_all()
+        step_ms = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
 
     side = {}
     if world > 1 and not from_root and not args.no_context:
@@ -279,8 +290,9 @@ def main():
     dom_kernel = "conv_tile_kernel"
     if prof.get("conv_fft", (0.0, 0))[0] > conv_ms:
         conv_ms, conv_n = prof["conv_fft"]
-        # fp32 planes: one wave per window pair (csrc/conv_wfft.hip); fp16 / 8-bit planes: one workgroup per pair (conv_fft.hip)
-        dom_kernel = "conv_wfft_kernel" if s == 4 and os.environ.get("PB_FFT_BODY", "wave") != "wg" else "conv_fft_kernel"
+        # one wave per window pair (csrc/conv_wfft.hip) for every plane type it is built for -- fp32, fp16, 8-bit --; the
+        # workgroup form (conv_fft.hip) only on request (PB_FFT_BODY=wg) or for fp16 temporaries
+        dom_kernel = "conv_wfft_kernel" if os.environ.get("PB_FFT_BODY", "wave") != "wg" and not cfg["opts"].get("half_temporaries") else "conv_fft_kernel"
     # one polynomial application = (2s + 3s + 3s) bytes per sample, spread over its launches
     calls_per_step = B if from_root else 1                       # from_root deblurs image by image as they arrive
     launches_per_poly = max(conv_n / (args.steps * cfg["n_iter"] * calls_per_step), 1e-9)
@@ -293,20 +305,26 @@ def main():
     try:
         import glob
         import hashlib
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_traffic.json")))
-        if cands and args.config == "cfg2" and B == 1 and (H, W) == (2160, 3840) and s == 4:
+        tname = "bench" if args.config == "cfg2" else "bench_" + args.config
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_traffic.json" % tname)))
+        c0 = CONFIGS[args.config]
+        if cands and (B, H, W, cfg["dtype"]) == (c0["batch"], c0["height"], c0["width"], c0["dtype"]) and not from_root:
             tj = json.load(open(cands[-1]))
             h = hashlib.sha256()
-            for f in sorted(glob.glob(os.path.join(REPO, "polyblur_amd", "csrc", "conv*"))):
+            for f in sorted(glob.glob(os.path.join(REPO, "polyblur_amd", "csrc", "conv*")) + glob.glob(os.path.join(REPO, "polyblur_amd", "csrc", "khat.h"))):
                 h.update(open(f, "rb").read())
             if tj.get("conv_sources_sha256_16") != h.hexdigest()[:16]:
                 # counters taken from other code say nothing about this build: no number rather than a stale one
                 traffic_src = "%s was taken from other sources of the reblurring pass (git %s): not used" % (os.path.basename(cands[-1]), tj.get("git", "?"))
             else:
+                # every instantiation of the dominant kernel that ran, weighted by its launches
+                num = den = 0
                 for k, v in tj.get("traffic", {}).items():
-                    if k.startswith(dom_kernel + "<float, float, float>"):
-                        traffic = v["hbm_bytes_per_launch"]
-                        traffic_src = "%s (rocprofv3 --pmc passes of this command at git %s, same sources of the pass)" % (os.path.basename(cands[-1]), tj.get("git", "?"))
+                    if k.startswith(dom_kernel + "<"):
+                        num += v["hbm_bytes_per_launch"] * v["launches"]; den += v["launches"]
+                if den:
+                    traffic = int(num / den)
+                    traffic_src = "%s (rocprofv3 --pmc passes of this command at git %s, same sources of the pass)" % (os.path.basename(cands[-1]), tj.get("git", "?"))
     except Exception:
         pass
     roofline = dict(bound="hbm", kernel=dom_kernel + " (stencil pass; taps as estimated, full 25x25 support)",
@@ -315,6 +333,31 @@ def main():
                     launches_per_polynomial=round(launches_per_poly, 3),
                     algorithmic_bytes_per_launch=int(alg_bytes_per_launch),
                     ms_per_step_with_launch_events=round(ms_per_step_prof, 4))
+    # A measured ceiling beside the nameplate: plain device copies in this same run -- 1 read + 1 write and
+    # 2 reads + 1 write (the shape of a Horner step) of fp32 planes, on the headline's planes (which the 256 MB
+    # last-level cache partly holds, as it does for the pass) and on a working set far beyond it
+    if not from_root and world == 1:
+        def copy_rate(n_elems, reads):
+            a = torch.rand(n_elems, device=dev); b = torch.rand(n_elems, device=dev); c = torch.empty(n_elems, device=dev)
+            f = (lambda: torch.add(a, b, out=c)) if reads == 2 else (lambda: c.copy_(a))
+            for _ in range(3):
+                f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(20):
+                f()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return (reads + 1) * 4.0 * n_elems * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        planes = 3 * 2160 * 3840
+        c11, c21 = copy_rate(planes, 1), copy_rate(planes, 2)
+        b11, b21 = copy_rate(16 * planes, 1), copy_rate(16 * planes, 2)
+        roofline["copy_ceiling_GBps"] = dict(read1_write1=round(b11, 1), read2_write1=round(b21, 1),
+                                             read1_write1_headline_planes=round(c11, 1), read2_write1_headline_planes=round(c21, 1),
+                                             note="torch device copies in this run; the first two on 16 x the headline's planes (1.6 GB per "
+                                                  "operand: HBM), the last two on the planes themselves (99.5 MB per operand)")
+        roofline["frac_of_copy"] = round(achieved / b21, 4) if b21 else None
     # whole-step figure of SURVEY 8d: 9 words per sample per iteration (8 for the polynomial + 1 read for the estimate),
     # plus the options' adders: halo masking 3, domain-transform prefilter 4 + 1 for the residual add-back, bilateral 2
     words = 9.0
@@ -350,14 +393,33 @@ def main():
         # which body evaluated the dense kernels (pb_set_dense_eval: the default threshold on live stencil phases)
         spectrum = [bool(not sp and int(sum(nph)) >= capi.PB_DENSE_MIN_PHASES)
                     for i in infos for sp, nph in zip(i["separable"], i["nphase"])]
-        if any(spectrum):
-            roofline["kernel"] = (dom_kernel + " (one Horner step per launch; taps as estimated, full 25x25 support; dense "
-                                  "kernels evaluated per 64x64 window in the frequency domain inside LDS)")
-            roofline["body"] = dict(tile_spectrum_images=sum(spectrum), of=len(spectrum),
+        # how each iteration's polynomial was evaluated (pb_body_selection after a call of k iterations = iteration k's choice)
+        per_it = []
+        try:
+            for k in range(1, cfg["n_iter"] + 1):
+                polyblur_deblurring(x, **dict(kw, n_iter=k))
+                sel = eng.body_selection(B)
+                one = sel[(sel[:, 0] == 1) & (sel[:, 3] == 1)]
+                three = sel[(sel[:, 0] == 1) & (sel[:, 3] == 0)]
+                halos = lambda t: sorted({(int(r[4]), int(r[5])) for r in t})[:4]
+                per_it.append(dict(one_pass_images=int(len(one)), one_pass_halos_xy=halos(one), three_step_images=int(len(three)),
+                                   three_step_halos_xy=halos(three), stencil_images=int((sel[:, 0] == 0).sum())))
+        except Exception as e:                                   # (a label, not a measurement)
+            per_it = [dict(error="%s: %s" % (type(e).__name__, str(e)[:120]))]
+        if any(spectrum) or any(p.get("one_pass_images") for p in per_it):
+            roofline["kernel"] = (dom_kernel + " (the polynomial of an iteration as three launches, one Horner step each, or -- where the "
+                                  "whole polynomial's filter fits the window -- as ONE window pass; taps as estimated, full 25x25 support; "
+                                  "evaluated per 64x64 window in the frequency domain inside registers / LDS)")
+            work = [1 if p.get("one_pass_images") and not p.get("three_step_images") and not p.get("stencil_images") else 3 for p in per_it]
+            roofline["body"] = dict(tile_spectrum_images=sum(spectrum), of=len(spectrum), per_iteration=per_it,
+                                    working_launches_per_polynomial=round(sum(work) / max(len(work), 1), 2),
                                     stencil_multiply_adds_per_sample_it_replaces=round(sum(macs) / len(macs), 1),
-                                    note="dense (non-rank-1) kernels estimated for this input; the pass is bound by LDS traffic and "
-                                         "the butterflies' vector instructions, not by HBM; context.end_to_end_dense_stencil_body is "
-                                         "the same call through the 2-D stencil body; context.inner_loop_rank1_* the separable case")
+                                    note="algorithmic bytes are SURVEY 8d's 8 words per sample and polynomial whatever the form: a "
+                                         "one-pass polynomial moves 2 of them through HBM (read x, write y), so `achieved` can exceed what "
+                                         "any three-pass evaluation could reach; launches_per_polynomial counts every launch issued -- with "
+                                         "device-built records the two later steps' launches of a one-pass polynomial are issued and find no "
+                                         "work; context.end_to_end_three_step_form is the same call with PB_POLY1=0, "
+                                         "context.end_to_end_dense_stencil_body through the 2-D stencil body")
         else:
             tflops = 2.0 * samples * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12 if conv_n else 0.0
             roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
@@ -390,6 +452,32 @@ def main():
         dt_ad, _ = timed(args.steps, lambda: step("adaptive"))
         ms_ad = 1e3 * dt_ad / args.steps
         side["end_to_end_adaptive_support"] = dict(ms_per_step=round(ms_ad, 4), mp_per_s=round(B * H * W / 1e6 / (ms_ad * 1e-3), 1))
+        # the same call with every polynomial as three Horner launches (a context created with PB_POLY1=0)
+        if not cfg["opts"]:
+            from polyblur_amd.engine import Engine
+            old_env = os.environ.get("PB_POLY1")
+            os.environ["PB_POLY1"] = "0"
+            try:
+                eng3 = Engine(local_rank)
+            finally:
+                if old_env is None:
+                    del os.environ["PB_POLY1"]
+                else:
+                    os.environ["PB_POLY1"] = old_env
+            try:
+                eng3.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+                o3 = eng3.make_options(n_iter=cfg["n_iter"], **KW)
+                out3 = torch.empty_like(x)
+                dt3_code = capi.PB_F32 if s == 4 else capi.PB_F16
+                f3 = lambda: eng3.polyblur_ptr(x.data_ptr(), out3.data_ptr(), dt3_code, x.shape, o3)
+                for _ in range(2):
+                    f3()
+                dt_3, _ = timed(args.steps, f3)
+                ms_3 = 1e3 * dt_3 / args.steps
+                side["end_to_end_three_step_form"] = dict(ms_per_step=round(ms_3, 4), mp_per_s=round(B * H * W / 1e6 / (ms_3 * 1e-3), 1),
+                                                          max_abs_vs_default=float((out3.float() - out.float()).abs().max()))
+            finally:
+                eng3.close()
         # the same call with every dense kernel through the 2-D stencil body (pb_set_dense_eval: PB_DENSE_STENCIL)
         eng.set_dense_eval("stencil")
         try:
@@ -472,6 +560,9 @@ def main():
     line = {
         "metric": "megapixels/sec (n_iter=3, alpha=6, beta=1)", "value": round(value, 1), "unit": "MP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_device": (dict(median=round(step_ms[len(step_ms) // 2], 4), min=round(step_ms[0], 4), max=round(step_ms[-1], 4),
+                                    n=len(step_ms), note="one event between steps, device time; `value` is the contract's total / K")
+                               if step_ms else None),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": desc, "name": args.config, "mode": args.mode, "images_per_gpu": B, "height": H, "width": W,
                    "parallelism": "images sharded, no data-path collective" if not from_root else
