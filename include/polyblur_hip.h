@@ -110,7 +110,9 @@ typedef struct pb_options {
                                    pb_blur_info: their taps live in the context's scratch and every reblurring step is a plain
                                    LDS-tiled stencil (conv_big.hip: up to 2401 multiply-adds per sample -- 10 to 40 times the
                                    time of the default size); the record's `kernel` then holds the central 25 x 25 taps
-                                   renormalised, theta / sigma / rho are exact; not with edgetaping or separable_approx */
+                                   renormalised, theta / sigma / rho are exact.  Edgetaping and separable_approx are
+                                   built for ODD sizes up to 25 only: with an even size or one above 25 pb_polyblur_batch and
+                                   pb_make_separable_kernels return PB_ERR_UNSUPPORTED */
 } pb_options;
 
 /* Per-image, per-iteration estimation record (device or host copy). Mirrors the values the
@@ -170,14 +172,14 @@ void pb_default_options(pb_options *opt);        /* the functional API's default
  * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>.
  * (PB_STRIP=1 in the environment sends rank-1 kernels of full support on fp32 planes through the streaming strip body,
  * conv_strip.hip: an experiment measured slower than the tile body; same results to fp32 rounding.)
- * With the wrap boundary and no edgetaper, pb_polyblur_batch lets an image whose kernel fits a 4-sample halo (the
- * clamped isotropic estimate sigma = rho = 0.3 under every policy, sigma, rho <~ 0.7 under PB_SUPPORT_ADAPTIVE: the
- * estimates of mildly blurred images) take its whole polynomial a3 K^3 + a2 K^2 + a1 K + b -- one filter in the
- * reference's 'fft' form, deblurring.py:139-169 -- as ONE window pass with that polynomial's spectrum: 1.7 x faster on such
- * kernels, same results to fp32 rounding (fewer roundings).  For fp32 images the first step's launch takes such images
- * along; where that is not possible (the last iteration of fp16 / 8-bit images) a launch of its own is issued under the
- * adaptive policy only.  PB_POLY1=0 in the environment switches the form off, PB_POLY1=1 extends it to every case and to
- * pb_inverse_filter (record sets are then not cached).  All three variables are read when the context is created. */
+ * With the wrap boundary and no edgetaper the three Horner steps of an image's polynomial are ONE filter,
+ * a3 K^3 + a2 K^2 + a1 K + b -- the reference's own 'fft' form, deblurring.py:139-169.  The engine measures that filter's
+ * halo per axis and takes the polynomial as one window pass with the polynomial's spectrum wherever that costs less than
+ * three passes with the kernel's halos (pb_polyblur_batch, pb_inverse_filter, pb_time_inner_loop; per image, decided on
+ * the device): same taps, same results to fp32 rounding (fewer roundings), 2 words per sample through HBM instead of 8.
+ * PB_POLY1=0 in the environment switches the form off, PB_POLY1=1 restricts it to kernels within the 4-sample halo class
+ * (round 3's form); PB_POLY_GAIN / PB_POLY_MIN_AREA tune the cost model (csrc/khat.h).  pb_body_selection reports the
+ * choice.  All of these variables are read when the context is created. */
 typedef enum pb_dense_eval { PB_DENSE_STENCIL = 0, PB_DENSE_AUTO = 1 } pb_dense_eval;
 int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases);
 /* Diagnostics: how the B images of the most recent estimation / reblurring pass on this context are evaluated --
@@ -228,7 +230,9 @@ int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_b
 
 /* method='direct_separable' (pb_options.separable_approx): from B records that hold (sigma, rho, theta) build the two
  * correlation kernels of the x-t separable approximation -- dev_sep[b] the 1-D pass, dev_sep[B + b] the oblique pass
- * with linear interpolation (intent of separable_gaussian2d.cpp:91-183; definition at pb_options.separable_approx). */
+ * with linear interpolation (intent of separable_gaussian2d.cpp:91-183; definition at pb_options.separable_approx).
+ * ker_size: odd, 3 .. 25 (0 means 25); an even size -- the reference's off-centre grid, filters.py:78 -- or a larger one
+ * returns PB_ERR_UNSUPPORTED.                                                                                          */
 int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *dev_sep, int support,
                               int ker_size);
 
@@ -342,6 +346,19 @@ int pb_comm_init(pb_comm **comm, pb_ctx *ctx, int rank, int world, const unsigne
 int pb_comm_destroy(pb_comm *comm);
 int pb_comm_scatter(pb_comm *comm, const void *root_batch, void *shard, int dtype, int B, int C, int H, int W, int root);
 int pb_comm_gather(pb_comm *comm, const void *shard, void *root_batch, int dtype, int B, int C, int H, int W, int root);
+/* The overlapped form of scatter -> deblur -> gather (what polyblur_amd/distributed.py:deblur_from_root does over
+ * torch.distributed; the reference's analogue is the sequential patch-group loop of deblurring.py:310-336): the batch
+ * lives on `root`, travels image by image -- exchange step t is one grouped ncclSend / ncclRecv operation on a stream of
+ * its own in which the root sends image t of every peer's shard and receives result t - 2 from every peer --, every
+ * rank deblurs image t - 1 meanwhile (pb_polyblur_batch, one image per call), and the results land in root_out on the
+ * root.  Called by every rank with the same B, C, H, W, dtype, options and root; root_batch / root_out are read /
+ * written on the root only (NULL elsewhere).  Returns with the context's stream behind every transfer.
+ * pb_comm_plan_steps / pb_comm_plan state the order of a step's operations (ops[3 i + 0..2] = { 1 send | 0 recv, peer,
+ * image index }, at most 2 (world - 1) of them), the order both sides enumerate them in -- host-only, no GPU needed.   */
+int pb_comm_deblur_from_root(pb_comm *comm, const void *root_batch, void *root_out, int dtype, int B, int C, int H, int W,
+                             const pb_options *opt, int root);
+int pb_comm_plan_steps(int B, int world, int root);
+int pb_comm_plan(int B, int world, int root, int rank, int step, int *ops, int *n_ops);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,7 @@ SYMBOLS = [
     "pb_fft_length_supported", "pb_make_separable_kernels", "pb_set_dense_eval",
     "pb_body_selection",
     "pb_comm_shard", "pb_comm_unique_id", "pb_comm_init", "pb_comm_destroy", "pb_comm_scatter", "pb_comm_gather",
+    "pb_comm_deblur_from_root", "pb_comm_plan_steps", "pb_comm_plan",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused", "conv_fft"]
 
@@ -148,6 +149,9 @@ def load_library():
             "pb_comm_destroy": (ci, [vp]),
             "pb_comm_scatter": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci]),
             "pb_comm_gather": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci]),
+            "pb_comm_deblur_from_root": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), ci]),
+            "pb_comm_plan_steps": (ci, [ci, ci, ci]),
+            "pb_comm_plan": (ci, [ci, ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]),
         }
         for name in SYMBOLS:
             fn = getattr(lib, name)           # AttributeError if the library does not export it

@@ -449,7 +449,8 @@ int pb_make_separable_kernels(pb_ctx *ctx, int B, const pb_blur_info *dev_info, 
     pb_default_options(&o);
     o.ker_size = ker_size;
     const int ksize = pb_kernel_size(&o);
-    if (!ksize || ksize > PB_KSIZE) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: the separable approximation is built for sizes from 2 to %d", ker_size, PB_KSIZE);
+    if (!ksize || ksize > PB_KSIZE || !(ksize & 1))
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: the separable approximation is built for odd sizes from 3 to %d (an even size is the reference's off-centre grid, filters.py:78: not built)", ker_size, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
     pb_forget_records(ctx, dev_sep, 2 * B);
     return pb_make_sep_records(ctx, B, dev_info, dev_sep, support, ksize);
@@ -594,6 +595,10 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE_MAX);
     if (opt->separable_approx && opt->edgetaping)
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "edgetaping is not defined for the separable approximation");
+    // (an even ker_size is the reference's off-centre tap grid, blur_estimation.py:222 / filters.py:78: the edgetaper weights
+    // and the 1-D kernels of the separable approximation are built on the centred grid only)
+    if (!(ksize & 1) && (opt->edgetaping || opt->separable_approx))
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for odd sizes only", ksize);
     // (kernels beyond the 25 x 25 record take conv_big.hip's pass: no edgetaper weights, no separable approximation there)
     if (ksize > PB_KSIZE && (opt->edgetaping || opt->separable_approx))
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);

@@ -107,8 +107,10 @@ struct pb_ctx {
     int poly_mode = 2;
     PolySpec poly_built = no_poly(), poly_want = no_poly();
     // cost model of the general one-pass form (PolySpec.on == 2; env PB_POLY_GAIN, PB_POLY_MIN_AREA): an image takes it when
-    // its composite tile area x 3 x poly_gain is at least the tile area of its three-step windows, or -- an image the
-    // stencil bodies would take -- at least poly_min_area samples
+    // its composite tile has at least poly_min_area samples and -- an image that would otherwise take three tile-spectrum
+    // passes -- 3 x poly_gain x that area is at least the tile area of its three-step windows (measured at 4K: a one-pass
+    // window costs what a three-step window costs, gain = 1; one pass over 768-sample tiles takes what three rank-1 stencil
+    // passes take)
     float poly_gain = 1.0f;
     int poly_min_area = 768;
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)

@@ -381,6 +381,7 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
     const bool strip = ctx->strip_mode && have && kf->any_strip && p.in_dtype == PB_F32 && p.x_dtype == PB_F32 &&
                        p.out_dtype == PB_F32 && p.epilogue == EPI_HORNER && p.pad == PB_KRAD && !p.skip_sep;
     bool strip_done = false;
+#ifdef PB_EXPERIMENTAL      // (python -m polyblur_amd.build --experimental: conv_strip.hip is a measured experiment, NOTEBOOK.md)
     if (strip) {
         p.strip = 1;
         const int rc = pb_launch_conv_strip(ctx, p);
@@ -388,6 +389,9 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
         else if (rc != PB_ERR_UNSUPPORTED) return rc;
         else p.strip = 0;
     }
+#else
+    (void)strip;
+#endif
     const bool tile_needed = !have || (strip_done ? kf->any_tile : kf->any_other);
     if (tile_needed) {
         const int rc = launch_stencil(ctx, p);

@@ -835,8 +835,7 @@ int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
     static const long min_jobs = [] { const char *e = getenv("PB_WAVE_MIN_JOBS"); return e ? atol(e) : 0L; }();
     if (!pb_conv_wfft_types(p)) return PB_ERR_UNSUPPORTED;
     const bool poly2 = p.poly != 0 && ctx->poly_built.on == 2;
-    // (the smallest tile area the cost model admits: three-step tiles are at least 40 x 40)
-    const float min_area = std::min(1600.f / (3.f * ctx->poly_gain), (float)ctx->poly_min_area);
+    const float min_area = (float)ctx->poly_min_area;      // (the smallest one-pass tile the cost model of khat.h admits)
     WGeom g;
     long per_max = 0, pairs12 = 0;
     if (!wfft_geometry(p, poly2, min_area, g, per_max, pairs12)) {

@@ -171,8 +171,10 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     if (ps.on == 2 && symm) {
         const int txp = KH_FT_N - 2 * hxp, typ = KH_FT_N - 2 * hyp;
         if (txp >= PB_POLY_MIN_TX && typ >= PB_POLY_MIN_TY) {
+            // (min_area also bounds the job grid: a launch that may carry one-pass images is sized for tiles of that area, and
+            // with records built on the device every surplus workgroup is dispatched to find that out)
             const float ap = (float)(txp * typ), ak = (float)((KH_FT_N - 2 * hxk) * (KH_FT_N - 2 * hyk));
-            poly = use3 ? 3.f * ps.gain * ap >= ak : ap >= (float)ps.min_area;
+            poly = ap >= (float)ps.min_area && (!use3 || 3.f * ps.gain * ap >= ak);
         }
     }
     const bool use = poly || use3;

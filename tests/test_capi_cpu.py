@@ -131,6 +131,33 @@ def test_comm_shards_match_the_python_layer(lib):
     assert lib.pb_comm_shard(4, 2, 2, ctypes.byref(first), ctypes.byref(count)) != 0      # rank out of range
 
 
+def test_comm_exchange_plan_matches_the_python_layer(lib):
+    """pb_comm_plan / pb_comm_plan_steps (csrc/comm.hip: what pb_comm_deblur_from_root walks) and
+    polyblur_amd.distributed.exchange_plan / exchange_steps enumerate the same operations in the same order for every
+    (B, world, root, rank, step); and the root's list of a step, filtered to one peer, is that peer's list with send and
+    recv swapped (the pairing RCCL needs: it has no tags)."""
+    from polyblur_amd.distributed import exchange_plan, exchange_steps
+    ops = (ctypes.c_int * (3 * 2 * 8))()
+    n = ctypes.c_int()
+    for B in (1, 2, 5, 8, 9, 33):
+        for world in (1, 2, 3, 8):
+            for root in sorted({0, world - 1, world // 2}):
+                steps = lib.pb_comm_plan_steps(B, world, root)
+                assert steps == exchange_steps(B, world, root)
+                for step in range(steps + 1):
+                    lists = {}
+                    for rank in range(world):
+                        assert lib.pb_comm_plan(B, world, root, rank, step, ops, ctypes.byref(n)) == 0
+                        got = [("send" if ops[3 * i] else "recv", ops[3 * i + 1], ops[3 * i + 2]) for i in range(n.value)]
+                        assert got == exchange_plan(B, world, root, rank, step), (B, world, root, rank, step)
+                        lists[rank] = got
+                    for peer in range(world):
+                        if peer != root:
+                            mirror = [("recv" if k == "send" else "send", root, img) for k, p, img in lists[root] if p == peer]
+                            assert mirror == lists[peer]
+    assert lib.pb_comm_plan_steps(4, 2, 2) < 0 and lib.pb_comm_plan(4, 2, 0, 2, 0, ops, ctypes.byref(n)) != 0
+
+
 def test_line_length_tiers(lib):
     """include/polyblur_hip.h: 1 = whole lines in LDS, 2 = through a line buffer in device memory, 0 = not taken"""
     want = {1: 0, 2: 1, 4096: 1, 8191: 1, 8192: 1, 8200: 2, 20480: 1, 20736: 2, 40001: 2, 65536: 2, 65537: 0, 9000: 1, 12000: 1, 12001: 2}

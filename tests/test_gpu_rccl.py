@@ -91,3 +91,30 @@ def test_c_abi_communicator_world_of_one():
     eng.synchronize()
     assert torch.equal(shard, x) and torch.equal(back, x)
     assert lib.pb_comm_destroy(comm) == 0
+
+
+def test_c_abi_deblur_from_root_world_of_one():
+    """pb_comm_deblur_from_root with one rank is the plain batch call (no exchange); with more ranks it walks pb_comm_plan,
+    whose order is checked against the Python layer's on the CPU (tests/test_capi_cpu.py) -- the lease has one GPU, so no
+    grouped ncclSend / ncclRecv of it has run here."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from polyblur_amd import _capi as capi, polyblur_deblurring
+    from polyblur_amd.engine import get_engine
+    from polyblur_amd.synthetic import synthetic_blurry_batch
+    eng = get_engine(0)
+    lib = eng.lib
+    comm = C.c_void_p()
+    eng._check(lib.pb_comm_init(C.byref(comm), eng.ctx, 0, 1, None))
+    x = torch.from_numpy(synthetic_blurry_batch(3, 3, 120, 168, seed0=9)[0]).cuda()
+    out = torch.zeros_like(x)
+    kw = dict(n_iter=2, c=0.362, b=0.468, alpha=6, beta=1)
+    o = eng.make_options(**kw)
+    eng.set_stream(torch.cuda.current_stream(0).cuda_stream)
+    eng._check(lib.pb_comm_deblur_from_root(comm, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), capi.PB_F32, 3, 3, 120, 168, C.byref(o), 0))
+    eng.synchronize()
+    assert torch.equal(out, polyblur_deblurring(x, **kw))
+    assert lib.pb_comm_deblur_from_root(comm, None, C.c_void_p(out.data_ptr()), capi.PB_F32, 3, 3, 120, 168, C.byref(o), 0) != 0   # the root passes the batch
+    assert lib.pb_comm_deblur_from_root(comm, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), 7, 3, 3, 120, 168, C.byref(o), 0) != 0  # unknown dtype
+    assert lib.pb_comm_destroy(comm) == 0

@@ -6,7 +6,10 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("PB_TEST_EXPERIMENTAL") != "1",
+                                 reason="conv_strip.hip is not in the default library: build with `python -m polyblur_amd.build "
+                                        "--experimental` and set PB_TEST_EXPERIMENTAL=1")]
 
 from oracle import polyblur_ref as ref                      # the checker (tests only)
 from polyblur_amd import _capi as capi
