@@ -393,12 +393,11 @@ def main():
         # which body evaluated the dense kernels (pb_set_dense_eval: the default threshold on live stencil phases)
         spectrum = [bool(not sp and int(sum(nph)) >= capi.PB_DENSE_MIN_PHASES)
                     for i in infos for sp, nph in zip(i["separable"], i["nphase"])]
-        # how each iteration's polynomial was evaluated (pb_body_selection after a call of k iterations = iteration k's choice)
+        # how each iteration's polynomial was evaluated (pb_body_selection: the device's choice, iteration by iteration)
         per_it = []
         try:
-            for k in range(1, cfg["n_iter"] + 1):
-                polyblur_deblurring(x, **dict(kw, n_iter=k))
-                sel = eng.body_selection(B)
+            for k in range(cfg["n_iter"]):
+                sel = eng.body_selection(B, k)
                 one = sel[(sel[:, 0] == 1) & (sel[:, 3] == 1)]
                 three = sel[(sel[:, 0] == 1) & (sel[:, 3] == 0)]
                 halos = lambda t: sorted({(int(r[4]), int(r[5])) for r in t})[:4]

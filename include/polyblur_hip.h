@@ -182,12 +182,13 @@ void pb_default_options(pb_options *opt);        /* the functional API's default
  * choice.  All of these variables are read when the context is created. */
 typedef enum pb_dense_eval { PB_DENSE_STENCIL = 0, PB_DENSE_AUTO = 1 } pb_dense_eval;
 int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases);
-/* Diagnostics: how the B images of the most recent estimation / reblurring pass on this context are evaluated --
+/* Diagnostics: how the B images of iteration `iteration` of the most recent pb_polyblur_batch call on this context were
+ * evaluated (-1: the most recent estimation / reblurring pass of any entry point) --
  * host[6 b + 0..5] = { tile-spectrum body (1) or a stencil body (0), halo class of the workgroup form, rank-1 strip flag,
  * whole polynomial in one window pass (1) or three Horner steps (0), window halo along x, along y }.  The choice is made
  * on the device from each record (no reference counterpart: filters.convolve2d, filters.py:14-49, has one evaluation);
  * bench.py labels its roofline line with it.  Synchronises the context's stream.                                   */
-int pb_body_selection(pb_ctx *ctx, int *host, int B);
+int pb_body_selection(pb_ctx *ctx, int iteration, int *host, int B);
 /* bytes of scratch the context currently holds (for the HBM-footprint report) */
 size_t pb_workspace_bytes(pb_ctx *ctx);
 

@@ -140,7 +140,7 @@ def load_library():
             "pb_overlap_add": (ci, [vp, vp, vp] + [ci] * 13 + [vp, vp]),
             "pb_fft_length_supported": (ci, [ci]),
             "pb_make_separable_kernels": (ci, [vp, ci, vp, vp, ci, ci]),
-            "pb_body_selection": (ci, [vp, C.POINTER(ci), ci]),
+            "pb_body_selection": (ci, [vp, ci, C.POINTER(ci), ci]),
             "pb_profile_begin": (ci, [vp]),
             "pb_profile_end": (ci, [vp, fp, C.POINTER(ci)]),
             "pb_comm_shard": (ci, [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]),

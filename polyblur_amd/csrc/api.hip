@@ -603,6 +603,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (ksize > PB_KSIZE && (opt->edgetaping || opt->separable_approx))
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
+    ctx->sel_slot = 0;
     Geometry g = geometry(B, C, H, W, ksize / 2);
     const bool poly_eligible = opt->boundary == PB_WRAP && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
     const long n = (long)g.P * g.HW;
@@ -684,6 +685,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (dtype != PB_F32 && it != n_iter - 1) dst = (it % 2 == 0) ? tmpimg : tmpimg2;
         const int cur_dtype = it == 0 ? dtype : work, dst_dtype = it == n_iter - 1 ? dtype : work;
         pb_blur_info *info = infos + (size_t)it * B;
+        ctx->sel_slot = it;                       // (this iteration's choices of body keep a slot of their own: pb_body_selection)
         // The estimation ends with the kernels' spectra and the images' choice of body: it has to know whether this
         // iteration's polynomial may take the one-pass form (pb_fft_sel.poly) -- exactly what run_polynomial will ask for.
         if (poly_eligible) {
@@ -731,6 +733,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         }
         cur = dst;
     }
+    ctx->sel_slot = 0;
     if (host_info) {
         PB_HIP(hipMemcpyAsync(host_info, infos, sizeof(pb_blur_info) * (size_t)n_iter * B, hipMemcpyDeviceToHost, ctx->stream));
         PB_HIP(hipStreamSynchronize(ctx->stream));
@@ -773,14 +776,16 @@ int pb_overlap_add(pb_ctx *ctx, const void *patches, void *out, int dtype, int B
                                dev_win_y, dev_win_x);
 }
 
-int pb_body_selection(pb_ctx *ctx, int *host, int B) {
-    if (!ctx || !host || B < 1) return PB_ERR_BADARG;
+int pb_body_selection(pb_ctx *ctx, int iteration, int *host, int B) {
+    if (!ctx || !host || B < 1 || iteration < -1) return PB_ERR_BADARG;
     PB_HIP(hipSetDevice(ctx->device));
     const auto it = ctx->scratch.find("conv.fftsel");
-    if (it == ctx->scratch.end() || it->second.bytes < sizeof(pb_fft_sel) * (size_t)B || ctx->khat_B < B)
+    if (it == ctx->scratch.end() || ctx->sel_B != B || it->second.bytes < sizeof(pb_fft_sel) * (size_t)B * PB_SEL_SLOTS)
         return pb_fail(ctx, PB_ERR_BADARG, "pb_body_selection: no selection for %d images on this context", B);
+    const int slot = (iteration < 0 ? ctx->sel_last : iteration) % PB_SEL_SLOTS;
     std::vector<pb_fft_sel> h((size_t)B);
-    PB_HIP(hipMemcpyAsync(h.data(), it->second.p, sizeof(pb_fft_sel) * (size_t)B, hipMemcpyDeviceToHost, ctx->stream));
+    PB_HIP(hipMemcpyAsync(h.data(), static_cast<const pb_fft_sel *>(it->second.p) + (size_t)slot * B, sizeof(pb_fft_sel) * (size_t)B,
+                          hipMemcpyDeviceToHost, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < B; ++b) {
         host[6 * b] = h[b].use_fft; host[6 * b + 1] = h[b].rf; host[6 * b + 2] = h[b].strip;

@@ -90,6 +90,7 @@ struct pb_ctx {
     struct BodyFlags { bool any_fft = false, any_other = false, any_strip = false, any_tile = false, any_fft3 = false; };
     struct RecFlags { int B; BodyFlags plain; bool poly_valid; PolySpec spec; BodyFlags poly; std::vector<pb_fft_sel> sel; };
     std::map<const void *, RecFlags> rec_cache;
+    int sel_slot = 0, sel_last = 0, sel_B = 0;           // "conv.fftsel" holds PB_SEL_SLOTS runs of sel_B records: the slot passes write to / read from
     const std::vector<pb_fft_sel> *known_sel = nullptr;   // the records of the pass being launched, where the host has them (sizes its job grid)
     const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)
     int khat_B = 0;                      // ... and how many of its records they cover (a longer run at the same address has stale tails)
@@ -170,6 +171,7 @@ enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
        EPI_TAPER = 1 };   // out = a * x + (1-a) * (K*in),  a = v1[py] * v2[px]
 
 // per image: which body evaluates a dense kernel (written on the device by khat_kernel, conv_fft.hip)
+constexpr int PB_SEL_SLOTS = 16;
 constexpr int PB_POLY_MIN_TX = 24, PB_POLY_MIN_TY = 16;     // smallest tile of a one-pass window (bounds the job grid)
 
 

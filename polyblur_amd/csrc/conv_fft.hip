@@ -336,8 +336,11 @@ int launch_fft_typed(pb_ctx *ctx, const ConvPass &p) {
 // Spectra + per-image body selection for the B images of `info` (B = P / C).
 int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel) {
     float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat", sizeof(float) * FT_N * FT_N * (size_t)B));
-    pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel", sizeof(pb_fft_sel) * (size_t)B));
+    // (one slot of selections per iteration of the call in progress, so that pb_body_selection can report every iteration's)
+    pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel", sizeof(pb_fft_sel) * (size_t)B * PB_SEL_SLOTS));
     if (!k || !s) return PB_ERR_NOMEM;
+    s += (size_t)(ctx->sel_slot % PB_SEL_SLOTS) * B;
+    ctx->sel_B = B; ctx->sel_last = ctx->sel_slot;
     if (k != ctx->khat_buf) { ctx->khat_buf = k; ctx->khat_owner = nullptr; ctx->khat_B = 0; ctx->khat_by_estimate = false; }   // (the scratch buffer was reallocated)
     *khat = k; *sel = s;
     return PB_OK;

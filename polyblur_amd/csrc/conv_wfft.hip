@@ -819,7 +819,7 @@ extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
 
 bool pb_conv_wfft_types(const ConvPass &p) {
     switch (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype) {
-        case 0: case 3: case 4: case 12: case 13: case 24: case 26: case 6: case 8: case 2: return true;
+        case 0: case 1: case 3: case 4: case 12: case 13: case 24: case 26: case 6: case 8: case 2: return true;
         default: return false;
     }
 }
@@ -866,6 +866,7 @@ int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
     // the first step and the one-pass polynomial of fp16 images (fp16 window)
     switch (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype) {
         case 0: return launch_wfft_typed<float, float, float>(ctx, p, g, groups);
+        case 1: return launch_wfft_typed<float, float, __half>(ctx, p, g, groups);          // (the last store of an fp16 image after fp32 iterations)
         case 3: return launch_wfft_typed<float, __half, float>(ctx, p, g, groups);
         case 4: return launch_wfft_typed<float, __half, __half>(ctx, p, g, groups);
         case 12: return launch_wfft_typed<__half, __half, float>(ctx, p, g, groups);

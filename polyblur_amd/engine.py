@@ -88,11 +88,11 @@ class Engine:
         m = {"stencil": capi.PB_DENSE_STENCIL, "auto": capi.PB_DENSE_AUTO}[mode]
         self._check(self.lib.pb_set_dense_eval(self.ctx, m, int(min_phases)))
 
-    def body_selection(self, B: int) -> np.ndarray:
-        """(B, 6) int32: per image {tile-spectrum body, halo class, strip, one-pass polynomial, halo x, halo y} of the most
-        recent estimation / reblurring pass (pb_body_selection)."""
+    def body_selection(self, B: int, iteration: int = -1) -> np.ndarray:
+        """(B, 6) int32: per image {tile-spectrum body, halo class, strip, one-pass polynomial, halo x, halo y} of iteration
+        `iteration` of the most recent polyblur call (-1: of the most recent estimation / reblurring pass; pb_body_selection)."""
         out = np.zeros((B, 6), np.int32)
-        self._check(self.lib.pb_body_selection(self.ctx, out.ctypes.data_as(capi.C.POINTER(capi.C.c_int)), int(B)))
+        self._check(self.lib.pb_body_selection(self.ctx, int(iteration), out.ctypes.data_as(capi.C.POINTER(capi.C.c_int)), int(B)))
         return out
 
     def workspace_bytes(self) -> int:

@@ -799,6 +799,25 @@ def test_kernel_sizes_against_reference_goldens(golden, k, method):
         assert maxabs(out, g["k13_fft_taper_halo"]) < 2e-5
 
 
+@pytest.mark.parametrize("k", [4, 12, 24, 36])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_even_kernel_sizes_link_by_link(golden, k, method):
+    """the ill-conditioned corner: even ker_size, three iterations.  The off-centre Gaussian's 'fft' transform
+    carries a half-sample phase (blur_estimation.py:221-223, filters.py:255-273) and every iteration amplifies the rounding
+    differences of the earlier ones 5-10 x, so the engine is held link by link -- one iteration on the REFERENCE's input of
+    that iteration -- to the plain fp32 tolerance, and the chained call to 3e-4 (tests/golden/make_golden_kersize_chain.py)."""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    g = golden("pipeline_kersize_chain.npz")
+    kw = dict(ker_size=k, method=method, **KW)
+    xs = [g["x0"]] + [g["k%d_%s_x%d" % (k, method, i)] for i in (1, 2, 3)]
+    for i in range(3):
+        out = polyblur_deblurring(torch.from_numpy(xs[i]).cuda(), n_iter=1, **kw).cpu().numpy()
+        assert maxabs(out, xs[i + 1]) < 2e-5, (k, method, i, maxabs(out, xs[i + 1]))
+    out = polyblur_deblurring(torch.from_numpy(xs[0]).cuda(), n_iter=3, **kw).cpu().numpy()
+    assert maxabs(out, xs[3]) < 3e-4
+
+
 @pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64)), (2, (1, 3, 20, 17)), (8, (2, 1, 33, 40)), (22, (1, 3, 64, 70)),
                                      (27, (2, 3, 70, 133)), (26, (1, 1, 40, 33)), (48, (1, 3, 150, 97)), (49, (2, 1, 20, 30)), (35, (1, 3, 300, 517))])
 def test_kernel_sizes_against_oracle(k, shape):
