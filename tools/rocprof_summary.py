@@ -70,7 +70,7 @@ def conv_sources_hash():
     """sha256 over the reblurring pass's sources: bench.py refuses HBM-traffic numbers taken from other code"""
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(here, "polyblur_amd", "csrc", "conv*"))):
+    for f in sorted(glob.glob(os.path.join(here, "polyblur_amd", "csrc", "conv*"))) + glob.glob(os.path.join(here, "polyblur_amd", "csrc", "khat.h")):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 try:
