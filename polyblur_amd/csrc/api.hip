@@ -90,6 +90,7 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     if (const char *e = getenv("PB_POLY1")) ctx->poly_mode = atoi(e);
     if (const char *e = getenv("PB_POLY_GAIN")) ctx->poly_gain = (float)atof(e);
     if (const char *e = getenv("PB_POLY_MIN_AREA")) ctx->poly_min_area = atoi(e);
+    if (const char *e = getenv("PB_POLY_COST128")) ctx->poly_cost128 = (float)atof(e);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     const char *side = getenv("PB_SIDE_STREAM");
@@ -302,7 +303,7 @@ void make_steps(const Geometry &g, const void *xsrc, int x_dtype, const float *x
 PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta) {
     const int mode = pb_poly_spec_mode(ctx, steps);
     if (!mode) return no_poly();
-    return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area};
+    return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area, ctx->poly_cost128};
 }
 
 // y = a3 K^3 x + a2 K^2 x + a1 K x + beta x by Horner, three stencil passes (deblurring.py:122-138).

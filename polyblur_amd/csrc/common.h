@@ -41,10 +41,12 @@ struct ProfRec {
 // One-pass polynomial: which filter the spectra in the context's scratch are those of (see pb_fft_sel.poly).
 // on: 0 = the kernel's own spectrum (three Horner steps); 1 = the polynomial's for kernels within the 4-sample halo class
 // (composite halo class 12: either tile-spectrum body can run it); 2 = the polynomial's wherever one window pass with
-// the composite filter's own per-axis halos is cheaper than the three steps (wave body only: conv_wfft.hip).
+// the composite filter's own per-axis halos is cheaper than the three steps (wave body only: conv_wfft.hip); 3 = as 2, and
+// on 128 x 128 windows (conv_w128.hip, pb_fft_sel.poly == 2) where THAT is cheapest -- cost128 = what a 128 x 128 window pair
+// costs in units of a 64 x 64 one (four waves, longer transforms).
 // gain, min_area: the cost model of mode 2 (khat.h).
-struct PolySpec { int on; float a3, a2, a1, b; float gain; int min_area; };
-inline PolySpec no_poly() { return PolySpec{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0}; }
+struct PolySpec { int on; float a3, a2, a1, b; float gain; int min_area; float cost128; };
+inline PolySpec no_poly() { return PolySpec{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0.f}; }
 inline bool same_spec(const PolySpec &x, const PolySpec &y) {
     return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b));
 }
@@ -105,7 +107,7 @@ struct pb_ctx {
     // launch can take such images along (same output type as the last step's) that costs nothing when no image
     // qualifies; otherwise a composite launch is needed, which finds no work then and costs 1 % of a 4K call even on the
     // side stream (1.182 -> 1.195 ms): issued under the adaptive policy only.
-    int poly_mode = 2;
+    int poly_mode = 3;
     PolySpec poly_built = no_poly(), poly_want = no_poly();
     // cost model of the general one-pass form (PolySpec.on == 2; env PB_POLY_GAIN, PB_POLY_MIN_AREA): an image takes it when
     // its composite tile has at least poly_min_area samples and -- an image that would otherwise take three tile-spectrum
@@ -114,6 +116,7 @@ struct pb_ctx {
     // passes take)
     float poly_gain = 1.0f;
     int poly_min_area = 768;
+    float poly_cost128 = 7.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
 };
 
@@ -172,6 +175,8 @@ enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
 
 // per image: which body evaluates a dense kernel (written on the device by khat_kernel, conv_fft.hip)
 constexpr int PB_SEL_SLOTS = 16;
+constexpr int PB_KHAT_STRIDE = 128 * 128;                  // floats of spectrum per image in "conv.khat": 64 x 64 of them, or 128 x 128 (one pass on 128 x 128 windows)
+constexpr int PB_POLY128_MIN_T = 64;                       // smallest tile side of a one-pass 128 x 128 window (bounds the job grid)
 constexpr int PB_POLY_MIN_TX = 24, PB_POLY_MIN_TY = 16;     // smallest tile of a one-pass window (bounds the job grid)
 
 
@@ -216,7 +221,9 @@ int pb_launch_conv_fft(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_strip(pb_ctx *ctx, const ConvPass &p);                    // conv_strip.hip; PB_ERR_UNSUPPORTED: not an all-fp32 plain Horner pass
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p);                     // conv_wfft.hip; PB_ERR_UNSUPPORTED: dtype combination not built
 bool pb_conv_fft_types(const ConvPass &p);                                   // conv_fft.hip: whether the workgroup form is built for the pass's types
-bool pb_conv_wfft_types(const ConvPass &p);                                  // ... whether it is built for the pass's types
+bool pb_conv_wfft_types(const ConvPass &p);
+int pb_launch_conv_w128(pb_ctx *ctx, const ConvPass &p);                     // conv_w128.hip: the one-pass polynomial on 128 x 128 windows (pb_fft_sel.poly == 2)
+bool pb_conv_w128_types(int in_dtype, int out_dtype);                                  // ... whether it is built for the pass's types
 int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps);                   // conv.hip: the PolySpec.on a polynomial with these steps may ask for
 // kernels larger than the 25 x 25 record (conv_big.hip): their taps on the ker_size grid, and one Horner step with them
 int pb_build_big_taps(pb_ctx *ctx, const pb_blur_info *dev_info, int B, int ksize, int shift, const float **taps);

@@ -412,13 +412,14 @@ static int launch_tile_spectrum(pb_ctx *ctx, const ConvPass &p) {
         const int rc = pb_launch_conv_wfft(ctx, p);
         if (rc != PB_ERR_UNSUPPORTED) return rc;
     }
-    if (p.poly != 0 && ctx->poly_built.on == 2)
+    if (p.poly != 0 && ctx->poly_built.on >= 2)
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "one-pass polynomial with per-axis halos: the wave form does not take this pass");
     return pb_launch_conv_fft(ctx, p);
 }
 
 // Which one-pass form a polynomial with these steps may ask for (PolySpec.on): 2 = the composite filter's own halos, where
-// every tile-spectrum launch of the polynomial goes to the wave form (conv_wfft.hip: fp32 / fp16 planes); 1 = kernels
+// every tile-spectrum launch of the polynomial goes to the wave form (conv_wfft.hip); 3 = as 2, and on 128 x 128 windows
+// where those are cheaper still (conv_w128.hip: fp32 / fp16 planes, a launch of its own); 1 = kernels
 // within the 4-sample halo class only (either form); 0 = never (ctx->poly_mode == 0, or a step the form does not suit).
 int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
     if (ctx->poly_mode == 0 || ctx->fft_min_phases < 0) return 0;
@@ -432,7 +433,7 @@ int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
     const bool fold = steps[0].out_dtype == steps[2].out_dtype;
     bool wave = ctx->poly_mode != 1 && ctx->fft_wave && (fold || pb_conv_wfft_types(pc));
     for (int s = 0; s < 3; ++s) wave = wave && pb_conv_wfft_types(steps[s]);
-    if (wave) return 2;
+    if (wave) return (ctx->poly_mode >= 3 && ctx->poly_cost128 > 0.f && pb_conv_w128_types(pc.in_dtype, pc.out_dtype)) ? 3 : 2;
     return (fold || pb_conv_fft_types(pc)) ? 1 : 0;
 }
 
@@ -491,7 +492,30 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
         if (!fft_pass_ok(pc)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "one-pass polynomial: composite pass not feasible");
         return launch_tile_spectrum(ctx, pc);
     };
+    // the images whose one pass runs on 128 x 128 windows (pb_fft_sel.poly == 2): a launch of their own, beside the others
+    auto composite128 = [&](float *k, pb_fft_sel *sel) -> int {
+        if (ctx->poly_want.on != 3) return PB_OK;
+        ConvPass pc = steps[0];
+        pc.out = steps[2].out; pc.out_kind = steps[2].out_kind; pc.out_dtype = steps[2].out_dtype;
+        pc.out_pitch = steps[2].out_pitch; pc.out_plane = steps[2].out_plane;
+        pc.scale = 1.f; pc.coef = 0.f; pc.clamp01 = steps[2].clamp01; pc.poly = 1;
+        pc.khat = k; pc.fsel = sel;
+        const std::vector<pb_fft_sel> *ksel = nullptr;
+        (void)known_flags(ctx, steps[0].info, B, &ksel);
+        ctx->known_sel = ksel;
+        const int rc = pb_launch_conv_w128(ctx, pc);
+        ctx->known_sel = nullptr;
+        return rc;
+    };
     if (!fft || have || !ctx->aux || ctx->prof_on) {
+        if (fft && ctx->poly_want.on == 3) {
+            float *k = nullptr; pb_fft_sel *sel = nullptr;
+            const bool built = (have || ctx->khat_by_estimate) && ctx->khat_owner == steps[0].info && ctx->khat_B == B;
+            int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !built);
+            if (rc) return rc;
+            rc = composite128(k, sel);
+            if (rc) return rc;
+        }
         for (int s = 0; s < 3; ++s) {
             ConvPass p = steps[s];
             p.khat_ready = s > 0;
@@ -517,7 +541,8 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->aux;
     // (the composite pass touches other images than the steps' launches do: it, too, runs -- or finds no work -- beside them)
-    if (poly_on && !fold) rc = composite(k, sel);
+    if (poly_on) rc = composite128(k, sel);
+    if (poly_on && !fold && !rc) rc = composite(k, sel);
     for (int s = 0; s < 3 && !rc; ++s) {
         ConvPass p = steps[s];
         p.khat = k; p.fsel = sel;

@@ -51,7 +51,7 @@ namespace {
 // agreement with the stencil).  Caller-supplied taps that are not point-symmetric keep the stencil body.
 static_assert(KH_NT == KH_THREADS && FT_N == KH_FT_N, "khat.h is written for these");
 __global__ __launch_bounds__(KH_NT) void khat_kernel(const pb_blur_info *infos, float *khat, pb_fft_sel *sel, int min_phases, const PolySpec ps) {
-    khat_body(infos + blockIdx.x, khat + (long)blockIdx.x * (FT_N * FT_N), sel + blockIdx.x, min_phases, (int)blockIdx.y, ps);
+    khat_body(infos + blockIdx.x, khat + (long)blockIdx.x * PB_KHAT_STRIDE, sel + blockIdx.x, min_phases, (int)blockIdx.y, ps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(FT_NT, 4) void conv_fft_kernel(const ConvPass a, co
     if (__builtin_amdgcn_readfirstlane(j1) == local - xcd * per || local >= g.njobs[c]) return;
     const int ty = __builtin_amdgcn_readfirstlane(div_small(local, g.inv_pairs_x[c])), pxi = local - ty * g.pairs_x[c];
     const ConvPass af = fold_pass(a, a.poly == 2 && sel->poly != 0);
-    window_pair<TIn, TX, TOut>(af, a.info + img, plane, ty, pxi, R, Z, a.khat + (long)img * (FT_N * FT_N));
+    window_pair<TIn, TX, TOut>(af, a.info + img, plane, ty, pxi, R, Z, a.khat + (long)img * PB_KHAT_STRIDE);
 }
 
 
@@ -335,7 +335,7 @@ int launch_fft_typed(pb_ctx *ctx, const ConvPass &p) {
 
 // Spectra + per-image body selection for the B images of `info` (B = P / C).
 int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel) {
-    float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat", sizeof(float) * FT_N * FT_N * (size_t)B));
+    float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat", sizeof(float) * PB_KHAT_STRIDE * (size_t)B));
     // (one slot of selections per iteration of the call in progress, so that pb_body_selection can report every iteration's)
     pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel", sizeof(pb_fft_sel) * (size_t)B * PB_SEL_SLOTS));
     if (!k || !s) return PB_ERR_NOMEM;

@@ -1,0 +1,383 @@
+// Tile-spectrum body of the one-pass polynomial on 128 x 128 windows: FOUR waves per window pair.
+//
+// Same pass, same operands, same result as the one-pass form of conv_wfft.hip (the whole polynomial a3 K^3 + a2 K^2 + a1 K + b
+// of the deconvolution as ONE circular correlation per window -- the reference's own 'fft' form, deblurring.py:139-169 -- with
+// the boundary models of filters.py:14-49 applied when the window is loaded): forward 2-D DFT, product with the polynomial's
+// real spectrum (khat128_body, khat.h), inverse DFT, of which the samples at least (hx, hy) from the window's edge are
+// kept (overlap-save); two horizontally adjacent real windows ride one complex transform, z = A + iB.
+//
+// Why a second window size.  The composite filter's halo is sqrt(3) times the kernel's: 20 x 24 samples for the headline's
+// first estimate (sigma 2.1 / rho 1.3 at 66 degrees).  A 64 x 64 window keeps 24 x 16 of its 4096 samples then -- three
+// Horner passes with the kernel's own 12-sample halo are cheaper --, a 128 x 128 window keeps 88 x 80 of 16384: 43 % in ONE
+// pass against 39 % in each of three.
+//
+// Who does it.  A lane still holds 64 complex values, so a 128-point line is shared by the two halves of a wave: lanes l and
+// l + 32 hold its two halves, exchange them with v_permlane32_swap for ONE radix-2 step (decimation in frequency forward,
+// in time backward; twiddles are compile-time constants: the step's index is the register number) and run the 64-point
+// transform of conv_wave_common.h on what they then hold.  A wave therefore owns 32 lines, a workgroup of four waves the 128:
+//
+//   load      wave w, lane (c, h): window column 32 w + c, rows 64 h .. 64 h + 63 in the registers
+//   columns   radix-2 across the wave's halves, fft64 in registers: the lower lanes hold the even, the upper the odd frequencies
+//   transpose through the workgroup's LDS matrix: lane (row slot, x half) holds 64 consecutive columns of one transformed row
+//   rows      radix-2, fft64, x real spectrum, inverse fft64, inverse radix-2
+//   transpose back, inverse column transform, epilogue (clamp, store)
+//
+// The transposes move 128 KB through 66 KB of LDS (two workgroups per CU: eight waves, two per SIMD, as in conv_wfft.hip) in
+// two rounds: every lane sends half its registers, the waves whose rows those are receive theirs -- 64 values per lane, 32
+// into the registers just freed and 32 into a spare set, which is why the window pair's 128 registers leave room for
+// this at all --, then the other half.  Four workgroup barriers per transpose.
+// No MFMA, no library FFT.
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "conv_wave_common.h"
+
+namespace {
+
+constexpr int W_N = 128;            // window side
+constexpr int W_P = 129;            // LDS row pitch in complex values (rows of 128 plus one: conflict-free both ways)
+constexpr size_t kW128Lds = sizeof(float2) * 64 * W_P;
+
+// cos / sin (2 pi m / 128), m = 0 .. 63: indexed with compile-time constants only
+static __device__ const float kC128[64] = {
+    1.0f, 0.9987954497337341f, 0.9951847195625305f, 0.9891765117645264f, 0.9807852506637573f, 0.9700312614440918f,
+    0.9569403529167175f, 0.9415440559387207f, 0.9238795042037964f, 0.903989315032959f, 0.8819212913513184f, 0.8577286005020142f,
+    0.8314695954322815f, 0.803207516670227f, 0.7730104327201843f, 0.7409511208534241f, 0.7071067690849304f, 0.6715589761734009f,
+    0.6343932747840881f, 0.5956993103027344f, 0.5555702447891235f, 0.5141027569770813f, 0.4713967442512512f, 0.4275550842285156f,
+    0.3826834261417389f, 0.3368898630142212f, 0.290284663438797f, 0.24298018217086792f, 0.19509032368659973f, 0.1467304676771164f,
+    0.0980171412229538f, 0.049067676067352295f, 6.123234262925839e-17f, -0.049067676067352295f, -0.0980171412229538f, -0.1467304676771164f,
+    -0.19509032368659973f, -0.24298018217086792f, -0.290284663438797f, -0.3368898630142212f, -0.3826834261417389f, -0.4275550842285156f,
+    -0.4713967442512512f, -0.5141027569770813f, -0.5555702447891235f, -0.5956993103027344f, -0.6343932747840881f, -0.6715589761734009f,
+    -0.7071067690849304f, -0.7409511208534241f, -0.7730104327201843f, -0.803207516670227f, -0.8314695954322815f, -0.8577286005020142f,
+    -0.8819212913513184f, -0.903989315032959f, -0.9238795042037964f, -0.9415440559387207f, -0.9569403529167175f, -0.9700312614440918f,
+    -0.9807852506637573f, -0.9891765117645264f, -0.9951847195625305f, -0.9987954497337341f};
+static __device__ const float kS128[64] = {
+    0.0f, 0.049067676067352295f, 0.0980171412229538f, 0.1467304676771164f, 0.19509032368659973f, 0.24298018217086792f,
+    0.290284663438797f, 0.3368898630142212f, 0.3826834261417389f, 0.4275550842285156f, 0.4713967442512512f, 0.5141027569770813f,
+    0.5555702447891235f, 0.5956993103027344f, 0.6343932747840881f, 0.6715589761734009f, 0.7071067690849304f, 0.7409511208534241f,
+    0.7730104327201843f, 0.803207516670227f, 0.8314695954322815f, 0.8577286005020142f, 0.8819212913513184f, 0.903989315032959f,
+    0.9238795042037964f, 0.9415440559387207f, 0.9569403529167175f, 0.9700312614440918f, 0.9807852506637573f, 0.9891765117645264f,
+    0.9951847195625305f, 0.9987954497337341f, 1.0f, 0.9987954497337341f, 0.9951847195625305f, 0.9891765117645264f,
+    0.9807852506637573f, 0.9700312614440918f, 0.9569403529167175f, 0.9415440559387207f, 0.9238795042037964f, 0.903989315032959f,
+    0.8819212913513184f, 0.8577286005020142f, 0.8314695954322815f, 0.803207516670227f, 0.7730104327201843f, 0.7409511208534241f,
+    0.7071067690849304f, 0.6715589761734009f, 0.6343932747840881f, 0.5956993103027344f, 0.5555702447891235f, 0.5141027569770813f,
+    0.4713967442512512f, 0.4275550842285156f, 0.3826834261417389f, 0.3368898630142212f, 0.290284663438797f, 0.24298018217086792f,
+    0.19509032368659973f, 0.1467304676771164f, 0.0980171412229538f, 0.049067676067352295f};
+
+// One radix-2 step between the halves of a wave.  Forward (decimation in frequency): lanes l < 32 hold a[r], lanes l + 32
+// hold b[r] = the sample 64 further on (r = register); afterwards the lower lanes hold a + b -- the input of the even
+// frequencies' 64-point transform -- and the upper (a - b) W128^r, that of the odd ones.  sg = +1 in the lower lanes, -1 in
+// the upper.
+__device__ __forceinline__ void r2_fwd(cf (&v)[64], bool upper, float sg) {
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        cf a = v[r], b = v[r];
+        swap_halves(a, b);                                     // a: the lower lanes' value in every lane, b: the upper lanes'
+        v[r] = a + b * sg;
+    }
+    if (upper) {
+#pragma unroll
+        for (int r = 1; r < 64; ++r) v[r] = cmul_s(v[r], (cf){kC128[r], -kS128[r]});
+    }
+}
+// Backward (decimation in time): the lower lanes hold e[r], the upper o[r]; afterwards the lower hold e + o conj(W128^r), the
+// upper e - o conj(W128^r) (the sample 64 further on).  Unnormalised.
+__device__ __forceinline__ void r2_inv(cf (&v)[64], bool upper, float sg) {
+    if (upper) {
+#pragma unroll
+        for (int r = 1; r < 64; ++r) v[r] = cmul_conj_s(v[r], (cf){kC128[r], -kS128[r]});
+    }
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        cf a = v[r], b = v[r];
+        swap_halves(a, b);
+        v[r] = a + b * sg;
+    }
+}
+
+// Column layout -> row layout.  Before: wave w, lane (c, h) holds, in register g, the element (column x = 32 w + c, row slot
+// 2 g + h).  After: wave w, lane (j, hh) holds, in register c, the element (row slot 32 w + j, column 64 hh + c).
+// Z: the workgroup's matrix, 64 slots x W_P.  Round A: every lane sends its registers 0 .. 31 (slots 0 .. 63: the rows of waves
+// 0 and 1, which receive 64 values per lane -- 32 into the registers they have just sent, 32 into `s`); round B: registers
+// 32 .. 63 (waves 2 and 3 receive into all 64; waves 0 and 1 move the spare set into the registers they have just sent).
+__device__ __forceinline__ void transpose_c2r(cf (&v)[64], float2 *Z, int w, int lane) {
+    const int c = lane & 31, h = lane >> 5, x = 32 * w + c;
+    const float2 *rd = Z + (32 * (w & 1) + c) * W_P + 64 * h;   // (as receiver: slot 32 (w & 1) + j, j = lane & 31; x half = lane >> 5)
+    cf s[32];
+#pragma unroll
+    for (int g = 0; g < 32; ++g) Z[(2 * g + h) * W_P + x] = pbfft::to_f2(v[g]);
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { v[i] = pbfft::to_cf(rd[i]); s[i] = pbfft::to_cf(rd[32 + i]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 32; ++g) Z[(2 * g + h) * W_P + x] = pbfft::to_f2(v[32 + g]);
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[32 + i] = s[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = pbfft::to_cf(rd[i]);
+    }
+    __syncthreads();
+}
+
+// Row layout -> column layout (the way back).  Before: wave w, lane (j, hh), register c = element (slot 32 w + j, column
+// 64 hh + c); after: wave w, lane (c, h), register g = element (column 32 w + c, slot 2 g + h).  Z: 64 columns x W_P slots.
+// Round A: registers 0 .. 31 = columns 0 .. 31 and 64 .. 95: the columns of waves 0 and 2; round B: the rest, waves 1 and 3.
+__device__ __forceinline__ void transpose_r2c(cf (&v)[64], float2 *Z, int w, int lane) {
+    const int j = lane & 31, hh = lane >> 5, slot = 32 * w + j;
+    const int c = lane & 31, h = lane >> 5;                    // (as receiver)
+    const float2 *rd = Z + (32 * (w >> 1) + c) * W_P + h;       // column index in the round's matrix: 32 (x half) + c; slots 2 g + h
+    cf s[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) Z[(32 * hh + i) * W_P + slot] = pbfft::to_f2(v[i]);
+    __syncthreads();
+    if (!(w & 1)) {
+#pragma unroll
+        for (int g = 0; g < 32; ++g) { v[g] = pbfft::to_cf(rd[2 * g]); s[g] = pbfft::to_cf(rd[2 * (32 + g)]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) Z[(32 * hh + i) * W_P + slot] = pbfft::to_f2(v[32 + i]);
+    __syncthreads();
+    if (!(w & 1)) {
+#pragma unroll
+        for (int g = 0; g < 32; ++g) v[32 + g] = s[g];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 64; ++g) v[g] = pbfft::to_cf(rd[2 * g]);
+    }
+    __syncthreads();
+}
+
+struct W128Geom { int ow, oh; };
+struct W128Jobs { int pairs_x, njobs, per; float inv_pairs_x; };
+__device__ __forceinline__ int div_rcp128(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }   // exact for 0 <= n < 2^21
+__device__ __forceinline__ W128Jobs jobs128_of(const W128Geom &g, int hx, int hy) {
+    const int Tx = W_N - 2 * hx, Ty = W_N - 2 * hy;
+    const int tiles_x = div_rcp128(g.ow + Tx - 1, __builtin_amdgcn_rcpf((float)Tx)), tiles_y = div_rcp128(g.oh + Ty - 1, __builtin_amdgcn_rcpf((float)Ty));
+    W128Jobs j;
+    j.pairs_x = (tiles_x + 1) >> 1;
+    j.njobs = j.pairs_x * tiles_y;
+    j.per = (j.njobs + 7) >> 3;
+    j.inv_pairs_x = __builtin_amdgcn_rcpf((float)j.pairs_x);
+    return j;
+}
+
+// One window pair, by the four waves of a workgroup.  Z: the workgroup's LDS matrix; kp: the image's spectrum,
+// [wave][register][lane] (khat128_body).  hx a multiple of 4, hy even; a tile is 128 - 2 hx by 128 - 2 hy outputs.
+template <typename TIn, typename TOut>
+__device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, int pxi, int hx, int hy, float2 *Z, const float *kp) {
+    const int Tx = W_N - 2 * hx, Ty = W_N - 2 * hy;
+    const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
+    const bool upper = h != 0;
+    const float sg = upper ? -1.f : 1.f;
+    const OutRegion rg = out_region(a);
+    const int oy0 = rg.y_lo + ty * Ty, wy0 = oy0 - hy;              // first output row / first window row, padded coordinates
+    const int wxA = rg.x_lo + 2 * pxi * Tx - hx, wxB = wxA + Tx;
+    const bool hasB = wxB + hx < rg.x_hi;
+    const int x = 32 * w + c;                                       // this lane's window column
+    const TIn *ipl = static_cast<const TIn *>(a.in) + (long)plane * a.in_plane;
+    TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
+    cf v[64];
+
+    // ---- the window: lane = (column, half), register r = row 64 h + r ----
+    {
+        const brsrc rin = plane_rsrc(ipl, a.in_plane);
+        const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
+        const int pitchb = a.in_pitch * (int)sizeof(TIn);
+        if (wy0 >= lo && wy0 + W_N <= Hp - lo && wxA >= lo && wxB + W_N <= Wp - lo && hasB) {
+            // both windows inside the source: one offset per lane, the row in the scalar offset
+            const unsigned colA = (unsigned)((wy0 - lo + 64 * h) * pitchb + (wxA - lo + x) * (int)sizeof(TIn));
+            const unsigned colB = colA + (unsigned)(Tx * (int)sizeof(TIn));
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                const int r = 8 * (q & 7) + (q >> 3);
+                v[r] = (cf){BufIO<TIn>::ld(rin, colA, r * pitchb), BufIO<TIn>::ld(rin, colB, r * pitchb)};
+            }
+        } else {
+            // border window: columns mapped through the boundary model once per lane, rows on the scalar side (one per half)
+            const int ixa = map_axis(wxA + x, a.W, a.in_kind, a.boundary, a.pad);
+            const int ixb = hasB ? map_axis(wxB + x, a.W, a.in_kind, a.boundary, a.pad) : -1;
+            const unsigned colA = ixa >= 0 ? (unsigned)ixa * (unsigned)sizeof(TIn) : kNoAccess;
+            const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
+            const bool wrap = a.boundary == PB_WRAP;
+            const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(wy0, Hp)) : wy0;
+            auto rowmap = [&](int p, bool &ok) -> int {
+                if (wrap) { while (p < 0) p += Hp; while (p >= Hp) p -= Hp; }
+                ok = wrap || (p >= 0 && p < Hp);
+                return ok ? (a.in_kind == SRC_VIRTUAL ? min(max(p - a.pad, 0), a.H - 1) : p) : 0;
+            };
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                const int r = 8 * (q & 7) + (q >> 3);
+                bool ok0, ok1;
+                const int i0 = rowmap(base + r, ok0), i1 = rowmap(base + 64 + r, ok1);
+                const bool ok = upper ? ok1 : ok0;
+                const unsigned ro_ = (unsigned)((upper ? i1 : i0) * pitchb);
+                v[r] = (cf){BufIO<TIn>::ld(rin, ok && colA != kNoAccess ? colA + ro_ : kNoAccess, 0),
+                            BufIO<TIn>::ld(rin, ok && colB != kNoAccess ? colB + ro_ : kNoAccess, 0)};
+            }
+        }
+    }
+    r2_fwd(v, upper, sg);                                           // columns
+    fft64_fwd(v);
+    transpose_c2r(v, Z, w, lane);
+    {
+        // rows: radix-2 across the halves (columns x and x + 64), 64-point transform, x spectrum, and back.  The spectrum's 64
+        // values per lane travel in a ring of four groups of eight, as in conv_wfft.hip.
+        const brsrc rk = plane_rsrc(kp, (long)W_N * W_N);
+        float kh[4][8];
+        auto khload = [&](int grp) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) kh[grp & 3][k2] = BufIO<float>::ld(rk, (unsigned)lane * 4u, ((w * 64 + 8 * grp + k2) * 64) * 4);
+        };
+        khload(0); khload(1); khload(2); khload(3);
+        __builtin_amdgcn_sched_barrier(0);
+        r2_fwd(v, upper, sg);
+        fft64_fwd_stage1(v);
+        centre_stage<0>(v, kh[0]); khload(4); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<1>(v, kh[1]); khload(5); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<2>(v, kh[2]); khload(6); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<3>(v, kh[3]); khload(7); __builtin_amdgcn_sched_barrier(0);
+        centre_stage<4>(v, kh[0]); centre_stage<5>(v, kh[1]); centre_stage<6>(v, kh[2]); centre_stage<7>(v, kh[3]);
+        fft64_inv_stage1(v);
+        r2_inv(v, upper, sg);
+    }
+    transpose_r2c(v, Z, w, lane);
+    fft64_inv_stage2(v);                                            // columns
+    fft64_inv_stage1(v);
+    r2_inv(v, upper, sg);
+
+    // ---- epilogue: lane = (column, half) again, register r = window row 64 h + r; the polynomial carries its own b x ----
+    {
+        const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
+        const int opitchb = a.out_pitch * (int)sizeof(TOut);
+        const brsrc ro = plane_rsrc(opl, a.out_plane);
+        const bool colin = x >= hx && x < W_N - hx;
+        const int pxA = wxA + x, pxB = wxB + x;
+        const bool okA = colin && pxA < rg.x_hi, okB = colin && hasB && pxB < rg.x_hi;
+        const float sc = a.scale;
+        const float clo = a.clamp01 ? 0.f : -INFINITY, chi = a.clamp01 ? 1.f : INFINITY;
+        const int row0 = 64 * h;                                    // this lane's first window row
+        // rows of the tile: hy <= 64 h + r < 128 - hy, and inside the output region.  (The lane's offset is that of its FIRST
+        // row of the tile -- the window's first rows lie above the output plane for the first tiles -- and a row's offset
+        // relative to it goes into the scalar offset.)
+        const int rlo = max(hy - row0, 0), rhi = min(min(W_N - hy, rg.y_hi - wy0) - row0, 64);
+        const unsigned baseA = okA && rlo < rhi ? (unsigned)((wy0 + row0 + rlo - oo) * opitchb + (pxA - oo) * (int)sizeof(TOut)) : kNoAccess;
+        const unsigned baseB = okB && rlo < rhi ? (unsigned)((wy0 + row0 + rlo - oo) * opitchb + (pxB - oo) * (int)sizeof(TOut)) : kNoAccess;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const bool rok = r >= rlo && r < rhi;
+            const float ra = __builtin_amdgcn_fmed3f(sc * v[r].x, clo, chi), rb = __builtin_amdgcn_fmed3f(sc * v[r].y, clo, chi);
+            BufIO<TOut>::st(ro, rok ? baseA + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, ra);
+            BufIO<TOut>::st(ro, rok ? baseB + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, rb);
+        }
+    }
+}
+
+// One workgroup of four waves per window pair; the GRID is the job list, as in conv_wfft.hip: workgroup b belongs to list
+// b % 8 (the XCD it is observed to run on) at position b / 8, every list owns the same contiguous eighth of every plane's
+// pairs, images in order; the jobs are the window pairs of the images whose record says "one pass on 128 x 128 windows"
+// (pb_fft_sel.poly == 2), each with its own halos.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256, 2) void conv_w128_kernel(const ConvPass a, const W128Geom g) {
+    extern __shared__ __attribute__((aligned(16))) float2 Zw[];
+    const int lane = threadIdx.x & 63;
+    const int C = a.C, B = a.P / C;
+    const int q = (int)(blockIdx.x & 7u);
+    int rem = (int)(blockIdx.x >> 3);
+    int img = 0, hx = 0, hy = 0;
+    if (B == 1) {
+        const PB_CONSTANT pb_fft_sel *s0 = as_constant(a.fsel);
+        if (!s0->use_fft || s0->poly != 2) return;
+        hx = s0->hx; hy = s0->hy;
+    } else {
+        auto share_of = [&](int i) -> int {
+            if (i >= B) return 0;
+            const pb_fft_sel s = a.fsel[i];
+            if (!s.use_fft || s.poly != 2) return 0;
+            return jobs128_of(g, s.hx, s.hy).per * C;
+        };
+        bool work = false;
+        int base = 0;
+        for (int c0 = 0; c0 < B; c0 += 64) {
+            const int n = share_of(c0 + lane), incl = wave_scan(n, lane);
+            const unsigned long long m = __ballot(base + incl > rem);
+            if (m) {
+                const int l = __builtin_ctzll(m);
+                img = c0 + l;
+                rem -= base + (__builtin_amdgcn_readlane(incl, l) - __builtin_amdgcn_readlane(n, l));
+                work = true;
+                break;
+            }
+            base += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (!work) return;
+        img = __builtin_amdgcn_readfirstlane(img); rem = __builtin_amdgcn_readfirstlane(rem);
+        hx = as_constant(a.fsel + img)->hx; hy = as_constant(a.fsel + img)->hy;
+    }
+    const W128Jobs j = jobs128_of(g, hx, hy);
+    const int pl = __builtin_amdgcn_readfirstlane(div_rcp128(rem, __builtin_amdgcn_rcpf((float)j.per)));
+    if (pl >= C) return;
+    const int pair = q * j.per + (rem - pl * j.per);
+    if (pair >= j.njobs) return;
+    const int ty = __builtin_amdgcn_readfirstlane(div_rcp128(pair, j.inv_pairs_x)), pxi = pair - ty * j.pairs_x;
+    w128_pair<TIn, TOut>(a, img * C + pl, ty, pxi, hx, hy, Zw, a.khat + (long)img * PB_KHAT_STRIDE);
+}
+
+template <typename TIn, typename TOut>
+int launch_w128_typed(pb_ctx *ctx, const ConvPass &p, const W128Geom &g, long groups) {
+    hipLaunchKernelGGL((conv_w128_kernel<TIn, TOut>), dim3((unsigned)groups), dim3(256), kW128Lds, ctx->stream, p, g);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+}  // namespace
+
+bool pb_conv_w128_types(int in_dtype, int out_dtype) { return in_dtype != PB_U8 && out_dtype != PB_U8; }
+
+// The one-pass polynomial of the images whose record selects 128 x 128 windows (pb_fft_sel.poly == 2): from the first step's
+// input to the last step's output (p: the composite pass -- scale 1, no x operand, the last step's clamp).
+int pb_launch_conv_w128(pb_ctx *ctx, const ConvPass &p) {
+    W128Geom g;
+    g.oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * p.pad;
+    g.ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * p.pad;
+    // the job list: exactly the images' where the host has their records, else the largest their halos may ask for
+    // (tiles of at least PB_POLY128_MIN_T samples per side)
+    long groups = 0;
+    const int B = p.P / p.C;
+    auto per_of = [&](int hx, int hy) -> long {
+        const int tx = W_N - 2 * hx, ty = W_N - 2 * hy;
+        const long nj = (long)(((g.ow + tx - 1) / tx + 1) / 2) * ((g.oh + ty - 1) / ty);
+        return (nj + 7) / 8;
+    };
+    if (ctx->known_sel) {
+        long per_sum = 0;
+        for (int b = 0; b < B && b < (int)ctx->known_sel->size(); ++b) {
+            const pb_fft_sel &e = (*ctx->known_sel)[(size_t)b];
+            if (e.use_fft && e.poly == 2) per_sum += per_of(e.hx, e.hy);
+        }
+        if (!per_sum) return PB_OK;
+        groups = 8L * per_sum * p.C;
+    } else {
+        const int hmax = (W_N - PB_POLY128_MIN_T) / 2;
+        groups = 8L * per_of(hmax, hmax) * p.P;
+    }
+    if (groups <= 0 || groups > (1L << 23)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "conv pass: too many 128 x 128 windows");
+    ProfScope prof(ctx, PB_PROF_CONV_FFT);
+    switch (p.in_dtype * 3 + p.out_dtype) {
+        case 0: return launch_w128_typed<float, float>(ctx, p, g, groups);
+        case 1: return launch_w128_typed<float, __half>(ctx, p, g, groups);
+        case 3: return launch_w128_typed<__half, float>(ctx, p, g, groups);
+        case 4: return launch_w128_typed<__half, __half>(ctx, p, g, groups);
+        default: return PB_ERR_UNSUPPORTED;
+    }
+}

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     if (B == 1) {
         // (one image: its record is read on the scalar side -- no trip through the vector memory queue)
         const PB_CONSTANT pb_fft_sel *s0 = as_constant(a.fsel);
-        if (!s0->use_fft || !poly_match(a.poly, s0->poly)) return;
+        if (!s0->use_fft || s0->poly == 2 || !poly_match(a.poly, s0->poly)) return;     // (poly == 2: conv_w128.hip's image)
         hx = s0->hx; hy = s0->hy;
         fold = a.poly == 2 && s0->poly != 0;
     } else {
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
         auto share_of = [&](int i) -> int {
             if (i >= B) return 0;
             const pb_fft_sel s = a.fsel[i];
-            if (!s.use_fft || !poly_match(a.poly, s.poly)) return 0;
+            if (!s.use_fft || s.poly == 2 || !poly_match(a.poly, s.poly)) return 0;
             return jobs_of(g, s.hx, s.hy).per * C;
         };
         bool work = false;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     if (pair >= j.njobs) return;                       // (the ragged end of the last list's run)
     const int ty = __builtin_amdgcn_readfirstlane(div_rcp(pair, j.inv_pairs_x)), pxi = pair - ty * j.pairs_x;
     const int plane = img * C + pl;
-    const float *kp = a.khat + (long)img * (FT_N * FT_N);
+    const float *kp = a.khat + (long)img * PB_KHAT_STRIDE;
     const pb_blur_info *info = a.info + img;
     const ConvPass af = fold_pass(a, fold);
     if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<true, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
@@ -609,7 +609,7 @@ bool pb_conv_wfft_types(const ConvPass &p) {
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
     static const long min_jobs = [] { const char *e = getenv("PB_WAVE_MIN_JOBS"); return e ? atol(e) : 0L; }();
     if (!pb_conv_wfft_types(p)) return PB_ERR_UNSUPPORTED;
-    const bool poly2 = p.poly != 0 && ctx->poly_built.on == 2;
+    const bool poly2 = p.poly != 0 && ctx->poly_built.on >= 2;
     const float min_area = (float)ctx->poly_min_area;      // (the smallest one-pass tile the cost model of khat.h admits)
     WGeom g;
     long per_max = 0, pairs12 = 0;
@@ -626,7 +626,7 @@ int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
         jobs = 0;
         for (int b = 0; b < B && b < (int)ctx->known_sel->size(); ++b) {
             const pb_fft_sel &e = (*ctx->known_sel)[(size_t)b];
-            const bool takes = e.use_fft && (p.poly == 2 || (e.poly != 0) == (p.poly != 0));      // (poly_match, conv_fft_common.h)
+            const bool takes = e.use_fft && e.poly != 2 && (p.poly == 2 || (e.poly != 0) == (p.poly != 0));      // (poly_match, conv_fft_common.h)
             if (!takes) continue;
             const int tx = FT_N - 2 * e.hx, ty = FT_N - 2 * e.hy;
             const long nj = (long)(((g.ow + tx - 1) / tx + 1) / 2) * ((g.oh + ty - 1) / ty);

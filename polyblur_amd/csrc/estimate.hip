@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     // redundant latency-bound work, identical values) and now forms its slice -- one launch less on every iteration's
     // critical path than a kernel of its own behind this one.
     if (khat)      // (the record as finish_record left it in LDS: no wait for its stores, no read back)
-        khat_body(info, khat + (long)blockIdx.x * (KH_FT_N * KH_FT_N), fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps, &rl);
+        khat_body(info, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps, &rl);
 }
 
 // method='direct_separable': the two correlation kernels of the x-t separable approximation of the image's Gaussian

@@ -53,6 +53,47 @@ constexpr int KH_SLICES = 8;          // workgroups per image: each forms the sp
 // parameter kernel): no wait for the record's stores to land, no read back.
 struct RecLds { const float *taps; int radius, nph, separable; };
 
+// The polynomial's spectrum on the 128 x 128 grid, in the order conv_w128.hip reads it: [wave w][register][lane], where in
+// the row phase wave w, lane (j, hh) holds row slot 32 w + j -- the slot 2 g + h is the column transform's register g in
+// lane half h, i.e. frequency fy = 2 K(g) + h with K(g) = (g >> 3) + 8 (g & 7) the 64-point transform's register order -- and
+// register `reg` of lane half hh holds fx = 2 K(reg) + hh.  Slice s of KH_SLICES forms registers 8 s .. 8 s + 7 (16 fx
+// values).  sk: the taps in LDS (zero outside the record's box); both transforms' 1/128 folded in.  Called by all KH_THREADS.
+__device__ __forceinline__ void khat128_body(const float *sk, float *out, int slice, const PolySpec ps) {
+    constexpr int NU = PB_KRAD + 1, NX = 16;
+    __shared__ double2 G8[NU * NX];
+    __shared__ double c8[128], s8[128];
+    const int tid = threadIdx.x;
+    if (tid < 128) { c8[tid] = cospi((double)tid / 64.0); s8[tid] = sinpi((double)tid / 64.0); }
+    __syncthreads();
+    auto K64 = [](int g) { return (g >> 3) + 8 * (g & 7); };
+    if (tid < NU * NX) {
+        const int u = tid / NX + PB_KRAD, xi = tid % NX, reg = 8 * slice + (xi >> 1), fx = 2 * K64(reg) + (xi & 1);
+        double ar = 0.0, ai = 0.0;
+#pragma unroll 5
+        for (int v = 0; v < PB_KSIZE; ++v) {
+            const int m = (fx * (v - PB_KRAD)) & 127;
+            const double k = (double)sk[u * PB_KSIZE + v];
+            ar += k * c8[m]; ai += k * s8[m];
+        }
+        G8[tid] = make_double2(ar, ai);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NX * 128; idx += KH_THREADS) {
+        const int xi = idx >> 7, s = idx & 127, fy = 2 * K64(s >> 1) + (s & 1);
+        double ar = 0.5 * G8[xi].x;
+#pragma unroll 4
+        for (int u = 1; u < NU; ++u) {
+            const int m = (fy * u) & 127;
+            const double2 g = G8[u * NX + xi];
+            ar += g.x * c8[m] - g.y * s8[m];
+        }
+        double v = 2.0 * ar;                                              // the kernel's transform at (fx, fy): real
+        v = (((double)ps.a3 * v + (double)ps.a2) * v + (double)ps.a1) * v + (double)ps.b;
+        const int reg = 8 * slice + (xi >> 1), hh = xi & 1, w = s >> 5, j = s & 31;
+        out[(w * 64 + reg) * 64 + j + 32 * hh] = (float)(v * (1.0 / 16384.0));
+    }
+}
+
 // Smallest r with  sum_{|i - n| > r} m[i] < tol  for the 2n+1 non-negative values m[0 .. 2n] (n <= 63): one wave, lane l
 // holds the pair of offsets +-(63 - l), a prefix sum over the lanes is the tail beyond each offset.
 template <typename F> __device__ __forceinline__ int tail_radius(F m, int n, float tol, int lane) {
@@ -166,25 +207,31 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     // image would take otherwise -- three passes over windows with the kernel's halos (window counts compared; a one-pass
     // window needs no x operand, and the pass moves 2 words per sample instead of 8: `gain`), or the stencil bodies
     // (`min_area`: the tile area from which one window pass beats three stencil passes).
-    bool poly = false;
+    bool poly = false, poly128 = false;
     if (ps.on == 1) poly = symm && Rh <= 4 && max(hxp, hyp) <= 12;
-    if (ps.on == 2 && symm) {
+    if (ps.on >= 2 && symm) {
         const int txp = KH_FT_N - 2 * hxp, typ = KH_FT_N - 2 * hyp;
-        if (txp >= PB_POLY_MIN_TX && typ >= PB_POLY_MIN_TY) {
-            // (min_area also bounds the job grid: a launch that may carry one-pass images is sized for tiles of that area, and
-            // with records built on the device every surplus workgroup is dispatched to find that out)
-            const float ap = (float)(txp * typ), ak = (float)((KH_FT_N - 2 * hxk) * (KH_FT_N - 2 * hyk));
-            poly = ap >= (float)ps.min_area && (!use3 || 3.f * ps.gain * ap >= ak);
-        }
+        // (min_area also bounds the job grid: a launch that may carry one-pass images is sized for tiles of that area, and
+        // with records built on the device every surplus workgroup is dispatched to find that out)
+        const float ak = (float)((KH_FT_N - 2 * hxk) * (KH_FT_N - 2 * hyk));
+        // cost of each form in 64 x 64 window pairs per output sample (a stencil evaluation counts like one pass at min_area)
+        const float c3 = use3 ? 3.f / (ps.gain * ak) : 1.f / (float)ps.min_area;
+        float c64 = INFINITY, c128 = INFINITY;
+        if (txp >= PB_POLY_MIN_TX && typ >= PB_POLY_MIN_TY && txp * typ >= ps.min_area) c64 = 1.f / (float)(txp * typ);
+        const int tx8 = 2 * KH_FT_N - 2 * hxp, ty8 = 2 * KH_FT_N - 2 * hyp;
+        if (ps.on == 3 && ps.cost128 > 0.f && tx8 >= PB_POLY128_MIN_T && ty8 >= PB_POLY128_MIN_T) c128 = ps.cost128 / (float)(tx8 * ty8);
+        poly128 = c128 < c64 && c128 < c3;
+        poly = poly128 || c64 <= c3;
     }
     const bool use = poly || use3;
     if (tid == 0 && slice == 0) {
         sel->use_fft = use ? 1 : 0;
         sel->rf = poly ? (ps.on == 1 ? 12 : 0) : Rh;
         sel->hx = poly ? hxp : hxk; sel->hy = poly ? hyp : hyk;
-        sel->strip = (separable != 0 && R > 8) ? 1 : 0; sel->poly = poly ? 1 : 0;
+        sel->strip = (separable != 0 && R > 8) ? 1 : 0; sel->poly = poly128 ? 2 : (poly ? 1 : 0);
         sel->pad_[0] = 0; sel->pad_[1] = 0;
     }
+    if (poly128) { khat128_body(sk, out, slice, ps); return; }
     if (!use) return;
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
     // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u}); this workgroup's x positions only

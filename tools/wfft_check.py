@@ -36,7 +36,7 @@ def make(mode):
             os.environ["PB_POLY1"] = old
 
 
-one, three = make(2), make(0)
+one, three = make(int(os.environ.get("WFFT_CHECK_MODE", "3"))), make(0)
 KERNELS = [  # theta deg, sigma, rho
     (66.0, 2.095, 1.314), (66.0, 1.656, 1.009), (66.0, 1.24, 0.625), (0.0, 2.0, 1.0), (0.0, 1.4, 0.9), (30.0, 0.65, 0.40),
     (0.0, 0.3, 0.3), (45.0, 3.0, 1.0), (0.0, 4.0, 4.0), (90.0, 1.2, 0.5), (120.0, 0.9, 0.5),
