@@ -342,7 +342,7 @@ int launch_w128_typed(pb_ctx *ctx, const ConvPass &p, const W128Geom &g, long gr
 
 }  // namespace
 
-bool pb_conv_w128_types(int in_dtype, int out_dtype) { return in_dtype != PB_U8 && out_dtype != PB_U8; }
+bool pb_conv_w128_types(int in_dtype, int out_dtype) { return in_dtype >= 0 && in_dtype <= 2 && out_dtype >= 0 && out_dtype <= 2; }
 
 // The one-pass polynomial of the images whose record selects 128 x 128 windows (pb_fft_sel.poly == 2): from the first step's
 // input to the last step's output (p: the composite pass -- scale 1, no x operand, the last step's clamp).
@@ -378,6 +378,11 @@ int pb_launch_conv_w128(pb_ctx *ctx, const ConvPass &p) {
         case 1: return launch_w128_typed<float, __half>(ctx, p, g, groups);
         case 3: return launch_w128_typed<__half, float>(ctx, p, g, groups);
         case 4: return launch_w128_typed<__half, __half>(ctx, p, g, groups);
+        case 2: return launch_w128_typed<float, unsigned char>(ctx, p, g, groups);
+        case 5: return launch_w128_typed<__half, unsigned char>(ctx, p, g, groups);
+        case 6: return launch_w128_typed<unsigned char, float>(ctx, p, g, groups);
+        case 7: return launch_w128_typed<unsigned char, __half>(ctx, p, g, groups);
+        case 8: return launch_w128_typed<unsigned char, unsigned char>(ctx, p, g, groups);
         default: return PB_ERR_UNSUPPORTED;
     }
 }

@@ -1,5 +1,5 @@
-"""GPU parity of the tile-spectrum wave body with per-axis run-time halos and of the general one-pass polynomial
-(csrc/conv_wfft.hip, csrc/khat.h; round 4).
+"""GPU parity of the tile-spectrum wave body with per-axis run-time halos and of the general one-pass polynomial, on 64 x 64
+and on 128 x 128 windows (csrc/conv_wfft.hip, csrc/conv_w128.hip, csrc/khat.h; round 4).
 
 Under the wrap boundary the reference's deconvolution is ONE filter a3 K^3 + a2 K^2 + a1 K + b (its own 'fft' form,
 deblurring.py:139-169).  The engine measures that composite filter's halo per axis (marginals of |taps|, convolution
@@ -34,7 +34,7 @@ def _engine(mode):
 
 @pytest.fixture(scope="module")
 def engines():
-    one, three = _engine(2), _engine(0)
+    one, three = _engine(3), _engine(0)
     yield one, three
     one.close()
     three.close()
@@ -44,16 +44,18 @@ def maxabs(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
 
 
-# (theta deg, sigma, rho) -> what the default context does with it under full support: (one pass?, halo x, halo y)
+# (theta deg, sigma, rho) -> what the default context does with it under full support: (form, halo x, halo y); form 0 = three
+# steps, 1 = one pass on 64 x 64 windows, 2 = one pass on 128 x 128 windows (csrc/conv_w128.hip)
 KERNELS = [
-    ((66.0, 2.095, 1.314), (0, 12, 12)),      # the headline's first estimate: composite halo (20, 24): three steps
-    ((66.0, 1.656, 1.009), (1, 16, 18)),      # its second: one pass, 32 x 28 tiles
-    ((66.0, 1.240, 0.625), (1, 12, 14)),      # its third
-    ((0.0, 1.4, 0.9), (1, 16, 10)),           # rank-1 kernel: its polynomial is not rank-1 -- one pass beats three stencil passes
+    ((66.0, 2.095, 1.314), (2, 20, 24)),      # the headline's first estimate: a 64 x 64 window would keep 24 x 16 samples
+    ((66.0, 1.656, 1.009), (2, 16, 18)),      # its second
+    ((66.0, 1.240, 0.625), (2, 12, 14)),      # its third
+    ((0.0, 1.4, 0.9), (2, 16, 10)),           # rank-1 kernel: its polynomial is not rank-1 -- one pass beats three stencil passes
     ((30.0, 0.65, 0.40), (1, 8, 6)),
     ((0.0, 0.3, 0.3), (1, 4, 4)),             # the clamped isotropic estimate
     ((90.0, 1.2, 0.5), (1, 8, 14)),           # rows much wider than columns
-    ((45.0, 3.0, 1.0), (0, 12, 12)),
+    ((45.0, 3.0, 1.0), (2, 28, 26)),
+    ((0.0, 4.0, 4.0), (0, 12, 12)),           # the widest kernel: composite halo 36 -- three stencil passes
 ]
 
 
@@ -75,7 +77,7 @@ def test_polynomial_against_oracle_and_three_steps(engines, shape, dtype):
             outs.append(eng.inverse_filter(xin, buf, 6.0, 1.0, capi.PB_WRAP).astype(np.float32))
             sel = eng.body_selection(B)
             if eng is one:
-                assert (sel[:, 3] == poly).all() and (not poly or ((sel[:, 4] == hx).all() and (sel[:, 5] == hy).all())), (deg, sg, rh, sel)
+                assert (sel[:, 3] == poly).all() and ((sel[:, 4] == hx).all() and (sel[:, 5] == hy).all()), (deg, sg, rh, sel)
             else:
                 assert (sel[:, 3] == 0).all()
         want = ref.inverse_filtering_rank3(xin.astype(np.float32), info["kernel"][:, None], 6.0, 1.0, method="fft")
@@ -85,26 +87,26 @@ def test_polynomial_against_oracle_and_three_steps(engines, shape, dtype):
 
 
 def test_mixed_batch_and_each_image_alone(engines):
-    """one image per evaluation -- one pass with wide halos, one pass with narrow ones, three tile-spectrum steps, rank-1
-    stencil -- in one batch: every image's result is bit for bit what it gets alone, and the other boundary model and
-    other coefficients rebuild what they need"""
+    """images of both one-pass forms in one batch (128 x 128 and 64 x 64 windows; dense and rank-1 kernels): every image's
+    result is bit for bit what it gets alone, and the other boundary model and other coefficients rebuild what they need"""
     one, _ = engines
-    x, _ = synthetic_blurry_batch(4, 3, 420, 660, seed0=82)
-    sg, rh = [1.656, 0.6, 2.5, 2.0], [1.009, 0.4, 1.2, 1.0]
-    th = [np.float32(np.deg2rad(66.0)), np.float32(0.5), np.float32(1.0), np.float32(0.0)]
+    x, _ = synthetic_blurry_batch(5, 3, 420, 660, seed0=82)
+    sg, rh = [1.656, 0.6, 2.5, 4.0, 4.0], [1.009, 0.4, 1.2, 4.0, 2.0]
+    th = [np.float32(np.deg2rad(66.0)), np.float32(0.5), np.float32(1.0), np.float32(0.0), np.float32(np.deg2rad(45.0))]
     buf = one.make_kernels(sg, rh, th, support=capi.PB_SUPPORT_FULL)
-    info = one.read_info(buf, 4)
+    info = one.read_info(buf, 5)
     k = info["kernel"][:, None]
     got = one.inverse_filter(x, buf, 6.0, 1.0, capi.PB_WRAP)
-    sel = one.body_selection(4)
-    assert sel[:, 3].tolist() == [1, 1, 0, 0] and sel[:, 0].tolist() == [1, 1, 1, 0], sel
+    sel = one.body_selection(5)
+    # 128 x 128 one pass, 64 x 64 one pass, 128 x 128 one pass, three rank-1 stencil passes, three tile-spectrum passes
+    assert sel[:, 3].tolist() == [2, 1, 2, 0, 0] and sel[:, 0].tolist() == [1, 1, 1, 0, 1], sel
     assert maxabs(got, ref.inverse_filtering_rank3(x, k, 6.0, 1.0, method="fft")) < 8e-6
-    for i in range(4):
+    for i in range(5):
         b1 = one.make_kernels(sg[i:i + 1], rh[i:i + 1], th[i:i + 1], support=capi.PB_SUPPORT_FULL, name="one.info")
         alone = one.inverse_filter(x[i:i + 1], b1, 6.0, 1.0, capi.PB_WRAP)
         assert np.array_equal(alone, got[i:i + 1]), i
     got = one.inverse_filter(x, buf, 6.0, 1.0, capi.PB_ZERO)                       # zero boundary: three steps, the kernel's own spectrum
-    assert (one.body_selection(4)[:, 3] == 0).all()
+    assert (one.body_selection(5)[:, 3] == 0).all()
     assert maxabs(got, ref.inverse_filtering_rank3(x, k, 6.0, 1.0, method="direct")) < 8e-6
     got = one.inverse_filter(x, buf, 2.0, 3.0, capi.PB_WRAP)                       # other coefficients: other spectra, other halos
     assert maxabs(got, ref.inverse_filtering_rank3(x, k, 2.0, 3.0, method="fft")) < 8e-6
