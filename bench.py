@@ -398,17 +398,18 @@ def main():
         try:
             for k in range(cfg["n_iter"]):
                 sel = eng.body_selection(B, k)
-                one = sel[(sel[:, 0] == 1) & (sel[:, 3] == 1)]
+                one = sel[(sel[:, 0] == 1) & (sel[:, 3] != 0)]
                 three = sel[(sel[:, 0] == 1) & (sel[:, 3] == 0)]
                 halos = lambda t: sorted({(int(r[4]), int(r[5])) for r in t})[:4]
-                per_it.append(dict(one_pass_images=int(len(one)), one_pass_halos_xy=halos(one), three_step_images=int(len(three)),
+                per_it.append(dict(one_pass_images=int(len(one)), one_pass_on_128x128_windows=int((one[:, 3] == 2).sum()),
+                                   one_pass_halos_xy=halos(one), three_step_images=int(len(three)),
                                    three_step_halos_xy=halos(three), stencil_images=int((sel[:, 0] == 0).sum())))
         except Exception as e:                                   # (a label, not a measurement)
             per_it = [dict(error="%s: %s" % (type(e).__name__, str(e)[:120]))]
         if any(spectrum) or any(p.get("one_pass_images") for p in per_it):
             roofline["kernel"] = (dom_kernel + " (the polynomial of an iteration as three launches, one Horner step each, or -- where the "
-                                  "whole polynomial's filter fits the window -- as ONE window pass; taps as estimated, full 25x25 support; "
-                                  "evaluated per 64x64 window in the frequency domain inside registers / LDS)")
+                                  "whole polynomial's filter fits a 64x64 or a 128x128 window (conv_w128_kernel, same event tag) -- as ONE window pass; "
+                                  "taps as estimated, full 25x25 support; evaluated per window in the frequency domain inside registers / LDS)")
             work = [1 if p.get("one_pass_images") and not p.get("three_step_images") and not p.get("stencil_images") else 3 for p in per_it]
             roofline["body"] = dict(tile_spectrum_images=sum(spectrum), of=len(spectrum), per_iteration=per_it,
                                     working_launches_per_polynomial=round(sum(work) / max(len(work), 1), 2),

@@ -47,27 +47,96 @@ static __device__ const double kSin64[64] = {
     -0.70710678118654768, -0.63439328416364593, -0.55557023301960218, -0.47139673682599792,
     -0.38268343236509039, -0.2902846772544625, -0.19509032201612872, -0.098017140329560506
 };
-constexpr int KH_SLICES = 8;          // workgroups per image: each forms the spectrum at 8 of the 64 x positions
+constexpr int KH_SLICES = 16;          // workgroups per image: each forms the spectrum at 4 of the 64 (8 of the 128) x positions
 
 // What khat_body needs of a record, for a caller that has just formed it and still holds it in LDS (estimate.hip's
 // parameter kernel): no wait for the record's stores to land, no read back.
 struct RecLds { const float *taps; int radius, nph, separable; };
 
+static __device__ const double kCos128[128] = {
+    1.0, 0.9987954562051724, 0.9951847266721969, 0.989176509964781,
+    0.9807852804032304, 0.970031253194544, 0.9569403357322088, 0.9415440651830208,
+    0.9238795325112867, 0.9039892931234433, 0.881921264348355, 0.8577286100002721,
+    0.8314696123025452, 0.8032075314806449, 0.773010453362737, 0.7409511253549591,
+    0.7071067811865476, 0.6715589548470183, 0.6343932841636455, 0.5956993044924335,
+    0.5555702330196023, 0.5141027441932217, 0.4713967368259978, 0.4275550934302822,
+    0.38268343236508984, 0.33688985339222005, 0.29028467725446233, 0.24298017990326398,
+    0.19509032201612833, 0.14673047445536175, 0.09801714032956077, 0.049067674327418126,
+    6.123233995736766e-17, -0.04906767432741801, -0.09801714032956065, -0.14673047445536164,
+    -0.1950903220161282, -0.24298017990326387, -0.29028467725446216, -0.33688985339221994,
+    -0.3826834323650897, -0.42755509343028186, -0.4713967368259977, -0.5141027441932217,
+    -0.555570233019602, -0.5956993044924334, -0.6343932841636454, -0.6715589548470184,
+    -0.7071067811865475, -0.7409511253549589, -0.773010453362737, -0.8032075314806448,
+    -0.8314696123025453, -0.857728610000272, -0.8819212643483549, -0.9039892931234433,
+    -0.9238795325112867, -0.9415440651830207, -0.9569403357322088, -0.970031253194544,
+    -0.9807852804032304, -0.989176509964781, -0.9951847266721968, -0.9987954562051724,
+    -1.0, -0.9987954562051724, -0.9951847266721969, -0.989176509964781,
+    -0.9807852804032304, -0.970031253194544, -0.9569403357322089, -0.9415440651830208,
+    -0.9238795325112868, -0.9039892931234434, -0.881921264348355, -0.8577286100002721,
+    -0.8314696123025455, -0.8032075314806449, -0.7730104533627371, -0.7409511253549591,
+    -0.7071067811865477, -0.6715589548470187, -0.6343932841636459, -0.5956993044924331,
+    -0.5555702330196022, -0.5141027441932218, -0.47139673682599786, -0.4275550934302825,
+    -0.38268343236509034, -0.33688985339221994, -0.29028467725446244, -0.24298017990326412,
+    -0.19509032201612866, -0.1467304744553623, -0.09801714032956045, -0.04906767432741803,
+    -1.8369701987210297e-16, 0.04906767432741766, 0.09801714032956009, 0.14673047445536194,
+    0.1950903220161283, 0.24298017990326376, 0.29028467725446205, 0.3368898533922196,
+    0.38268343236509, 0.42755509343028214, 0.4713967368259976, 0.5141027441932216,
+    0.5555702330196018, 0.5956993044924329, 0.6343932841636456, 0.6715589548470183,
+    0.7071067811865474, 0.7409511253549589, 0.7730104533627367, 0.803207531480645,
+    0.8314696123025452, 0.857728610000272, 0.8819212643483548, 0.9039892931234431,
+    0.9238795325112865, 0.9415440651830208, 0.9569403357322088, 0.970031253194544,
+    0.9807852804032303, 0.9891765099647809, 0.9951847266721969, 0.9987954562051724
+};
+static __device__ const double kSin128[128] = {
+    0.0, 0.049067674327418015, 0.0980171403295606, 0.14673047445536175,
+    0.19509032201612825, 0.24298017990326387, 0.29028467725446233, 0.33688985339222005,
+    0.3826834323650898, 0.4275550934302821, 0.47139673682599764, 0.5141027441932217,
+    0.5555702330196022, 0.5956993044924334, 0.6343932841636455, 0.6715589548470183,
+    0.7071067811865475, 0.7409511253549591, 0.773010453362737, 0.8032075314806448,
+    0.8314696123025452, 0.8577286100002721, 0.8819212643483549, 0.9039892931234433,
+    0.9238795325112867, 0.9415440651830208, 0.9569403357322089, 0.970031253194544,
+    0.9807852804032304, 0.989176509964781, 0.9951847266721968, 0.9987954562051724,
+    1.0, 0.9987954562051724, 0.9951847266721969, 0.989176509964781,
+    0.9807852804032304, 0.970031253194544, 0.9569403357322089, 0.9415440651830208,
+    0.9238795325112867, 0.9039892931234434, 0.881921264348355, 0.8577286100002721,
+    0.8314696123025455, 0.8032075314806449, 0.7730104533627371, 0.740951125354959,
+    0.7071067811865476, 0.6715589548470186, 0.6343932841636455, 0.5956993044924335,
+    0.5555702330196022, 0.5141027441932218, 0.47139673682599786, 0.42755509343028203,
+    0.3826834323650899, 0.33688985339222033, 0.2902846772544624, 0.24298017990326407,
+    0.1950903220161286, 0.1467304744553618, 0.09801714032956083, 0.049067674327417966,
+    1.2246467991473532e-16, -0.049067674327417724, -0.09801714032956059, -0.14673047445536158,
+    -0.19509032201612836, -0.24298017990326382, -0.2902846772544621, -0.3368898533922201,
+    -0.38268343236508967, -0.4275550934302818, -0.47139673682599764, -0.5141027441932216,
+    -0.555570233019602, -0.5956993044924332, -0.6343932841636453, -0.6715589548470184,
+    -0.7071067811865475, -0.7409511253549589, -0.7730104533627367, -0.803207531480645,
+    -0.8314696123025452, -0.857728610000272, -0.8819212643483549, -0.9039892931234431,
+    -0.9238795325112865, -0.9415440651830208, -0.9569403357322088, -0.970031253194544,
+    -0.9807852804032303, -0.9891765099647809, -0.9951847266721969, -0.9987954562051724,
+    -1.0, -0.9987954562051724, -0.9951847266721969, -0.9891765099647809,
+    -0.9807852804032304, -0.970031253194544, -0.9569403357322089, -0.9415440651830209,
+    -0.9238795325112866, -0.9039892931234433, -0.881921264348355, -0.8577286100002722,
+    -0.8314696123025455, -0.8032075314806453, -0.7730104533627369, -0.7409511253549591,
+    -0.7071067811865477, -0.6715589548470187, -0.6343932841636459, -0.5956993044924332,
+    -0.5555702330196022, -0.5141027441932219, -0.4713967368259979, -0.42755509343028253,
+    -0.3826834323650904, -0.33688985339222, -0.2902846772544625, -0.24298017990326418,
+    -0.19509032201612872, -0.1467304744553624, -0.0980171403295605, -0.04906767432741809
+};
+
 // The polynomial's spectrum on the 128 x 128 grid, in the order conv_w128.hip reads it: [wave w][register][lane], where in
 // the row phase wave w, lane (j, hh) holds row slot 32 w + j -- the slot 2 g + h is the column transform's register g in
 // lane half h, i.e. frequency fy = 2 K(g) + h with K(g) = (g >> 3) + 8 (g & 7) the 64-point transform's register order -- and
-// register `reg` of lane half hh holds fx = 2 K(reg) + hh.  Slice s of KH_SLICES forms registers 8 s .. 8 s + 7 (16 fx
+// register `reg` of lane half hh holds fx = 2 K(reg) + hh.  Slice s of KH_SLICES = 16 forms registers 4 s .. 4 s + 3 (8 fx
 // values).  sk: the taps in LDS (zero outside the record's box); both transforms' 1/128 folded in.  Called by all KH_THREADS.
 __device__ __forceinline__ void khat128_body(const float *sk, float *out, int slice, const PolySpec ps) {
-    constexpr int NU = PB_KRAD + 1, NX = 16;
+    constexpr int NU = PB_KRAD + 1, NX = 2 * 64 / KH_SLICES, RPS = 64 / KH_SLICES;      // fx values / registers per slice
     __shared__ double2 G8[NU * NX];
     __shared__ double c8[128], s8[128];
     const int tid = threadIdx.x;
-    if (tid < 128) { c8[tid] = cospi((double)tid / 64.0); s8[tid] = sinpi((double)tid / 64.0); }
+    if (tid < 128) { c8[tid] = kCos128[tid]; s8[tid] = kSin128[tid]; }
     __syncthreads();
     auto K64 = [](int g) { return (g >> 3) + 8 * (g & 7); };
     if (tid < NU * NX) {
-        const int u = tid / NX + PB_KRAD, xi = tid % NX, reg = 8 * slice + (xi >> 1), fx = 2 * K64(reg) + (xi & 1);
+        const int u = tid / NX + PB_KRAD, xi = tid % NX, reg = RPS * slice + (xi >> 1), fx = 2 * K64(reg) + (xi & 1);
         double ar = 0.0, ai = 0.0;
 #pragma unroll 5
         for (int v = 0; v < PB_KSIZE; ++v) {
@@ -89,7 +158,7 @@ __device__ __forceinline__ void khat128_body(const float *sk, float *out, int sl
         }
         double v = 2.0 * ar;                                              // the kernel's transform at (fx, fy): real
         v = (((double)ps.a3 * v + (double)ps.a2) * v + (double)ps.a1) * v + (double)ps.b;
-        const int reg = 8 * slice + (xi >> 1), hh = xi & 1, w = s >> 5, j = s & 31;
+        const int reg = RPS * slice + (xi >> 1), hh = xi & 1, w = s >> 5, j = s & 31;
         out[(w * 64 + reg) * 64 + j + 32 * hh] = (float)(v * (1.0 / 16384.0));
     }
 }
