@@ -116,7 +116,8 @@ struct pb_ctx {
     // passes take)
     float poly_gain = 1.0f;
     int poly_min_area = 768;
-    float poly_cost128 = 7.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows
+    float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
+                                         // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
 };
 

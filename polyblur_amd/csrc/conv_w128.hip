@@ -193,7 +193,50 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         const brsrc rin = plane_rsrc(ipl, a.in_plane);
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
         const int pitchb = a.in_pitch * (int)sizeof(TIn);
-        if (wy0 >= lo && wy0 + W_N <= Hp - lo && wxA >= lo && wxB + W_N <= Wp - lo && hasB) {
+        const bool inside = wy0 >= lo && wy0 + W_N <= Hp - lo && wxA >= lo && wxB + W_N <= Wp - lo && hasB;
+        if (sizeof(TIn) == 4 && inside && ((a.in_pitch | (wxA - lo)) & 3) == 0) {
+            // fp32 windows inside the source on 16-byte boundaries: every wave brings ITS 32 columns of both windows global ->
+            // LDS in 16-byte pieces (four rows per wave instruction: 8 pieces of window A and 8 of window B per row), through
+            // its quarter of the workgroup's LDS: four chunks of 32 rows -- 16 for the lower lanes, 16 for the upper --
+            // through two 8 KB buffers, two chunks requested before the first is waited for (as in conv_wfft.hip; the LDS
+            // reads are issued behind the compiler's back for the same reason).  128 four-byte loads per lane become 32 wave
+            // instructions of 1 KB.
+            char *zw = reinterpret_cast<char *>(Z) + w * (int)(kW128Lds / 4);
+            lds_char *zl = lds_ptr(zw);
+            const int pc = lane & 15;
+            const unsigned vo = (unsigned)((lane >> 4) * pitchb + ((pc < 8 ? wxA : wxB - 32) - lo + 32 * w + 4 * pc) * 4);
+            auto request = [&](int k, int buf) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)       // LDS rows 4 j .. 4 j + 3 of the chunk: lane half j >> 2, its rows 16 k + 4 (j & 3) ..
+                    dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (wy0 - lo + 64 * (j >> 2) + 16 * k + 4 * (j & 3)) * pitchb);
+            };
+            const unsigned la = lds_addr(zw) + (unsigned)(h * 4096 + c * 4);      // LDS row 16 h + i of a buffer: 256 bytes, A then B
+            auto pick = [&](int k, int buf) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const unsigned ad = la + (unsigned)(buf * 8192 + g4 * 1024);
+                    asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(v[16 * k + 4 * g4]) : "v"(ad));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(v[16 * k + 4 * g4 + 1]) : "v"(ad));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:160" : "=v"(v[16 * k + 4 * g4 + 2]) : "v"(ad));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:192 offset1:224" : "=v"(v[16 * k + 4 * g4 + 3]) : "v"(ad));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[16 * k]), "+v"(v[16 * k + 1]), "+v"(v[16 * k + 2]), "+v"(v[16 * k + 3]), "+v"(v[16 * k + 4]),
+                             "+v"(v[16 * k + 5]), "+v"(v[16 * k + 6]), "+v"(v[16 * k + 7]), "+v"(v[16 * k + 8]), "+v"(v[16 * k + 9]), "+v"(v[16 * k + 10]),
+                             "+v"(v[16 * k + 11]), "+v"(v[16 * k + 12]), "+v"(v[16 * k + 13]), "+v"(v[16 * k + 14]), "+v"(v[16 * k + 15]) :: "memory");
+            };
+            request(0, 0); request(1, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            pick(0, 0);
+            request(2, 0);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            pick(1, 1);
+            request(3, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            pick(2, 0);
+            wait_vm0();
+            pick(3, 1);
+            __syncthreads();                                        // (the transposes reuse every wave's quarter)
+        } else if (inside) {
             // both windows inside the source: one offset per lane, the row in the scalar offset
             const unsigned colA = (unsigned)((wy0 - lo + 64 * h) * pitchb + (wxA - lo + x) * (int)sizeof(TIn));
             const unsigned colB = colA + (unsigned)(Tx * (int)sizeof(TIn));
