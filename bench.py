@@ -292,7 +292,8 @@ def main():
         conv_ms, conv_n = prof["conv_fft"]
         # one wave per window pair (csrc/conv_wfft.hip) for every plane type it is built for -- fp32, fp16, 8-bit --; the
         # workgroup form (conv_fft.hip) only on request (PB_FFT_BODY=wg) or for fp16 temporaries
-        dom_kernel = "conv_wfft_kernel" if os.environ.get("PB_FFT_BODY", "wave") != "wg" and not cfg["opts"].get("half_temporaries") else "conv_fft_kernel"
+        # (the one-pass polynomial on 128 x 128 windows, conv_w128_kernel, carries the same event tag: one class)
+        dom_kernel = "conv_wfft_kernel + conv_w128_kernel" if os.environ.get("PB_FFT_BODY", "wave") != "wg" and not cfg["opts"].get("half_temporaries") else "conv_fft_kernel"
     # one polynomial application = (2s + 3s + 3s) bytes per sample, spread over its launches
     calls_per_step = B if from_root else 1                       # from_root deblurs image by image as they arrive
     launches_per_poly = max(conv_n / (args.steps * cfg["n_iter"] * calls_per_step), 1e-9)
@@ -319,8 +320,9 @@ def main():
             else:
                 # every instantiation of the dominant kernel that ran, weighted by its launches
                 num = den = 0
+                doms = ("conv_wfft_kernel<", "conv_w128_kernel<") if dom_kernel.startswith("conv_wfft") else (dom_kernel + "<",)
                 for k, v in tj.get("traffic", {}).items():
-                    if k.startswith(dom_kernel + "<"):
+                    if k.startswith(doms):
                         num += v["hbm_bytes_per_launch"] * v["launches"]; den += v["launches"]
                 if den:
                     traffic = int(num / den)

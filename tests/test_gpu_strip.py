@@ -1,5 +1,5 @@
 """GPU parity of the streaming strip body for rank-1 kernels (csrc/conv_strip.hip; opt-in, PB_STRIP=1: measured slower
-than the tile body it was meant to replace -- DESIGN.md section 4 -- and kept as the measured experiment).  It must agree
+than the tile body it was meant to replace -- NOTEBOOK.md section 4 -- and kept as the measured experiment behind --experimental).  It must agree
 with the oracle and with the tile body under both boundary models, on border and interior strips, in mixed batches."""
 import os
 
