@@ -91,6 +91,7 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     if (const char *e = getenv("PB_POLY_GAIN")) ctx->poly_gain = (float)atof(e);
     if (const char *e = getenv("PB_POLY_MIN_AREA")) ctx->poly_min_area = atoi(e);
     if (const char *e = getenv("PB_POLY_COST128")) ctx->poly_cost128 = (float)atof(e);
+    if (const char *e = getenv("PB_POLY_MIN_PAIRS128")) ctx->poly_min_pairs128 = atol(e);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     const char *side = getenv("PB_SIDE_STREAM");
@@ -303,7 +304,13 @@ void make_steps(const Geometry &g, const void *xsrc, int x_dtype, const float *x
 PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta) {
     const int mode = pb_poly_spec_mode(ctx, steps);
     if (!mode) return no_poly();
-    return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area, ctx->poly_cost128};
+    // (128 x 128 windows need an image of some size: a workgroup takes ~38 us for its pair whatever the launch, and a 700 x 500
+    // image yields 72 of them for 256 CUs -- 0.35 against 0.32 ms per call.  The rule looks at ONE image, not at the batch, so
+    // that what an image gets does not depend on the batch it travels in; the threshold sits just below 1080p x 3 channels
+    // (396 pairs at 90 x 90 tiles: alone 4 % slower through 128 x 128 windows, in a batch of 32 10 % faster))
+    const long pairs128 = (long)((steps[2].W + 179) / 180) * ((steps[2].H + 89) / 90) * steps[2].C;
+    const float cost128 = pairs128 >= ctx->poly_min_pairs128 ? ctx->poly_cost128 : 0.f;
+    return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area, cost128};
 }
 
 // y = a3 K^3 x + a2 K^2 x + a1 K x + beta x by Horner, three stencil passes (deblurring.py:122-138).

@@ -48,7 +48,7 @@ struct ProfRec {
 struct PolySpec { int on; float a3, a2, a1, b; float gain; int min_area; float cost128; };
 inline PolySpec no_poly() { return PolySpec{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0.f}; }
 inline bool same_spec(const PolySpec &x, const PolySpec &y) {
-    return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b));
+    return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b && (x.cost128 > 0.f) == (y.cost128 > 0.f)));
 }
 
 // rf = window halo class of the workgroup form (conv_fft.hip): 4, 8 or 12 -- 0 when only the wave form can run the image
@@ -116,6 +116,7 @@ struct pb_ctx {
     // passes take)
     float poly_gain = 1.0f;
     int poly_min_area = 768;
+    long poly_min_pairs128 = 350;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)

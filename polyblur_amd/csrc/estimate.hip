@@ -1364,6 +1364,41 @@ long long_grid(long items, size_t slot_bytes) {
 // flight.  Lines of up to 4096 samples (32 KB of LDS per two rows) fit five workgroups per CU; with many more
 // workgroups than that they run 128 threads.  Longer lines are limited by LDS to two or three workgroups per CU and
 // keep 256 threads (measured at 7680: 241 us per 8K image against 339 us with 128).
+// The directional maxima of (gx, gy) planes (blur_estimation.py:122-134, under the saturation mask :117-118) as a pass of
+// its own: what grad_cols_kernel<1> folds in its epilogue, for the estimation of a single small batch whose row and column
+// transforms run side by side on two streams (pb_estimate_impl).  One partial per workgroup in the layout of the column
+// tiles' partials (blur_params_kernel folds them); the same products and the same maximum: bit-identical results.
+template <int NA>
+__global__ __launch_bounds__(NT) void dir_maxima_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                         const float *__restrict__ gray, long HW, int bpp, unsigned *__restrict__ mags,
+                                                         int tiles_pad, int n_angles, int discard_sat, float thr, AngleTable ang) {
+    __shared__ float red[(NT / 64) * PB_MAX_ANGLES];
+    const int plane = blockIdx.x / bpp, blk = blockIdx.x - plane * bpp;
+    const float *px = gx + (long)plane * HW, *py = gy + (long)plane * HW, *pg = gray + (long)plane * HW;
+    float best[PB_MAX_ANGLES];
+#pragma unroll
+    for (int k = 0; k < PB_MAX_ANGLES; ++k) best[k] = 0.f;
+    const int na = n_angles + 1;
+    auto fold = [&](float dx, float dy, float g) {
+        if (discard_sat && g > thr) return;
+#pragma unroll
+        for (int k = 0; k < (NA ? NA : PB_MAX_ANGLES); ++k)
+            if (NA || k < na) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
+    };
+    if ((HW & 3) == 0) {
+        const long n4 = HW >> 2;
+        for (long i = (long)blk * NT + threadIdx.x; i < n4; i += (long)bpp * NT) {
+            const float4 a = reinterpret_cast<const float4 *>(px)[i], b = reinterpret_cast<const float4 *>(py)[i];
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (discard_sat) g = reinterpret_cast<const float4 *>(pg)[i];
+            fold(a.x, b.x, g.x); fold(a.y, b.y, g.y); fold(a.z, b.z, g.z); fold(a.w, b.w, g.w);
+        }
+    } else {
+        for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)bpp * NT) fold(px[i], py[i], discard_sat ? pg[i] : 0.f);
+    }
+    reduce_maxima<NT>(best, red, mags + (long)plane * PB_MAX_ANGLES * tiles_pad + blk, tiles_pad, n_angles);
+}
+
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
                 const unsigned *mm, int planes_per_image) {
     const FftPlan *pl = pb_get_plan(ctx, W);
@@ -1505,10 +1540,17 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (!plh) return PB_ERR_NOMEM;
     const int est_lognb = pick_lognb(plh, W, B, opt->n_angles == 6, nullptr);                   // as launch_cols
     const int col_tiles = (W + (2 << est_lognb) - 1) / (2 << est_lognb);
+    // (see below: transforms side by side + a maxima pass; an experiment that measured SLOWER -- 0.90 against 0.85 ms per 4K call,
+    // 0.35 against 0.32 ms at 700 x 500: the column workgroups take a CU's whole LDS, so the row workgroups do not run beside
+    // them, and the maxima pass and the fork / join come on top -- and stays off unless PB_EST_OVERLAP=1 is in the environment)
+    static const int overlap_env = [] { const char *e = getenv("PB_EST_OVERLAP"); return e ? atoi(e) : -1; }();
+    const bool lines_in_lds = pb_fft_length_supported(H) == 1 && pb_fft_length_supported(W) == 1;
+    const bool overlap = ctx->aux && !ctx->prof_on && lines_in_lds && overlap_env > 0;
+    const int est_tiles = overlap ? 512 : col_tiles;          // partial maxima per image: column tiles, or the maxima pass's workgroups
     float *gray = static_cast<float *>(pb_scratch(ctx, "est.gray", sizeof(float) * B * HW));
     float *gx = static_cast<float *>(pb_scratch(ctx, "est.gx", sizeof(float) * B * HW));
     unsigned *mm = static_cast<unsigned *>(pb_scratch(ctx, "est.mm", sizeof(unsigned) * 2 * B));
-    unsigned *mags = static_cast<unsigned *>(pb_scratch(ctx, "est.mags", sizeof(unsigned) * (size_t)B * ((col_tiles + 3) & ~3) * PB_MAX_ANGLES));
+    unsigned *mags = static_cast<unsigned *>(pb_scratch(ctx, "est.mags", sizeof(unsigned) * (size_t)B * ((std::max(col_tiles, 512) + 3) & ~3) * PB_MAX_ANGLES));
     if (!gray || !gx || !mm || !mags) return PB_ERR_NOMEM;
     const float *wts = pb_get_interp_weights(ctx, opt->n_angles, opt->n_interpolated_angles);
     if (!wts) return PB_ERR_NOMEM;
@@ -1561,10 +1603,43 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     PB_LAUNCH_CHECK();
     }
     const bool norm = opt->q > 0.f;                  // q == 0: transforms of the un-normalised image, maxima rescaled afterwards
-    int rc = launch_rows(ctx, gray, gx, B, H, W, norm, mm, 1);
-    if (rc) return rc;
-    rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, norm, mm, 1, mags, opt->n_angles, opt->discard_saturation);
-    if (rc) return rc;
+    int rc = PB_OK;
+    if (overlap) {
+        // (experiment, PB_EST_OVERLAP=1) both transforms are chains of dependent stages on an under-filled chip, so they are
+        // issued side by side -- rows (-> gx) on the side stream, a gy-writing column pass here -- and one HBM-speed pass
+        // folds the maxima.  Same results bit for bit; measured slower (above).
+        float *gy = static_cast<float *>(pb_scratch(ctx, "est.gy", sizeof(float) * B * HW));
+        if (!gy) return PB_ERR_NOMEM;
+        PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->aux;
+        rc = launch_rows(ctx, gray, gx, B, H, W, norm, mm, 1);
+        ctx->stream = main_stream;
+        PB_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
+        if (!rc) rc = launch_cols(ctx, gray, nullptr, gy, B, H, W, 0, norm, mm, 1, nullptr, opt->n_angles, 0);
+        PB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (rc) return rc;
+        AngleTable ang;
+        for (int k = 0; k < PB_MAX_ANGLES; ++k) {
+            const float t = opt->n_angles > 0 ? 3.14159265358979323846f * (float)k / (float)opt->n_angles : 0.f;
+            ang.cs[k] = std::cos(t); ang.sn[k] = std::sin(t);
+        }
+        ProfScope prof(ctx, PB_PROF_GRAD_COLS);
+        const int tp = (est_tiles + 3) & ~3;
+        if (opt->n_angles == 6)
+            hipLaunchKernelGGL(dir_maxima_kernel<7>, dim3((unsigned)(B * est_tiles)), dim3(NT), 0, ctx->stream, gx, gy, gray, HW, est_tiles, mags, tp,
+                               opt->n_angles, opt->discard_saturation, 0.99f, ang);
+        else
+            hipLaunchKernelGGL(dir_maxima_kernel<0>, dim3((unsigned)(B * est_tiles)), dim3(NT), 0, ctx->stream, gx, gy, gray, HW, est_tiles, mags, tp,
+                               opt->n_angles, opt->discard_saturation, 0.99f, ang);
+        PB_LAUNCH_CHECK();
+    } else {
+        rc = launch_rows(ctx, gray, gx, B, H, W, norm, mm, 1);
+        if (rc) return rc;
+        rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, norm, mm, 1, mags, opt->n_angles, opt->discard_saturation);
+        if (rc) return rc;
+    }
     float *khat = nullptr;
     pb_fft_sel *fsel = nullptr;
     if (ctx->fft_min_phases >= 0) {
@@ -1573,7 +1648,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     }
     ProfScope prof(ctx, PB_PROF_PARAMS);
     hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? KH_SLICES : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
-                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, col_tiles, ksize,
+                       opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, est_tiles, ksize,
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
                        ctx->fft_min_phases, ctx->poly_want);
     PB_LAUNCH_CHECK();

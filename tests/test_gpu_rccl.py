@@ -26,7 +26,7 @@ def _line(out):
 
 
 def test_bench_under_torchrun_one_rank():
-    args = ["--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-context", "--no-parity"]
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-context", "--no-parity"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     plain = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
     assert plain.returncode == 0, plain.stderr[-2000:]
