@@ -304,24 +304,54 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
         const int opitchb = a.out_pitch * (int)sizeof(TOut);
         const brsrc ro = plane_rsrc(opl, a.out_plane);
-        const bool colin = x >= hx && x < W_N - hx;
-        const int pxA = wxA + x, pxB = wxB + x;
-        const bool okA = colin && pxA < rg.x_hi, okB = colin && hasB && pxB < rg.x_hi;
-        const float sc = a.scale;
         const float clo = a.clamp01 ? 0.f : -INFINITY, chi = a.clamp01 ? 1.f : INFINITY;
-        const int row0 = 64 * h;                                    // this lane's first window row
-        // rows of the tile: hy <= 64 h + r < 128 - hy, and inside the output region.  (The lane's offset is that of its FIRST
-        // row of the tile -- the window's first rows lie above the output plane for the first tiles -- and a row's offset
-        // relative to it goes into the scalar offset.)
-        const int rlo = max(hy - row0, 0), rhi = min(min(W_N - hy, rg.y_hi - wy0) - row0, 64);
-        const unsigned baseA = okA && rlo < rhi ? (unsigned)((wy0 + row0 + rlo - oo) * opitchb + (pxA - oo) * (int)sizeof(TOut)) : kNoAccess;
-        const unsigned baseB = okB && rlo < rhi ? (unsigned)((wy0 + row0 + rlo - oo) * opitchb + (pxB - oo) * (int)sizeof(TOut)) : kNoAccess;
+        const int rmax = min(W_N - hy, rg.y_hi - wy0);              // window rows hy .. rmax - 1 are the tile's rows inside the region
+        if (hasB && wxB + W_N - hx <= rg.x_hi && ((a.out_pitch | (wxA - oo)) & 3) == 0) {
+            // both tiles complete along x, 16-byte boundaries: every wave sends ITS 32 columns of both windows through its
+            // quarter of the LDS (written by columns, read back as 16-byte row pieces: 8 of window A, 8 of window B per row,
+            // four rows per wave instruction), registers 0 .. 31 of both lane halves first, then 32 .. 63 -- 32 stores of 1 KB
+            // per wave instead of 128 of 256 bytes.
+            __syncthreads();                                        // (the last transpose's reads of the other waves' quarters)
+            float *zw = reinterpret_cast<float *>(reinterpret_cast<char *>(Z) + w * (int)(kW128Lds / 4));
+            float *zt = zw + (32 * h) * 64 + c;
+            const int pc = lane & 15, lr = lane >> 4;
+            const int xcol = 32 * w + 4 * (pc & 7);                 // first window column of this lane's piece
+            const bool colok = xcol >= hx && xcol < W_N - hx;
+            const int cb = ((pc < 8 ? wxA : wxB) + xcol - oo) * (int)sizeof(TOut), rb = (wy0 - oo + lr) * opitchb;   // (rb < 0 above the plane: only for rows outside the tile)
 #pragma unroll
-        for (int r = 0; r < 64; ++r) {
-            const bool rok = r >= rlo && r < rhi;
-            const float ra = __builtin_amdgcn_fmed3f(sc * v[r].x, clo, chi), rb = __builtin_amdgcn_fmed3f(sc * v[r].y, clo, chi);
-            BufIO<TOut>::st(ro, rok ? baseA + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, ra);
-            BufIO<TOut>::st(ro, rok ? baseB + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, rb);
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { zt[i * 64] = v[32 * p + i].x; zt[i * 64 + 32] = v[32 * p + i].y; }
+                wave_lds_fence();
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int row = 64 * (t >> 3) + 32 * p + 4 * (t & 7);          // window row of the instruction's first LDS row
+                    const f4v q = *reinterpret_cast<const f4v *>(zw + (4 * t + lr) * 64 + 4 * pc);
+                    f4v o;
+                    o.x = __builtin_amdgcn_fmed3f(q.x, clo, chi); o.y = __builtin_amdgcn_fmed3f(q.y, clo, chi);
+                    o.z = __builtin_amdgcn_fmed3f(q.z, clo, chi); o.w = __builtin_amdgcn_fmed3f(q.w, clo, chi);
+                    const bool ok = colok && row + lr >= hy && row + lr < rmax;
+                    Piece4<TOut>::st(ro, ok ? (unsigned)(rb + row * opitchb + cb) : kNoAccess, 0, o);
+                }
+                wave_lds_fence();
+            }
+        } else {
+            const bool colin = x >= hx && x < W_N - hx;
+            const int pxA = wxA + x, pxB = wxB + x;
+            const bool okA = colin && pxA < rg.x_hi, okB = colin && hasB && pxB < rg.x_hi;
+            const int row0 = 64 * h;                                // this lane's first window row
+            // (the lane's offset is that of its FIRST row of the tile -- the window's first rows lie above the output plane for
+            // the first tiles -- and a row's offset relative to it is added per row)
+            const int rlo = max(hy - row0, 0), rhi = min(rmax - row0, 64);
+            const unsigned baseA = okA && rlo < rhi ? (unsigned)((wy0 + row0 + rlo - oo) * opitchb + (pxA - oo) * (int)sizeof(TOut)) : kNoAccess;
+            const unsigned baseB = okB && rlo < rhi ? (unsigned)((wy0 + row0 + rlo - oo) * opitchb + (pxB - oo) * (int)sizeof(TOut)) : kNoAccess;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const bool rok = r >= rlo && r < rhi;
+                const float ra = __builtin_amdgcn_fmed3f(v[r].x, clo, chi), rb = __builtin_amdgcn_fmed3f(v[r].y, clo, chi);
+                BufIO<TOut>::st(ro, rok ? baseA + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, ra);
+                BufIO<TOut>::st(ro, rok ? baseB + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, rb);
+            }
         }
     }
 }
