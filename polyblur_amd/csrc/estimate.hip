@@ -1364,6 +1364,7 @@ long long_grid(long items, size_t slot_bytes) {
 // flight.  Lines of up to 4096 samples (32 KB of LDS per two rows) fit five workgroups per CU; with many more
 // workgroups than that they run 128 threads.  Longer lines are limited by LDS to two or three workgroups per CU and
 // keep 256 threads (measured at 7680: 241 us per 8K image against 339 us with 128).
+#ifdef PB_EXPERIMENTAL
 // The directional maxima of (gx, gy) planes (blur_estimation.py:122-134, under the saturation mask :117-118) as a pass of
 // its own: what grad_cols_kernel<1> folds in its epilogue, for the estimation of a single small batch whose row and column
 // transforms run side by side on two streams (pb_estimate_impl).  One partial per workgroup in the layout of the column
@@ -1398,6 +1399,8 @@ __global__ __launch_bounds__(NT) void dir_maxima_kernel(const float *__restrict_
     }
     reduce_maxima<NT>(best, red, mags + (long)plane * PB_MAX_ANGLES * tiles_pad + blk, tiles_pad, n_angles);
 }
+
+#endif
 
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
                 const unsigned *mm, int planes_per_image) {
@@ -1542,10 +1545,14 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     const int col_tiles = (W + (2 << est_lognb) - 1) / (2 << est_lognb);
     // (see below: transforms side by side + a maxima pass; an experiment that measured SLOWER -- 0.90 against 0.85 ms per 4K call,
     // 0.35 against 0.32 ms at 700 x 500: the column workgroups take a CU's whole LDS, so the row workgroups do not run beside
-    // them, and the maxima pass and the fork / join come on top -- and stays off unless PB_EST_OVERLAP=1 is in the environment)
+    // them, and the maxima pass and the fork / join come on top -- and is only in the --experimental build, behind PB_EST_OVERLAP=1)
+#ifdef PB_EXPERIMENTAL      // (python -m polyblur_amd.build --experimental)
     static const int overlap_env = [] { const char *e = getenv("PB_EST_OVERLAP"); return e ? atoi(e) : -1; }();
     const bool lines_in_lds = pb_fft_length_supported(H) == 1 && pb_fft_length_supported(W) == 1;
     const bool overlap = ctx->aux && !ctx->prof_on && lines_in_lds && overlap_env > 0;
+#else
+    const bool overlap = false;
+#endif
     const int est_tiles = overlap ? 512 : col_tiles;          // partial maxima per image: column tiles, or the maxima pass's workgroups
     float *gray = static_cast<float *>(pb_scratch(ctx, "est.gray", sizeof(float) * B * HW));
     float *gx = static_cast<float *>(pb_scratch(ctx, "est.gx", sizeof(float) * B * HW));
@@ -1604,6 +1611,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     }
     const bool norm = opt->q > 0.f;                  // q == 0: transforms of the un-normalised image, maxima rescaled afterwards
     int rc = PB_OK;
+#ifdef PB_EXPERIMENTAL
     if (overlap) {
         // (experiment, PB_EST_OVERLAP=1) both transforms are chains of dependent stages on an under-filled chip, so they are
         // issued side by side -- rows (-> gx) on the side stream, a gy-writing column pass here -- and one HBM-speed pass
@@ -1634,7 +1642,9 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
             hipLaunchKernelGGL(dir_maxima_kernel<0>, dim3((unsigned)(B * est_tiles)), dim3(NT), 0, ctx->stream, gx, gy, gray, HW, est_tiles, mags, tp,
                                opt->n_angles, opt->discard_saturation, 0.99f, ang);
         PB_LAUNCH_CHECK();
-    } else {
+    } else
+#endif
+    {
         rc = launch_rows(ctx, gray, gx, B, H, W, norm, mm, 1);
         if (rc) return rc;
         rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, norm, mm, 1, mags, opt->n_angles, opt->discard_saturation);
