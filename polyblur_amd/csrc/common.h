@@ -111,15 +111,16 @@ struct pb_ctx {
     PolySpec poly_built = no_poly(), poly_want = no_poly();
     // cost model of the general one-pass form (PolySpec.on == 2; env PB_POLY_GAIN, PB_POLY_MIN_AREA): an image takes it when
     // its composite tile has at least poly_min_area samples and -- an image that would otherwise take three tile-spectrum
-    // passes -- 3 x poly_gain x that area is at least the tile area of its three-step windows (measured at 4K: a one-pass
-    // window costs what a three-step window costs, gain = 1; one pass over 768-sample tiles takes what three rank-1 stencil
-    // passes take)
+    // passes -- 3 x that area is at least poly_gain x the tile area of its three-step windows (cost per output sample, in
+    // window pairs: 3 / (poly_gain x three-step tile area) against 1 / composite tile area; measured at 4K: a one-pass window
+    // costs what a three-step window costs, gain = 1; one pass over 768-sample tiles takes what three rank-1 stencil passes
+    // take)
     float poly_gain = 1.0f;
     int poly_min_area = 768;
     long poly_min_pairs128 = 350;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
-    int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes)       // ... written by the estimation's own parameter kernel (device-built records)
+    int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes; --experimental builds only)
 };
 
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...);

@@ -97,21 +97,25 @@ __device__ __forceinline__ void r2_inv(cf (&v)[64], bool upper, float sg) {
     }
 }
 
-// Column layout -> row layout.  Before: wave w, lane (c, h) holds, in register g, the element (column x = 32 w + c, row slot
-// 2 g + h).  After: wave w, lane (j, hh) holds, in register c, the element (row slot 32 w + j, column 64 hh + c).
+// Column layout -> row layout, WITH the rows' forward radix-2 step.  Before: wave w, lane (c, h) holds, in register g, the
+// element (column x = 32 w + c, row slot 2 g + h).  After: wave w, lane (j, hh) holds, in register c, for row slot 32 w + j:
+// hh = 0: a[c] + b[c], hh = 1: (a[c] - b[c]) W128^c, with a[c] = column c and b[c] = column 64 + c of that row -- what r2_fwd
+// would make of the plain transpose, but both lanes of a pair read BOTH halves of their row from the matrix (64 more LDS
+// reads per lane) instead of exchanging them through v_permlane32_swap (320 vector instructions).
 // Z: the workgroup's matrix, 64 slots x W_P.  Round A: every lane sends its registers 0 .. 31 (slots 0 .. 63: the rows of waves
 // 0 and 1, which receive 64 values per lane -- 32 into the registers they have just sent, 32 into `s`); round B: registers
 // 32 .. 63 (waves 2 and 3 receive into all 64; waves 0 and 1 move the spare set into the registers they have just sent).
-__device__ __forceinline__ void transpose_c2r(cf (&v)[64], float2 *Z, int w, int lane) {
+__device__ __forceinline__ void transpose_c2r_r2(cf (&v)[64], float2 *Z, int w, int lane, bool upper, float sg) {
     const int c = lane & 31, h = lane >> 5, x = 32 * w + c;
-    const float2 *rd = Z + (32 * (w & 1) + c) * W_P + 64 * h;   // (as receiver: slot 32 (w & 1) + j, j = lane & 31; x half = lane >> 5)
+    const float2 *rd = Z + (32 * (w & 1) + c) * W_P;            // (as receiver: slot 32 (w & 1) + j, j = lane & 31)
     cf s[32];
+    auto both = [&](int i) -> cf { return pbfft::to_cf(rd[i]) + pbfft::to_cf(rd[64 + i]) * sg; };
 #pragma unroll
     for (int g = 0; g < 32; ++g) Z[(2 * g + h) * W_P + x] = pbfft::to_f2(v[g]);
     __syncthreads();
     if (w < 2) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { v[i] = pbfft::to_cf(rd[i]); s[i] = pbfft::to_cf(rd[32 + i]); }
+        for (int i = 0; i < 32; ++i) { v[i] = both(i); s[i] = both(32 + i); }
     }
     __syncthreads();
 #pragma unroll
@@ -122,25 +126,38 @@ __device__ __forceinline__ void transpose_c2r(cf (&v)[64], float2 *Z, int w, int
         for (int i = 0; i < 32; ++i) v[32 + i] = s[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < 64; ++i) v[i] = pbfft::to_cf(rd[i]);
+        for (int i = 0; i < 64; ++i) v[i] = both(i);
     }
     __syncthreads();
+    if (upper) {
+#pragma unroll
+        for (int r = 1; r < 64; ++r) v[r] = cmul_s(v[r], (cf){kC128[r], -kS128[r]});
+    }
 }
 
-// Row layout -> column layout (the way back).  Before: wave w, lane (j, hh), register c = element (slot 32 w + j, column
-// 64 hh + c); after: wave w, lane (c, h), register g = element (column 32 w + c, slot 2 g + h).  Z: 64 columns x W_P slots.
-// Round A: registers 0 .. 31 = columns 0 .. 31 and 64 .. 95: the columns of waves 0 and 2; round B: the rest, waves 1 and 3.
-__device__ __forceinline__ void transpose_r2c(cf (&v)[64], float2 *Z, int w, int lane) {
+// Row layout -> column layout (the way back), WITH the rows' inverse radix-2 step.  Before: wave w, lane (j, hh), register c:
+// hh = 0: e[c], hh = 1: o[c] of row slot 32 w + j (the two 64-point inverse transforms); after: wave w, lane (c, h), register
+// g = element (column 32 w + c, slot 2 g + h) of e + o conj(W128^c) (columns 0 .. 63) and e - o conj(W128^c) (columns
+// 64 .. 127): the upper lanes multiply by the twiddles before they send, and the receivers of columns x and x + 64 both read
+// e[x] and o'[x] from the matrix and add or subtract.  Z: 64 columns x W_P slots.  Round A: registers 0 .. 31 -> columns
+// 0 .. 31 and 64 .. 95: waves 0 and 2; round B: the rest, waves 1 and 3.
+__device__ __forceinline__ void transpose_r2c_r2(cf (&v)[64], float2 *Z, int w, int lane, bool upper) {
     const int j = lane & 31, hh = lane >> 5, slot = 32 * w + j;
     const int c = lane & 31, h = lane >> 5;                    // (as receiver)
-    const float2 *rd = Z + (32 * (w >> 1) + c) * W_P + h;       // column index in the round's matrix: 32 (x half) + c; slots 2 g + h
+    const float2 *rd = Z + c * W_P + h;                         // e[x] in matrix row c, o'[x] in row 32 + c; slots 2 g + h
+    const float sg = (w >> 1) ? -1.f : 1.f;                     // columns 64 .. 127 (waves 2, 3): e - o'
     cf s[32];
+    auto both = [&](int g) -> cf { return pbfft::to_cf(rd[2 * g]) + pbfft::to_cf(rd[32 * W_P + 2 * g]) * sg; };
+    if (upper) {
+#pragma unroll
+        for (int r = 1; r < 64; ++r) v[r] = cmul_conj_s(v[r], (cf){kC128[r], -kS128[r]});
+    }
 #pragma unroll
     for (int i = 0; i < 32; ++i) Z[(32 * hh + i) * W_P + slot] = pbfft::to_f2(v[i]);
     __syncthreads();
     if (!(w & 1)) {
 #pragma unroll
-        for (int g = 0; g < 32; ++g) { v[g] = pbfft::to_cf(rd[2 * g]); s[g] = pbfft::to_cf(rd[2 * (32 + g)]); }
+        for (int g = 0; g < 32; ++g) { v[g] = both(g); s[g] = both(32 + g); }
     }
     __syncthreads();
 #pragma unroll
@@ -151,7 +168,7 @@ __device__ __forceinline__ void transpose_r2c(cf (&v)[64], float2 *Z, int w, int
         for (int g = 0; g < 32; ++g) v[32 + g] = s[g];
     } else {
 #pragma unroll
-        for (int g = 0; g < 64; ++g) v[g] = pbfft::to_cf(rd[2 * g]);
+        for (int g = 0; g < 64; ++g) v[g] = both(g);
     }
     __syncthreads();
 }
@@ -272,10 +289,10 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
     }
     r2_fwd(v, upper, sg);                                           // columns
     fft64_fwd(v);
-    transpose_c2r(v, Z, w, lane);
+    transpose_c2r_r2(v, Z, w, lane, upper, sg);                      // ... and the rows' radix-2 step
     {
-        // rows: radix-2 across the halves (columns x and x + 64), 64-point transform, x spectrum, and back.  The spectrum's 64
-        // values per lane travel in a ring of four groups of eight, as in conv_wfft.hip.
+        // rows: (radix-2 across the halves -- columns x and x + 64 -- inside the transposes,) 64-point transform, x spectrum,
+        // and back.  The spectrum's 64 values per lane travel in a ring of four groups of eight, as in conv_wfft.hip.
         const brsrc rk = plane_rsrc(kp, (long)W_N * W_N);
         float kh[4][8];
         auto khload = [&](int grp) {
@@ -284,7 +301,6 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         };
         khload(0); khload(1); khload(2); khload(3);
         __builtin_amdgcn_sched_barrier(0);
-        r2_fwd(v, upper, sg);
         fft64_fwd_stage1(v);
         centre_stage<0>(v, kh[0]); khload(4); __builtin_amdgcn_sched_barrier(0);
         centre_stage<1>(v, kh[1]); khload(5); __builtin_amdgcn_sched_barrier(0);
@@ -292,9 +308,8 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         centre_stage<3>(v, kh[3]); khload(7); __builtin_amdgcn_sched_barrier(0);
         centre_stage<4>(v, kh[0]); centre_stage<5>(v, kh[1]); centre_stage<6>(v, kh[2]); centre_stage<7>(v, kh[3]);
         fft64_inv_stage1(v);
-        r2_inv(v, upper, sg);
     }
-    transpose_r2c(v, Z, w, lane);
+    transpose_r2c_r2(v, Z, w, lane, upper);                         // ... with the rows' inverse radix-2 step
     fft64_inv_stage2(v);                                            // columns
     fft64_inv_stage1(v);
     r2_inv(v, upper, sg);

@@ -187,7 +187,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     __shared__ double2 G[NR * PXS];
     __shared__ double cs[KH_FT_N], sn[KH_FT_N];
     __shared__ float sk[PB_KSIZE * PB_KSIZE];
-    __shared__ float s_m[2][K1], s_m2[2][K2], s_m3[2][K3];     // |taps| marginals over the x / y offsets and their powers
+    __shared__ float s_m[2][K1], s_mp[2][3 * K1 - 2], s_m2[2][K2 + 2 * (K1 - 1)], s_m3[2][K3];   // |taps| marginals over the x / y offsets (s_mp, s_m2: zero-padded) and their powers
     __shared__ int s_h[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nph = rl ? rl->nph : info->nphase[0] + info->nphase[1] + info->nphase[2];
@@ -203,6 +203,9 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         sk[i] = in ? k : 0.f;
         sym = sym && (!in || k == km);
     }
+    constexpr int PD = K1 - 1;                                       // zeros on either side of m (s_mp) and of m * m (s_m2), see below
+    if (tid < 2 * (K1 + 2 * PD)) s_mp[tid / (K1 + 2 * PD)][tid % (K1 + 2 * PD)] = 0.f;
+    if (tid < 2 * (K2 + 2 * PD)) s_m2[tid / (K2 + 2 * PD)][tid % (K2 + 2 * PD)] = 0.f;
     PB_PT(20);
     const bool symm = __syncthreads_and(sym) && min_phases >= 0;
     // The window halo of the tile-spectrum body, per axis.  The spectrum below holds EVERY tap of the record's box; the halo
@@ -216,33 +219,39 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     // marginal of |K * K| is at most the marginal of |K| convolved with itself, so |a3| m^3 + |a2| m^2 + |a1| m (1-D
     // convolution powers of the kernel's marginal m) bounds the composite's marginal from above -- 13 and 18 samples for the
     // kernel above where the box of 3 x 12 would say 36: Gaussian tails compound like sqrt(3), not like 3.
+    // (fixed trip counts over zero-padded arrays, fully unrolled: every load of a sum is in flight at once -- with the
+    // bounds of the overlap as loop limits these three steps took 10 k cycles of the kernel's 41 k)
     if (tid < K1) {
         float a = 0.f;
-#pragma unroll 5
+#pragma unroll
         for (int u = 0; u < K1; ++u) a += fabsf(sk[u * K1 + tid]);
-        s_m[0][tid] = a;
+        s_m[0][tid] = a; s_mp[0][PD + tid] = a;
     } else if (tid >= 64 && tid < 64 + K1) {
         float a = 0.f;
-#pragma unroll 5
+#pragma unroll
         for (int v = 0; v < K1; ++v) a += fabsf(sk[(tid - 64) * K1 + v]);
-        s_m[1][tid - 64] = a;
+        s_m[1][tid - 64] = a; s_mp[1][PD + tid - 64] = a;
     }
     __syncthreads();
+    PB_PT(24);
     if (ps.on) {
         const int ax = tid >> 7, i = tid & 127;
-        if (i < K2) {
+        if (i < K2) {                                               // (m * m)[i] = sum_j m[j] m[i - j]
             float a = 0.f;
-            for (int j = max(0, i - (K1 - 1)); j <= min(i, K1 - 1); ++j) a += s_m[ax][j] * s_m[ax][i - j];
-            s_m2[ax][i] = a;
+#pragma unroll
+            for (int j = 0; j < K1; ++j) a += s_m[ax][j] * s_mp[ax][PD + i - j];
+            s_m2[ax][PD + i] = a;
         }
         __syncthreads();
-        if (i < K3) {
+        if (i < K3) {                                               // (m * m * m)[i] = sum_j m[j] (m * m)[i - j]
             float a = 0.f;
-            for (int j = max(0, i - (K2 - 1)); j <= min(i, K1 - 1); ++j) a += s_m[ax][j] * s_m2[ax][i - j];
+#pragma unroll
+            for (int j = 0; j < K1; ++j) a += s_m[ax][j] * s_m2[ax][PD + i - j];
             s_m3[ax][i] = a;
         }
         __syncthreads();
     }
+    PB_PT(25);
     {
         // wave 0 / 1: the kernel along x / y; wave 2 / 3: the composite along x / y
         const int ax = wave & 1;
@@ -253,7 +262,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
             const float c3 = fabsf(ps.a3), c2 = fabsf(ps.a2), c1 = fabsf(ps.a1);
             r = tail_radius([&](int i) {
                     float v = c3 * s_m3[ax][i];
-                    if (i >= PB_KRAD && i < PB_KRAD + K2) v += c2 * s_m2[ax][i - PB_KRAD];
+                    if (i >= PB_KRAD && i < PB_KRAD + K2) v += c2 * s_m2[ax][K1 - 1 + i - PB_KRAD];
                     if (i >= 2 * PB_KRAD && i < 2 * PB_KRAD + K1) v += c1 * s_m[ax][i - 2 * PB_KRAD];
                     return v;
                 }, 3 * PB_KRAD, 1e-10f, lane);
@@ -263,6 +272,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         if (lane == 0) s_h[wave] = r;
     }
     __syncthreads();
+    PB_PT(26);
     // halos: x in multiples of 4 (windows stay on 16-byte boundaries), y even (conv_wfft.hip stages two window rows at a time)
     const int hxk = max(4, (s_h[0] + 3) & ~3), hyk = max(2, (s_h[1] + 1) & ~1);
     const int hxp = max(4, (s_h[2] + 3) & ~3), hyp = max(2, (s_h[3] + 1) & ~1);
@@ -300,7 +310,8 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         sel->strip = (separable != 0 && R > 8) ? 1 : 0; sel->poly = poly128 ? 2 : (poly ? 1 : 0);
         sel->pad_[0] = 0; sel->pad_[1] = 0;
     }
-    if (poly128) { khat128_body(sk, out, slice, ps); return; }
+    PB_PT(23);
+    if (poly128) { khat128_body(sk, out, slice, ps); PB_PT(22); return; }
     if (!use) return;
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
     // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u}); this workgroup's x positions only

@@ -17,7 +17,7 @@ img, _ = synthetic_blurry_batch(1, 3, 2160, 3840, seed0=5)
 d = torch.from_numpy(img).cuda()
 KW = dict(c=0.362, b=0.468, alpha=6, beta=1)
 names = {0: "entry", 1: "maxima + range folded", 2: "interpolated", 3: "argmin, sigma, rho", 4: "taps + sum", 5: "marginals", 6: "acorr, gtaps, residual terms",
-         7: "residual sum", 8: "phases", 20: "khat: taps copied, symmetry", 21: "khat: first sum", 22: "khat: second sum, stored"}
+         7: "residual sum", 8: "phases", 20: "khat: taps copied, symmetry", 24: "khat: marginals", 25: "khat: convolution powers", 26: "khat: tail radii", 23: "khat: halos measured, form chosen", 22: "khat: spectrum stored"}
 acc = {}
 for rep in range(6):
     polyblur_deblurring(d, n_iter=1, **KW)
