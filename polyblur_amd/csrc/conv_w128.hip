@@ -70,32 +70,28 @@ static __device__ const float kS128[64] = {
 // hold b[r] = the sample 64 further on (r = register); afterwards the lower lanes hold a + b -- the input of the even
 // frequencies' 64-point transform -- and the upper (a - b) W128^r, that of the odd ones.  sg = +1 in the lower lanes, -1 in
 // the upper.
-__device__ __forceinline__ void r2_fwd(cf (&v)[64], bool upper, float sg) {
+__device__ __forceinline__ void r2_twiddle_fwd(cf (&v)[64], bool upper) {
+    if (upper) {
+#pragma unroll
+        for (int r = 1; r < 64; ++r) v[r] = cmul_s(v[r], (cf){kC128[r], -kS128[r]});
+    }
+}
+__device__ __forceinline__ void r2_twiddle_inv(cf (&v)[64], bool upper) {
+    if (upper) {
+#pragma unroll
+        for (int r = 1; r < 64; ++r) v[r] = cmul_conj_s(v[r], (cf){kC128[r], -kS128[r]});
+    }
+}
+__device__ __forceinline__ void r2_exchange(cf (&v)[64], float sg) {
 #pragma unroll
     for (int r = 0; r < 64; ++r) {
         cf a = v[r], b = v[r];
         swap_halves(a, b);                                     // a: the lower lanes' value in every lane, b: the upper lanes'
         v[r] = a + b * sg;
     }
-    if (upper) {
-#pragma unroll
-        for (int r = 1; r < 64; ++r) v[r] = cmul_s(v[r], (cf){kC128[r], -kS128[r]});
-    }
 }
-// Backward (decimation in time): the lower lanes hold e[r], the upper o[r]; afterwards the lower hold e + o conj(W128^r), the
-// upper e - o conj(W128^r) (the sample 64 further on).  Unnormalised.
-__device__ __forceinline__ void r2_inv(cf (&v)[64], bool upper, float sg) {
-    if (upper) {
-#pragma unroll
-        for (int r = 1; r < 64; ++r) v[r] = cmul_conj_s(v[r], (cf){kC128[r], -kS128[r]});
-    }
-#pragma unroll
-    for (int r = 0; r < 64; ++r) {
-        cf a = v[r], b = v[r];
-        swap_halves(a, b);
-        v[r] = a + b * sg;
-    }
-}
+__device__ __forceinline__ void r2_fwd(cf (&v)[64], bool upper, float sg) { r2_exchange(v, sg); r2_twiddle_fwd(v, upper); }
+__device__ __forceinline__ void r2_inv(cf (&v)[64], bool upper, float sg) { r2_twiddle_inv(v, upper); r2_exchange(v, sg); }
 
 // Column layout -> row layout, WITH the rows' forward radix-2 step.  Before: wave w, lane (c, h) holds, in register g, the
 // element (column x = 32 w + c, row slot 2 g + h).  After: wave w, lane (j, hh) holds, in register c, for row slot 32 w + j:
@@ -129,10 +125,7 @@ __device__ __forceinline__ void transpose_c2r_r2(cf (&v)[64], float2 *Z, int w, 
         for (int i = 0; i < 64; ++i) v[i] = both(i);
     }
     __syncthreads();
-    if (upper) {
-#pragma unroll
-        for (int r = 1; r < 64; ++r) v[r] = cmul_s(v[r], (cf){kC128[r], -kS128[r]});
-    }
+    r2_twiddle_fwd(v, upper);
 }
 
 // Row layout -> column layout (the way back), WITH the rows' inverse radix-2 step.  Before: wave w, lane (j, hh), register c:
@@ -148,10 +141,7 @@ __device__ __forceinline__ void transpose_r2c_r2(cf (&v)[64], float2 *Z, int w, 
     const float sg = (w >> 1) ? -1.f : 1.f;                     // columns 64 .. 127 (waves 2, 3): e - o'
     cf s[32];
     auto both = [&](int g) -> cf { return pbfft::to_cf(rd[2 * g]) + pbfft::to_cf(rd[32 * W_P + 2 * g]) * sg; };
-    if (upper) {
-#pragma unroll
-        for (int r = 1; r < 64; ++r) v[r] = cmul_conj_s(v[r], (cf){kC128[r], -kS128[r]});
-    }
+    r2_twiddle_inv(v, upper);
 #pragma unroll
     for (int i = 0; i < 32; ++i) Z[(32 * hh + i) * W_P + slot] = pbfft::to_f2(v[i]);
     __syncthreads();
@@ -227,19 +217,31 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
                 for (int j = 0; j < 8; ++j)       // LDS rows 4 j .. 4 j + 3 of the chunk: lane half j >> 2, its rows 16 k + 4 (j & 3) ..
                     dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (wy0 - lo + 64 * (j >> 2) + 16 * k + 4 * (j & 3)) * pitchb);
             };
-            const unsigned la = lds_addr(zw) + (unsigned)(h * 4096 + c * 4);      // LDS row 16 h + i of a buffer: 256 bytes, A then B
+            // Both lanes of a pair read BOTH halves' rows of the chunk (LDS rows i and 16 + i of a buffer: 256 bytes each, A then
+            // B) and form a + b (lower lanes) or a - b (upper lanes) themselves: the columns' forward radix-2 step without its
+            // lane exchange (64 more LDS reads per lane instead of 320 vector instructions).
+            const unsigned la = lds_addr(zw) + (unsigned)(c * 4);
             auto pick = [&](int k, int buf) {
+                cf tb[16];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const unsigned ad = la + (unsigned)(buf * 8192 + g4 * 1024);
+                    const unsigned ad = la + (unsigned)(buf * 8192 + g4 * 1024), ad2 = ad + 4096u;
                     asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(v[16 * k + 4 * g4]) : "v"(ad));
                     asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(v[16 * k + 4 * g4 + 1]) : "v"(ad));
                     asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:160" : "=v"(v[16 * k + 4 * g4 + 2]) : "v"(ad));
                     asm volatile("ds_read2_b32 %0, %1 offset0:192 offset1:224" : "=v"(v[16 * k + 4 * g4 + 3]) : "v"(ad));
+                    asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(tb[4 * g4]) : "v"(ad2));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(tb[4 * g4 + 1]) : "v"(ad2));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:160" : "=v"(tb[4 * g4 + 2]) : "v"(ad2));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:192 offset1:224" : "=v"(tb[4 * g4 + 3]) : "v"(ad2));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[16 * k]), "+v"(v[16 * k + 1]), "+v"(v[16 * k + 2]), "+v"(v[16 * k + 3]), "+v"(v[16 * k + 4]),
                              "+v"(v[16 * k + 5]), "+v"(v[16 * k + 6]), "+v"(v[16 * k + 7]), "+v"(v[16 * k + 8]), "+v"(v[16 * k + 9]), "+v"(v[16 * k + 10]),
                              "+v"(v[16 * k + 11]), "+v"(v[16 * k + 12]), "+v"(v[16 * k + 13]), "+v"(v[16 * k + 14]), "+v"(v[16 * k + 15]) :: "memory");
+                asm volatile("" : "+v"(tb[0]), "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(tb[4]), "+v"(tb[5]), "+v"(tb[6]), "+v"(tb[7]), "+v"(tb[8]),
+                             "+v"(tb[9]), "+v"(tb[10]), "+v"(tb[11]), "+v"(tb[12]), "+v"(tb[13]), "+v"(tb[14]), "+v"(tb[15]) :: "memory");
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[16 * k + i] = v[16 * k + i] + tb[i] * sg;
             };
             request(0, 0); request(1, 1);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -253,6 +255,7 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             wait_vm0();
             pick(3, 1);
             __syncthreads();                                        // (the transposes reuse every wave's quarter)
+            r2_twiddle_fwd(v, upper);
         } else if (inside) {
             // both windows inside the source: one offset per lane, the row in the scalar offset
             const unsigned colA = (unsigned)((wy0 - lo + 64 * h) * pitchb + (wxA - lo + x) * (int)sizeof(TIn));
@@ -262,6 +265,7 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
                 const int r = 8 * (q & 7) + (q >> 3);
                 v[r] = (cf){BufIO<TIn>::ld(rin, colA, r * pitchb), BufIO<TIn>::ld(rin, colB, r * pitchb)};
             }
+            r2_fwd(v, upper, sg);
         } else {
             // border window: columns mapped through the boundary model once per lane, rows on the scalar side (one per half)
             const int ixa = map_axis(wxA + x, a.W, a.in_kind, a.boundary, a.pad);
@@ -285,10 +289,10 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
                 v[r] = (cf){BufIO<TIn>::ld(rin, ok && colA != kNoAccess ? colA + ro_ : kNoAccess, 0),
                             BufIO<TIn>::ld(rin, ok && colB != kNoAccess ? colB + ro_ : kNoAccess, 0)};
             }
+            r2_fwd(v, upper, sg);
         }
     }
-    r2_fwd(v, upper, sg);                                           // columns
-    fft64_fwd(v);
+    fft64_fwd(v);                                                   // columns (their radix-2 step: above)
     transpose_c2r_r2(v, Z, w, lane, upper, sg);                      // ... and the rows' radix-2 step
     {
         // rows: (radix-2 across the halves -- columns x and x + 64 -- inside the transposes,) 64-point transform, x spectrum,
@@ -312,9 +316,10 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
     transpose_r2c_r2(v, Z, w, lane, upper);                         // ... with the rows' inverse radix-2 step
     fft64_inv_stage2(v);                                            // columns
     fft64_inv_stage1(v);
-    r2_inv(v, upper, sg);
+    r2_twiddle_inv(v, upper);                                       // (the halves' exchange: in the epilogue)
 
-    // ---- epilogue: lane = (column, half) again, register r = window row 64 h + r; the polynomial carries its own b x ----
+    // ---- epilogue: lane = (column, half); after the exchange register r = window row 64 h + r; the polynomial carries its
+    // own b x ----
     {
         const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0;
         const int opitchb = a.out_pitch * (int)sizeof(TOut);
@@ -325,7 +330,8 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             // both tiles complete along x, 16-byte boundaries: every wave sends ITS 32 columns of both windows through its
             // quarter of the LDS (written by columns, read back as 16-byte row pieces: 8 of window A, 8 of window B per row,
             // four rows per wave instruction), registers 0 .. 31 of both lane halves first, then 32 .. 63 -- 32 stores of 1 KB
-            // per wave instead of 128 of 256 bytes.
+            // per wave instead of 128 of 256 bytes.  The columns' inverse radix-2 step rides along: the lanes write e (lower
+            // half) and o conj(W) (upper half) and the row pieces read back are e + o' (window rows 0 .. 63) and e - o' (64 ..).
             __syncthreads();                                        // (the last transpose's reads of the other waves' quarters)
             float *zw = reinterpret_cast<float *>(reinterpret_cast<char *>(Z) + w * (int)(kW128Lds / 4));
             float *zt = zw + (32 * h) * 64 + c;
@@ -339,14 +345,18 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
                 for (int i = 0; i < 32; ++i) { zt[i * 64] = v[32 * p + i].x; zt[i * 64 + 32] = v[32 * p + i].y; }
                 wave_lds_fence();
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int row = 64 * (t >> 3) + 32 * p + 4 * (t & 7);          // window row of the instruction's first LDS row
-                    const f4v q = *reinterpret_cast<const f4v *>(zw + (4 * t + lr) * 64 + 4 * pc);
-                    f4v o;
-                    o.x = __builtin_amdgcn_fmed3f(q.x, clo, chi); o.y = __builtin_amdgcn_fmed3f(q.y, clo, chi);
-                    o.z = __builtin_amdgcn_fmed3f(q.z, clo, chi); o.w = __builtin_amdgcn_fmed3f(q.w, clo, chi);
-                    const bool ok = colok && row + lr >= hy && row + lr < rmax;
-                    Piece4<TOut>::st(ro, ok ? (unsigned)(rb + row * opitchb + cb) : kNoAccess, 0, o);
+                for (int t = 0; t < 8; ++t) {
+                    const int row = 32 * p + 4 * t;                                 // window row of the instruction's first LDS row (lower half)
+                    const f4v qe = *reinterpret_cast<const f4v *>(zw + (4 * t + lr) * 64 + 4 * pc);
+                    const f4v qo = *reinterpret_cast<const f4v *>(zw + (32 + 4 * t + lr) * 64 + 4 * pc);
+                    f4v o0, o1;
+                    o0.x = __builtin_amdgcn_fmed3f(qe.x + qo.x, clo, chi); o0.y = __builtin_amdgcn_fmed3f(qe.y + qo.y, clo, chi);
+                    o0.z = __builtin_amdgcn_fmed3f(qe.z + qo.z, clo, chi); o0.w = __builtin_amdgcn_fmed3f(qe.w + qo.w, clo, chi);
+                    o1.x = __builtin_amdgcn_fmed3f(qe.x - qo.x, clo, chi); o1.y = __builtin_amdgcn_fmed3f(qe.y - qo.y, clo, chi);
+                    o1.z = __builtin_amdgcn_fmed3f(qe.z - qo.z, clo, chi); o1.w = __builtin_amdgcn_fmed3f(qe.w - qo.w, clo, chi);
+                    const bool ok0 = colok && row + lr >= hy && row + lr < rmax, ok1 = colok && 64 + row + lr >= hy && 64 + row + lr < rmax;
+                    Piece4<TOut>::st(ro, ok0 ? (unsigned)(rb + row * opitchb + cb) : kNoAccess, 0, o0);
+                    Piece4<TOut>::st(ro, ok1 ? (unsigned)(rb + (64 + row) * opitchb + cb) : kNoAccess, 0, o1);
                 }
                 wave_lds_fence();
             }
@@ -363,7 +373,10 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
 #pragma unroll
             for (int r = 0; r < 64; ++r) {
                 const bool rok = r >= rlo && r < rhi;
-                const float ra = __builtin_amdgcn_fmed3f(v[r].x, clo, chi), rb = __builtin_amdgcn_fmed3f(v[r].y, clo, chi);
+                cf ea = v[r], eb = v[r];
+                swap_halves(ea, eb);                               // (the columns' inverse radix-2 step, register by register)
+                const cf er = ea + eb * sg;
+                const float ra = __builtin_amdgcn_fmed3f(er.x, clo, chi), rb = __builtin_amdgcn_fmed3f(er.y, clo, chi);
                 BufIO<TOut>::st(ro, rok ? baseA + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, ra);
                 BufIO<TOut>::st(ro, rok ? baseB + (unsigned)((r - rlo) * opitchb) : kNoAccess, 0, rb);
             }
