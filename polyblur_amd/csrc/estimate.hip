@@ -547,6 +547,79 @@ __global__ __launch_bounds__(NTH, (NTH == 256 && FUSED) ? 5 : 1) void grad_rows_
 }
 
 // ------------------------------------------------------------------------------------
+// gray + its range + the row transform in ONE pass (q == 0, lines that take the fused transform): the first stage's loads
+// read the image's channels, form the gray samples exactly as gray_minmax_kernel does (blur_estimation.py:36), store them
+// for the column pass and fold them into the workgroup's (min, max) partial -- the gray plane is written once and read
+// once instead of written once and read twice, and one launch of a whole-image pass goes away.
+// ------------------------------------------------------------------------------------
+template <typename T, int CC> struct GrayRowsIO {
+    struct Pre {};
+    const T *row0;             // channel 0, first row of the pair
+    long cstride;              // samples between channels
+    float *g0, *o0;            // gray and gx, first row of the pair
+    int W, C;
+    bool has1;
+    float invc, lo, hi;
+    __device__ __forceinline__ float2 load(int p, int) {
+        const int nc = CC ? CC : C;
+        float a = pb_ld(row0 + p), b = has1 ? pb_ld(row0 + W + p) : 0.f;
+        if (CC == 3) {
+            const float a1 = pb_ld(row0 + cstride + p), a2 = pb_ld(row0 + 2 * cstride + p);
+            const float b1 = has1 ? pb_ld(row0 + cstride + W + p) : 0.f, b2 = has1 ? pb_ld(row0 + 2 * cstride + W + p) : 0.f;
+            a = a + a1 + a2; b = b + b1 + b2;
+        } else {
+            for (int c = 1; c < nc; ++c) {
+                a += pb_ld(row0 + c * cstride + p);
+                if (has1) b += pb_ld(row0 + c * cstride + W + p);
+            }
+        }
+        if (nc == 3) { a = a / 3.0f; b = b / 3.0f; }
+        else if (nc != 1) { a *= invc; b *= invc; }
+        g0[p] = a;
+        lo = fminf(lo, a); hi = fmaxf(hi, a);
+        if (has1) { g0[W + p] = b; lo = fminf(lo, b); hi = fmaxf(hi, b); }
+        return make_float2(a, b);
+    }
+    __device__ __forceinline__ Pre prefetch(int, int) const { return Pre(); }
+    __device__ __forceinline__ void store(int p, int, float2 v, Pre) const {
+        o0[p] = v.x;
+        if (has1) o0[W + p] = -v.y;
+    }
+};
+
+template <typename T, int CC, int NTH>
+__global__ __launch_bounds__(NTH, NTH == 256 ? 5 : 1) void gray_rows_kernel(const T *__restrict__ in, float *__restrict__ gray, float *__restrict__ gx,
+                                                                            float2 *__restrict__ part, int C, int H, int W, pbfft::DevPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float2 sfft[];
+    const int pairs = (H + 1) / 2;
+    const int b = blockIdx.x / pairs, pr = blockIdx.x - b * pairs;
+    const int r0 = 2 * pr;
+    const long HW = (long)H * W;
+    GrayRowsIO<T, CC> io;
+    io.row0 = in + (long)b * C * HW + (long)r0 * W;
+    io.cstride = HW;
+    io.g0 = gray + (long)b * HW + (long)r0 * W;
+    io.o0 = gx + (long)b * HW + (long)r0 * W;
+    io.W = W; io.C = C; io.has1 = r0 + 1 < H; io.invc = 1.f / (float)C;
+    io.lo = INFINITY; io.hi = -INFINITY;
+    pbfft::spectral_derivative_fused(sfft, plan, 0, io);
+    float lo = io.lo, hi = io.hi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    __syncthreads();                                               // (the transform's last reads of sfft)
+    float *red = reinterpret_cast<float *>(sfft);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = lo; red[2 * (threadIdx.x >> 6) + 1] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NTH / 64; ++w) { lo = fminf(lo, red[2 * w]); hi = fmaxf(hi, red[2 * w + 1]); }
+        part[(long)b * pairs + pr] = make_float2(lo, hi);          // one partial per row pair, folded by the parameter kernel
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // spectral derivative along columns: one workgroup = 2*NB adjacent columns (NB complex lines)
 // MODE 0: write gy.  MODE 1: fuse the directional maxima (needs gx of the same plane).
 // ------------------------------------------------------------------------------------
@@ -1443,6 +1516,49 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     return PB_OK;
 }
 
+// gray + range partials + row transform in one launch (gray_rows_kernel); PB_ERR_UNSUPPORTED where the lines do not take the
+// fused transform (the caller then runs the gray pass and launch_rows).  *partials = partials per image.
+int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, float *gray, float *gx, float2 **part,
+                     int *partials) {
+    static const int on = [] { const char *e = getenv("PB_EST_GRAY_ROWS"); return e ? atoi(e) : 1; }();
+    if (!on) return PB_ERR_UNSUPPORTED;
+    const FftPlan *pl = pb_get_plan(ctx, W);
+    if (!pl) return PB_ERR_NOMEM;
+    const size_t lds = fft_lds_bytes(pl, 1);
+    if (lds > kMaxLds || pl->bluestein_m || pl->nstage < 2) return PB_ERR_UNSUPPORTED;
+    const int pairs = (H + 1) / 2;
+    const long blocks = (long)B * pairs;
+    if (blocks > 0x7fffffffL) return PB_ERR_UNSUPPORTED;
+    float2 *pt = static_cast<float2 *>(pb_scratch(ctx, "est.part", sizeof(float2) * (size_t)blocks));
+    if (!pt) return PB_ERR_NOMEM;
+    const pbfft::DevPlan dp = dev_plan(pl);
+    ProfScope prof(ctx, PB_PROF_GRAD_ROWS);
+#define PB_GROWS(T, CC, NTH)                                                                                       \
+    do {                                                                                                           \
+        int rc = allow_lds(ctx, gray_rows_kernel<T, CC, NTH>, lds);                                                \
+        if (rc) return rc;                                                                                         \
+        hipLaunchKernelGGL((gray_rows_kernel<T, CC, NTH>), dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream,    \
+                           static_cast<const T *>(in), gray, gx, pt, C, H, W, dp);                                 \
+    } while (0)
+#define PB_GROWS_C(T, NTH) do { if (C == 3) PB_GROWS(T, 3, NTH); else PB_GROWS(T, 0, NTH); } while (0)
+#define PB_GROWS_T(NTH)                                                                                            \
+    do {                                                                                                           \
+        if (dtype == PB_F32) PB_GROWS_C(float, NTH);                                                               \
+        else if (dtype == PB_F16) PB_GROWS_C(__half, NTH);                                                         \
+        else PB_GROWS_C(unsigned char, NTH);                                                                       \
+    } while (0)
+    static const int force_nt = [] { const char *e = getenv("PB_ROWS_NT"); return e ? atoi(e) : 0; }();
+    const bool one_round = blocks <= 256L * 5;                      // (as launch_rows)
+    if (lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_GROWS_T(128);
+    else PB_GROWS_T(256);
+#undef PB_GROWS_T
+#undef PB_GROWS_C
+#undef PB_GROWS
+    PB_LAUNCH_CHECK();
+    *part = pt; *partials = pairs;
+    return PB_OK;
+}
+
 int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, int P, int H, int W, int mode,
                 bool normalize, const unsigned *mm, int planes_per_image, unsigned *mags, int n_angles,
                 int discard_sat) {
@@ -1563,7 +1679,15 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     if (!wts) return PB_ERR_NOMEM;
     const float2 *part_q0 = nullptr;
     int bpi_q0 = 0;
-    {
+    // q == 0: gray, its range and the row transform in one launch where the lines allow it
+    bool rows_done = false;
+    if (opt->q <= 0.f && !overlap) {
+        float2 *pt = nullptr;
+        const int rcg = launch_gray_rows(ctx, in, dtype, B, C, H, W, gray, gx, &pt, &bpi_q0);
+        if (rcg == PB_OK) { rows_done = true; part_q0 = pt; }
+        else if (rcg != PB_ERR_UNSUPPORTED) return rcg;
+    }
+    if (!rows_done) {
     ProfScope prof(ctx, PB_PROF_GRAY);
     const bool vec = (HW & 3) == 0;
     int bpi = (int)((HW / (vec ? 4 : 1) + NT * 4 - 1) / (NT * 4));
@@ -1645,7 +1769,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     } else
 #endif
     {
-        rc = launch_rows(ctx, gray, gx, B, H, W, norm, mm, 1);
+        if (!rows_done) rc = launch_rows(ctx, gray, gx, B, H, W, norm, mm, 1);
         if (rc) return rc;
         rc = launch_cols(ctx, gray, gx, nullptr, B, H, W, 1, norm, mm, 1, mags, opt->n_angles, opt->discard_saturation);
         if (rc) return rc;
