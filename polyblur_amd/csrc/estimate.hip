@@ -18,7 +18,12 @@
 // kernel's phases, first workgroup (tools/params_trace.py)
 #ifdef PB_PARAMS_TRACE
 __device__ unsigned long long g_params_trace[32];
+#ifdef PB_PT_WANT       // (with it: the kernel body runs twice and the stamps are those of repetition PB_PT_WANT -- 1 = warm instruction cache)
+__device__ int g_pt_rep;
+#define PB_PT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_pt_rep == PB_PT_WANT) g_params_trace[i] = __builtin_readcyclecounter(); } while (0)
+#else
 #define PB_PT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_params_trace[i] = __builtin_readcyclecounter(); } while (0)
+#endif
 extern "C" int pb_debug_params_trace(unsigned long long *host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_params_trace), sizeof(unsigned long long) * 32);
 }
@@ -1169,6 +1174,11 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     __shared__ float s_lo[NT / 64], s_hi[NT / 64];
     pb_blur_info *info = infos + blockIdx.x;
     const int na = n_angles + 1;
+#ifdef PB_PT_WANT
+    for (int pt_rep = 0; pt_rep < 2; ++pt_rep) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_pt_rep = pt_rep;
+    __syncthreads();
+#endif
     PB_PT(0);
     // q == 0 (part != nullptr): the transforms ran on the UN-normalised gray image -- the derivative is linear and kills
     // the offset, and without quantiles the clip of normalize() never acts (blur_estimation.py:92-109) -- so the
@@ -1310,6 +1320,10 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     // critical path than a kernel of its own behind this one.
     if (khat)      // (the record as finish_record left it in LDS: no wait for its stores, no read back)
         khat_body(info, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps, &rl);
+#ifdef PB_PT_WANT
+    __syncthreads();
+    }
+#endif
 }
 
 // method='direct_separable': the two correlation kernels of the x-t separable approximation of the image's Gaussian
@@ -1781,6 +1795,9 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
         if (rc) return rc;
     }
     ProfScope prof(ctx, PB_PROF_PARAMS);
+#ifdef PB_ABL_PARAMS_REPS
+    for (int rep = 0; rep < PB_ABL_PARAMS_REPS; ++rep)
+#endif
     hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? KH_SLICES : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, est_tiles, ksize,
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
