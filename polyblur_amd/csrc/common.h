@@ -147,7 +147,7 @@ struct ProfScope {
     }
 };
 void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes);   // nullptr on failure (error set)
-const FftPlan *pb_get_plan(pb_ctx *ctx, int n);
+const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices = false);   // ext_radices: the caller's kernel holds radices 18 / 20 / 24
 const float *pb_get_interp_weights(pb_ctx *ctx, int n_angles, int n_interp);
 
 #define PB_HIP(call)                                                                          \

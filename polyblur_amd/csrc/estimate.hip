@@ -9,7 +9,9 @@
 //   blur_params_kernel   cubic interpolation, argmin, affine model, 25x25 Gaussian
 //                                                                blur_estimation.py:138-232
 // Everything stays on the stream: no host synchronisation between stages.
+#include <algorithm>
 #include <cmath>
+#include <functional>
 #include <cstdlib>
 
 #include "common.h"
@@ -37,10 +39,11 @@ constexpr int NT = 256;
 // ------------------------------------------------------------------------------------
 // FFT plans (host)
 // ------------------------------------------------------------------------------------
-static void factorize(int n, std::vector<int> &radix, int &rest) {
+static void factorize(int n, std::vector<int> &radix, int &rest, bool ext_ok = false) {
     // greedy: the largest in-register radix that divides what is left (fewer LDS passes and barriers)
     static const int pref[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 7, 3, 2};
     radix.clear();
+    const int n0 = n;
     bool found = true;
     while (n > 1 && found) {
         found = false;
@@ -48,6 +51,38 @@ static void factorize(int n, std::vector<int> &radix, int &rest) {
             if (n % r == 0) { radix.push_back(r); n /= r; found = true; break; }
     }
     rest = n;
+    // Lines held in LDS: where radices 18 / 20 / 24 save a stage over the greedy plan (4320 = 16 x 15 x 9 x 2 -> 18 x 16 x 15,
+    // 7680 = 16 x 16 x 15 x 2 -> 24 x 20 x 16: two LDS round trips and barriers fewer per line), the plan with the fewest
+    // stages and, among those, the smallest sum of radices; every other length keeps its greedy plan.
+    static const bool ext_off = getenv("PB_FFT_EXT_RADIX") && atoi(getenv("PB_FFT_EXT_RADIX")) == 0;
+    if (!ext_ok || rest != 1 || ext_off || (long)n0 * 8 > 160 * 1024 || radix.size() < 3) return;
+    static const int ext[] = {24, 20, 18, 16, 15, 12, 10, 9, 8, 6, 5, 4, 7, 3, 2};
+    std::vector<int> best, cur;
+    int best_sum = 0;
+    const size_t limit = radix.size() - 1;                // only plans with fewer stages are of interest
+    std::function<void(int, int, int)> dfs = [&](int left, int max_r, int sum) {
+        if (left == 1) {
+            if (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && sum < best_sum)) { best = cur; best_sum = sum; }
+            return;
+        }
+        if (cur.size() >= limit || (!best.empty() && cur.size() >= best.size())) return;
+        for (int r : ext) {
+            if (r > max_r || left % r) continue;
+            cur.push_back(r);
+            dfs(left / r, r, sum + r);
+            cur.pop_back();
+        }
+    };
+    dfs(n0, 24, 0);
+    if (best.empty() || best.size() >= radix.size()) return;
+    // order: the first radix is the one of the stages that talk to global memory (and, in the column kernel, carry the
+    // epilogue's prefetched operands): the largest one up to 16, as in the greedy plans; the rest ascending, so that the
+    // widest butterfly is the innermost stage, which has no twiddles to hold
+    std::sort(best.begin(), best.end());
+    int first = -1;
+    for (int i = (int)best.size() - 1; i >= 0; --i) if (best[i] <= 16) { first = i; break; }
+    if (first > 0) std::rotate(best.begin(), best.begin() + first, best.begin() + first + 1);
+    radix = best;
 }
 
 // frequency index held at position p after the DIF stages
@@ -96,14 +131,15 @@ extern "C" int pb_fft_length_supported(int n) {
     return core * (long)sizeof(float2) <= 160 * 1024 ? 1 : 2;
 }
 
-const FftPlan *pb_get_plan(pb_ctx *ctx, int n) {
-    auto it = ctx->plans.find(n);
+const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices) {
+    const int key = ext_radices ? -n : n;                 // (two plans per length: the kernel variants without the radices above 16 take the greedy one)
+    auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) return &it->second;
     FftPlan pl;
     pl.n = n;
     std::vector<int> radix;
     int rest = 1;
-    factorize(n, radix, rest);
+    factorize(n, radix, rest, ext_radices);
     const double two_pi = 6.283185307179586476925286766559;
     int core = n;
     if (rest != 1) {               // Bluestein with a power-of-two core
@@ -175,7 +211,7 @@ const FftPlan *pb_get_plan(pb_ctx *ctx, int n) {
         ok = ok && pl.chirp && pl.bfilt_rev && pl.dnat;
     }
     if (!ok) { pb_fail(ctx, PB_ERR_NOMEM, "fft plan %d: device allocation failed", n); return nullptr; }
-    auto res = ctx->plans.emplace(n, pl);
+    auto res = ctx->plans.emplace(key, pl);
     return &res.first->second;
 }
 
@@ -490,7 +526,7 @@ __global__ __launch_bounds__(NTH, (NTH == 256 && FUSED) ? 5 : 1) void grad_rows_
     const float inv = 1.f / scale;
     if constexpr (FUSED) {
         RowsIO io{row0, row1, gx + ((long)plane * H + r0) * W, W, has1, normalize != 0, lo, scale, inv};
-        pbfft::spectral_derivative_fused(sfft, plan, 0, io);
+        pbfft::spectral_derivative_fused<(NTH == 512 ? 24 : 16)>(sfft, plan, 0, io);    // (512 threads: the variant of the long lines, radices up to 24)
         return;
     }
     const bool vec = (W & 3) == 0;                 // rows are 16-byte aligned: whole-row float4 traffic
@@ -607,7 +643,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 5 : 1) void gray_rows_kernel(cons
     io.o0 = gx + (long)b * HW + (long)r0 * W;
     io.W = W; io.C = C; io.has1 = r0 + 1 < H; io.invc = 1.f / (float)C;
     io.lo = INFINITY; io.hi = -INFINITY;
-    pbfft::spectral_derivative_fused(sfft, plan, 0, io);
+    pbfft::spectral_derivative_fused<(NTH == 512 ? 24 : 16)>(sfft, plan, 0, io);
     float lo = io.lo, hi = io.hi;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -715,7 +751,7 @@ template <int MODE, int NA> struct ColsIO {
     }
 };
 
-template <int MODE, int NA, int NTH>
+template <int MODE, int NA, int NTH, int MAXR = 16>
 __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict__ planes, const float *__restrict__ gx,
                                                        float *__restrict__ gy, int H, int W, int lognb, int normalize,
                                                        const unsigned *__restrict__ mm, int planes_per_image,
@@ -754,7 +790,7 @@ __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict_
         io.lo = lo; io.scale = scale; io.inv = inv; io.sat_threshold = sat_threshold; io.ang = ang;
 #pragma unroll
         for (int k = 0; k < PB_MAX_ANGLES; ++k) io.best[k] = 0.f;
-        pbfft::spectral_derivative_fused(sfft, plan, lognb, io);
+        pbfft::spectral_derivative_fused<MAXR>(sfft, plan, lognb, io);
         if (MODE == 1) {
             __syncthreads();
             reduce_maxima<NTH>(io.best, reinterpret_cast<float *>(sfft), mags_tile, tiles_pad, n_angles);
@@ -1398,6 +1434,11 @@ __global__ __launch_bounds__(NT) void make_kernels_kernel(pb_blur_info *infos, i
     finish_record(infos + blockIdx.x, support, from_taps != 0, red, ksize);
 }
 
+bool plan_ext(const FftPlan *pl) {                    // a plan holding radices above 16: only some kernel variants run it
+    for (int i = 0; i < pl->nstage; ++i) if (pl->radix[i] > 16) return true;
+    return false;
+}
+
 size_t fft_lds_bytes(const FftPlan *pl, int nb) {
     const size_t n = pl->bluestein_m ? pl->bluestein_m : pl->n;
     return n * nb * sizeof(float2);
@@ -1491,7 +1532,7 @@ __global__ __launch_bounds__(NT) void dir_maxima_kernel(const float *__restrict_
 
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
                 const unsigned *mm, int planes_per_image) {
-    const FftPlan *pl = pb_get_plan(ctx, W);
+    const FftPlan *pl = pb_get_plan(ctx, W, true);       // (the 512-thread variant holds the radices above 16)
     if (!pl) return PB_ERR_NOMEM;
     const size_t lds = fft_lds_bytes(pl, 1);
     const long blocks = (long)P * ((H + 1) / 2);
@@ -1523,7 +1564,8 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     static const int force_nt = [] { const char *e = getenv("PB_ROWS_NT"); return e ? atoi(e) : 0; }();
     const bool one_round = blocks <= 256L * 5;
     if (!fused) PB_ROWS(256, false);
-    else if (lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_ROWS(128, true);
+    else if (!plan_ext(pl) && lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_ROWS(128, true);
+    else if (plan_ext(pl) || force_nt == 512 || (force_nt == 0 && lds > 40 * 1024)) PB_ROWS(512, true);
     else PB_ROWS(256, true);
 #undef PB_ROWS
     PB_LAUNCH_CHECK();
@@ -1536,10 +1578,15 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                      int *partials) {
     static const int on = [] { const char *e = getenv("PB_EST_GRAY_ROWS"); return e ? atoi(e) : 1; }();
     if (!on) return PB_ERR_UNSUPPORTED;
-    const FftPlan *pl = pb_get_plan(ctx, W);
+    const FftPlan *pl = pb_get_plan(ctx, W, true);
     if (!pl) return PB_ERR_NOMEM;
     const size_t lds = fft_lds_bytes(pl, 1);
     if (lds > kMaxLds || pl->bluestein_m || pl->nstage < 2) return PB_ERR_UNSUPPORTED;
+    // Measured (same box, PB_EST_GRAY_ROWS=0/1): 4K fp32 0.820 -> 0.811 ms per call, 32 x 1080p fp32 7.11 -> 7.00 ms; but 8K
+    // lines (two workgroups per CU: six load streams with nothing to hide them behind) 4.22 -> 4.33 ms, and fp16 / 8-bit
+    // planes (2- and 1-byte loads where the gray pass reads 8 and 4 bytes per lane) 35.0 -> 35.4 ms for 64 x 1080p fp16: the
+    // fused launch is built for fp32 planes and taken for lines of up to 4096 samples (PB_EST_GRAY_ROWS=2: any length).
+    if (dtype != PB_F32 || (on < 2 && lds > 32 * 1024)) return PB_ERR_UNSUPPORTED;
     const int pairs = (H + 1) / 2;
     const long blocks = (long)B * pairs;
     if (blocks > 0x7fffffffL) return PB_ERR_UNSUPPORTED;
@@ -1555,15 +1602,13 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                            static_cast<const T *>(in), gray, gx, pt, C, H, W, dp);                                 \
     } while (0)
 #define PB_GROWS_C(T, NTH) do { if (C == 3) PB_GROWS(T, 3, NTH); else PB_GROWS(T, 0, NTH); } while (0)
-#define PB_GROWS_T(NTH)                                                                                            \
-    do {                                                                                                           \
-        if (dtype == PB_F32) PB_GROWS_C(float, NTH);                                                               \
-        else if (dtype == PB_F16) PB_GROWS_C(__half, NTH);                                                         \
-        else PB_GROWS_C(unsigned char, NTH);                                                                       \
-    } while (0)
+#define PB_GROWS_T(NTH) PB_GROWS_C(float, NTH)
     static const int force_nt = [] { const char *e = getenv("PB_ROWS_NT"); return e ? atoi(e) : 0; }();
     const bool one_round = blocks <= 256L * 5;                      // (as launch_rows)
-    if (lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_GROWS_T(128);
+    // (lines above 40 KB of LDS -- 8K rows -- leave room for two or three workgroups per CU: 512 threads each keep the
+    // CU's SIMDs supplied, PB_ROWS_NT=256 to compare)
+    if (!plan_ext(pl) && lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_GROWS_T(128);
+    else if (plan_ext(pl) || force_nt == 512 || (force_nt == 0 && lds > 40 * 1024)) PB_GROWS_T(512);
     else PB_GROWS_T(256);
 #undef PB_GROWS_T
 #undef PB_GROWS_C
@@ -1576,8 +1621,11 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, int P, int H, int W, int mode,
                 bool normalize, const unsigned *mm, int planes_per_image, unsigned *mags, int n_angles,
                 int discard_sat) {
-    const FftPlan *pl = pb_get_plan(ctx, H);
+    // (the 1024-thread variants of the gy-writing and the 7-direction kernels exist with the radices above 16)
+    const bool ext_variant = mode == 0 || (mode == 1 && n_angles == 6);
+    const FftPlan *pl = pb_get_plan(ctx, H, ext_variant);
     if (!pl) return PB_ERR_NOMEM;
+    const bool ext = plan_ext(pl);
     int nt = NT;
     const int lognb = pick_lognb(pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt);
     const size_t lds = fft_lds_bytes(pl, 1 << lognb);
@@ -1618,7 +1666,17 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
                            lds, ctx->stream, planes, gx, gy, H, W, lognb, normalize ? 1 : 0, mm,                 \
                            planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);            \
     } while (0)
-    if (mode == 0 && nt == 512) {
+#define PB_COLS_EXT(MODE, NA)                                                                                    \
+    do {                                                                                                         \
+        int rc = allow_lds(ctx, grad_cols_kernel<MODE, NA, 1024, 24>, lds);                                      \
+        if (rc) return rc;                                                                                       \
+        hipLaunchKernelGGL((grad_cols_kernel<MODE, NA, 1024, 24>), dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(1024), \
+                           lds, ctx->stream, planes, gx, gy, H, W, lognb, normalize ? 1 : 0, mm,                 \
+                           planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);            \
+    } while (0)
+    if (ext && mode == 0) PB_COLS_EXT(0, 0);
+    else if (ext) PB_COLS_EXT(1, 7);
+    else if (mode == 0 && nt == 512) {
         // (192 x 1080p planes: 2.27 -> 1.61 ms against 8-column tiles with 256 threads)
         int rc = allow_lds(ctx, grad_cols_kernel<0, 0, 1024>, lds);
         if (rc) return rc;
@@ -1646,6 +1704,7 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
                            planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);
     }
     else PB_COLS(1, 0);
+#undef PB_COLS_EXT
 #undef PB_COLS
     PB_LAUNCH_CHECK();
     return PB_OK;

@@ -19,7 +19,8 @@
 // -- four LDS round trips and barriers for a 3840-point line instead of eight.
 //
 // Lengths whose prime factors are all <= 7 use radices up to 16 (composites 16/15/12/10/9/8/6 are evaluated
-// in registers as two-level Cooley-Tukey, so a 3840-point line needs 3 LDS passes, not 6); any other length
+// in registers as two-level Cooley-Tukey, so a 3840-point line needs 3 LDS passes, not 6) -- and 18 / 20 / 24 where
+// that saves a stage (4320 = 18 x 16 x 15, 7680 = 24 x 20 x 16: the 8K sides); any other length
 // goes through Bluestein's chirp-z with a power-of-two inner length (plan.bluestein_m).
 #pragma once
 #include "common.h"
@@ -161,6 +162,13 @@ static __device__ const float kCos15[15] = {1.0f, 0.9135454576426009f, 0.6691306
 static __device__ const float kSin15[15] = {0.0f, 0.40673664307580015f, 0.7431448254773941f, 0.9510565162951535f, 0.9945218953682734f, 0.8660254037844387f, 0.5877852522924732f, 0.20791169081775931f, -0.20791169081775907f, -0.587785252292473f, -0.8660254037844384f, -0.9945218953682733f, -0.9510565162951536f, -0.743144825477394f, -0.40673664307580015f};
 static __device__ const float kCos16[16] = {1.0f, 0.9238795325112867f, 0.7071067811865476f, 0.38268343236508984f, 0.0f, -0.3826834323650897f, -0.7071067811865475f, -0.9238795325112867f, -1.0f, -0.9238795325112868f, -0.7071067811865477f, -0.38268343236509034f, 0.0f, 0.38268343236509f, 0.7071067811865474f, 0.9238795325112865f};
 static __device__ const float kSin16[16] = {0.0f, 0.3826834323650898f, 0.7071067811865475f, 0.9238795325112867f, 1.0f, 0.9238795325112867f, 0.7071067811865476f, 0.3826834323650899f, 0.0f, -0.38268343236508967f, -0.7071067811865475f, -0.9238795325112865f, -1.0f, -0.9238795325112866f, -0.7071067811865477f, -0.3826834323650904f};
+// (radices 18 / 20 / 24: lines of 4320 or 7680 samples in three stages instead of four -- 8K images)
+static __device__ const float kCos18[18] = {1.0f, 0.9396926207859084f, 0.766044443118978f, 0.5000000000000001f, 0.17364817766693041f, -0.1736481776669303f, -0.4999999999999998f, -0.7660444431189779f, -0.9396926207859083f, -1.0f, -0.9396926207859084f, -0.7660444431189783f, -0.5000000000000004f, -0.17364817766693033f, 0.17364817766692997f, 0.49999999999999933f, 0.7660444431189778f, 0.9396926207859084f};
+static __device__ const float kSin18[18] = {0.0f, 0.3420201433256687f, 0.6427876096865393f, 0.8660254037844386f, 0.984807753012208f, 0.984807753012208f, 0.8660254037844387f, 0.6427876096865395f, 0.3420201433256689f, 0.0f, -0.34202014332566866f, -0.6427876096865389f, -0.8660254037844384f, -0.984807753012208f, -0.9848077530122081f, -0.866025403784439f, -0.6427876096865396f, -0.3420201433256686f};
+static __device__ const float kCos20[20] = {1.0f, 0.9510565162951535f, 0.8090169943749475f, 0.5877852522924731f, 0.30901699437494745f, 0.0f, -0.30901699437494734f, -0.587785252292473f, -0.8090169943749473f, -0.9510565162951535f, -1.0f, -0.9510565162951538f, -0.8090169943749476f, -0.5877852522924732f, -0.30901699437494756f, 0.0f, 0.30901699437494723f, 0.5877852522924729f, 0.8090169943749473f, 0.9510565162951535f};
+static __device__ const float kSin20[20] = {0.0f, 0.3090169943749474f, 0.5877852522924731f, 0.8090169943749475f, 0.9510565162951535f, 1.0f, 0.9510565162951536f, 0.8090169943749475f, 0.5877852522924732f, 0.3090169943749475f, 0.0f, -0.3090169943749469f, -0.587785252292473f, -0.8090169943749473f, -0.9510565162951535f, -1.0f, -0.9510565162951536f, -0.8090169943749476f, -0.5877852522924734f, -0.3090169943749476f};
+static __device__ const float kCos24[24] = {1.0f, 0.9659258262890683f, 0.8660254037844387f, 0.7071067811865476f, 0.5000000000000001f, 0.25881904510252074f, 0.0f, -0.25881904510252063f, -0.4999999999999998f, -0.7071067811865475f, -0.8660254037844387f, -0.9659258262890682f, -1.0f, -0.9659258262890683f, -0.8660254037844388f, -0.7071067811865479f, -0.5000000000000004f, -0.25881904510252063f, 0.0f, 0.2588190451025203f, 0.5000000000000001f, 0.7071067811865474f, 0.8660254037844384f, 0.9659258262890681f};
+static __device__ const float kSin24[24] = {0.0f, 0.25881904510252074f, 0.49999999999999994f, 0.7071067811865475f, 0.8660254037844386f, 0.9659258262890683f, 1.0f, 0.9659258262890683f, 0.8660254037844387f, 0.7071067811865476f, 0.49999999999999994f, 0.258819045102521f, 0.0f, -0.2588190451025208f, -0.4999999999999997f, -0.7071067811865471f, -0.8660254037844384f, -0.9659258262890683f, -1.0f, -0.9659258262890684f, -0.8660254037844386f, -0.7071067811865477f, -0.5000000000000004f, -0.25881904510252157f};
 template <int A, int B> __device__ __forceinline__ void dft_ct(cf (&v)[A * B], const float *cs, const float *sn) {
     cf y[A * B];
 #pragma unroll
@@ -192,6 +200,9 @@ template <> __device__ __forceinline__ void dft_small<10>(cf (&v)[10]) { dft_ct<
 template <> __device__ __forceinline__ void dft_small<12>(cf (&v)[12]) { dft_ct<4, 3>(v, kCos12, kSin12); }
 template <> __device__ __forceinline__ void dft_small<15>(cf (&v)[15]) { dft_ct<3, 5>(v, kCos15, kSin15); }
 template <> __device__ __forceinline__ void dft_small<16>(cf (&v)[16]) { dft_ct<4, 4>(v, kCos16, kSin16); }
+template <> __device__ __forceinline__ void dft_small<18>(cf (&v)[18]) { dft_ct<2, 9>(v, kCos18, kSin18); }
+template <> __device__ __forceinline__ void dft_small<20>(cf (&v)[20]) { dft_ct<4, 5>(v, kCos20, kSin20); }
+template <> __device__ __forceinline__ void dft_small<24>(cf (&v)[24]) { dft_ct<4, 6>(v, kCos24, kSin24); }
 
 // t / m and t % m for 0 <= t < 2^23 with a float reciprocal and a one-step fix-up
 __device__ __forceinline__ void divmod(int t, int m, float inv_m, int &q, int &r) {
@@ -201,7 +212,7 @@ __device__ __forceinline__ void divmod(int t, int m, float inv_m, int &q, int &r
     else if (r >= m) { r -= m; ++q; }
 }
 
-// The R - 1 twiddles W^q of one butterfly, W = tw[m]: the powers 1, 2, 4, 8 come from the table (exact), the others
+// The R - 1 twiddles W^q of one butterfly, W = tw[m]: the powers 1, 2, 4, 8 (, 16) come from the table (exact), the others
 // are products of two of them or of an earlier product (at most three roundings) -- four gathers instead of fifteen,
 // and no integer multiply per gather.
 template <int R>
@@ -213,7 +224,7 @@ __device__ __forceinline__ void twiddle_powers(cf (&w)[R], const float2 *__restr
 #pragma unroll
     for (int q = 3; q < R; ++q) {
         if ((q & (q - 1)) != 0) {
-            const int hi = q >= 8 ? 8 : (q >= 4 ? 4 : 2);
+            const int hi = q >= 16 ? 16 : (q >= 8 ? 8 : (q >= 4 ? 4 : 2));
             w[q] = cmul(w[hi], w[q - hi]);
         }
     }
@@ -263,9 +274,14 @@ __device__ __forceinline__ void stage(float2 *s, int N, int lognb, int L, const 
     }
 }
 
-template <bool DIT>
+// MAXR: the largest radix compiled in (a kernel's register allocation is that of its widest butterfly, taken or not: the
+// radices above 16 are only in the variants that run the plans holding them)
+template <bool DIT, int MAXR = 16>
 __device__ __forceinline__ void stage_any(float2 *s, int N, int lognb, int L, int radix, const float2 *tw) {
     switch (radix) {
+        case 24: if constexpr (MAXR >= 24) stage<24, DIT>(s, N, lognb, L, tw); break;
+        case 20: if constexpr (MAXR >= 24) stage<20, DIT>(s, N, lognb, L, tw); break;
+        case 18: if constexpr (MAXR >= 24) stage<18, DIT>(s, N, lognb, L, tw); break;
         case 16: stage<16, DIT>(s, N, lognb, L, tw); break;
         case 15: stage<15, DIT>(s, N, lognb, L, tw); break;
         case 12: stage<12, DIT>(s, N, lognb, L, tw); break;
@@ -387,6 +403,9 @@ __device__ __forceinline__ void last_stage(const float2 *s, int N, int lognb, co
 
 #define PB_FFT_RADIX_SWITCH(radix, CALL)                                                                       \
     switch (radix) {                                                                                           \
+        case 24: if constexpr (MAXR >= 24) { CALL(24); } break;                                                \
+        case 20: if constexpr (MAXR >= 24) { CALL(20); } break;                                                \
+        case 18: if constexpr (MAXR >= 24) { CALL(18); } break;                                                \
         case 16: CALL(16); break;                                                                              \
         case 15: CALL(15); break;                                                                              \
         case 12: CALL(12); break;                                                                              \
@@ -404,7 +423,7 @@ __device__ __forceinline__ void last_stage(const float2 *s, int N, int lognb, co
 __device__ __forceinline__ bool fused_plan(const DevPlan &p) { return p.line_n == p.n && p.nstage >= 2; }
 
 // Must be called by all threads of the workgroup; s needs no initialisation and holds nothing of interest afterwards.
-template <class IO>
+template <int MAXR = 16, class IO>
 __device__ __forceinline__ void spectral_derivative_fused(float2 *s, const DevPlan &p, int lognb, IO &io) {
     const int last = p.nstage - 1;
 #define PB_FIRST(R) first_stage<R>(s, p.n, lognb, p.tw, io)
@@ -413,7 +432,7 @@ __device__ __forceinline__ void spectral_derivative_fused(float2 *s, const DevPl
     __syncthreads();
     int L = p.n / p.radix[0];
     for (int i = 1; i < last; ++i) {
-        stage_any<false>(s, p.n, lognb, L, p.radix[i], p.tw);
+        stage_any<false, MAXR>(s, p.n, lognb, L, p.radix[i], p.tw);
         L /= p.radix[i];
         __syncthreads();
     }
@@ -423,7 +442,7 @@ __device__ __forceinline__ void spectral_derivative_fused(float2 *s, const DevPl
     __syncthreads();
     for (int i = last - 1; i >= 1; --i) {
         L *= p.radix[i];
-        stage_any<true>(s, p.n, lognb, L, p.radix[i], p.tw);
+        stage_any<true, MAXR>(s, p.n, lognb, L, p.radix[i], p.tw);
         __syncthreads();
     }
 #define PB_LAST(R) last_stage<R>(s, p.n, lognb, p.tw, io)

@@ -50,6 +50,20 @@ def test_fourier_gradients_sizes(eng, shape):
     assert maxabs(gx, rx) < 4e-6 * scale and maxabs(gy, ry) < 4e-6 * scale
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 4320, 40), (1, 1, 40, 7680), (2, 1, 3240, 24), (1, 1, 33, 4320), (1, 1, 7680, 18),
+                                   (1, 1, 12, 6480), (1, 1, 5400, 16)])
+def test_fourier_gradients_extended_radices(eng, shape):
+    """lines whose plan takes radices 18 / 20 / 24 to save a stage (4320 = 16 x 15 x 18, 7680 = 16 x 20 x 24 -- the 8K sides --,
+    3240, 5400, 6480): the 512-thread row variant and the 1024-thread column variants (csrc/estimate.hip: factorize,
+    plan_ext); the other kernel variants keep the greedy plan of the same length"""
+    rng = np.random.default_rng(13)
+    x = rng.random(shape, dtype=np.float32)
+    gx, gy = eng.fourier_gradients(x)
+    rx, ry = ref.spectral_gradients(x)
+    scale = max(1.0, float(np.abs(rx).max()), float(np.abs(ry).max()))
+    assert maxabs(gx, rx) < 4e-6 * scale and maxabs(gy, ry) < 4e-6 * scale
+
+
 def opts(**kw):
     from polyblur_amd.engine import Engine
     return Engine.make_options(**kw)
