@@ -87,6 +87,8 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     }
     if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
     if (const char *e = getenv("PB_STRIP")) ctx->strip_mode = atoi(e);
+    if (const char *e = getenv("PB_EST_GRAY_ROWS")) ctx->est_gray_rows = atoi(e);
+    if (const char *e = getenv("PB_FFT_EXT_RADIX")) ctx->fft_ext_radix = atoi(e);
     if (const char *e = getenv("PB_POLY1")) ctx->poly_mode = atoi(e);
     if (const char *e = getenv("PB_POLY_GAIN")) ctx->poly_gain = (float)atof(e);
     if (const char *e = getenv("PB_POLY_MIN_AREA")) ctx->poly_min_area = atoi(e);

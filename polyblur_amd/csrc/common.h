@@ -120,6 +120,8 @@ struct pb_ctx {
     long poly_min_pairs128 = 350;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
+    int est_gray_rows = 1;               // env PB_EST_GRAY_ROWS: 1 = gray + range + row transform in one launch where measured faster (fp32 planes, lines of up to 4096 samples), 2 = for any line held in LDS, 0 = never
+    int fft_ext_radix = 1;               // env PB_FFT_EXT_RADIX: 0 = greedy plans only (radices up to 16)
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes; --experimental builds only)
 };
 

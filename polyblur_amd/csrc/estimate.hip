@@ -54,8 +54,7 @@ static void factorize(int n, std::vector<int> &radix, int &rest, bool ext_ok = f
     // Lines held in LDS: where radices 18 / 20 / 24 save a stage over the greedy plan (4320 = 16 x 15 x 9 x 2 -> 18 x 16 x 15,
     // 7680 = 16 x 16 x 15 x 2 -> 24 x 20 x 16: two LDS round trips and barriers fewer per line), the plan with the fewest
     // stages and, among those, the smallest sum of radices; every other length keeps its greedy plan.
-    static const bool ext_off = getenv("PB_FFT_EXT_RADIX") && atoi(getenv("PB_FFT_EXT_RADIX")) == 0;
-    if (!ext_ok || rest != 1 || ext_off || (long)n0 * 8 > 160 * 1024 || radix.size() < 3) return;
+    if (!ext_ok || rest != 1 || (long)n0 * 8 > 160 * 1024 || radix.size() < 3) return;
     static const int ext[] = {24, 20, 18, 16, 15, 12, 10, 9, 8, 6, 5, 4, 7, 3, 2};
     std::vector<int> best, cur;
     int best_sum = 0;
@@ -139,7 +138,7 @@ const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices) {
     pl.n = n;
     std::vector<int> radix;
     int rest = 1;
-    factorize(n, radix, rest, ext_radices);
+    factorize(n, radix, rest, ext_radices && ctx->fft_ext_radix != 0);
     const double two_pi = 6.283185307179586476925286766559;
     int core = n;
     if (rest != 1) {               // Bluestein with a power-of-two core
@@ -1576,7 +1575,7 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
 // fused transform (the caller then runs the gray pass and launch_rows).  *partials = partials per image.
 int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, float *gray, float *gx, float2 **part,
                      int *partials) {
-    static const int on = [] { const char *e = getenv("PB_EST_GRAY_ROWS"); return e ? atoi(e) : 1; }();
+    const int on = ctx->est_gray_rows;
     if (!on) return PB_ERR_UNSUPPORTED;
     const FftPlan *pl = pb_get_plan(ctx, W, true);
     if (!pl) return PB_ERR_NOMEM;

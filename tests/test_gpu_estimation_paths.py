@@ -1,0 +1,77 @@
+"""The estimation's two launch sequences and two plan families give the same records.
+
+q == 0, fp32 planes, lines of up to 4096 samples: gray + range partials + row transform run as ONE launch
+(csrc/estimate.hip: gray_rows_kernel) instead of gray_minmax_kernel + grad_rows_kernel -- the same sums in the same order,
+so every field of the record must be bit-identical (PB_EST_GRAY_ROWS=0 / 1 / 2 select never / default / any line length).
+Lines of 4320 / 7680 / 3240 ... samples take radices 18 / 20 / 24 (PB_FFT_EXT_RADIX=0: the greedy plan): a different
+factorisation rounds differently, so those are compared within the tolerance of the reference goldens
+(tests/test_gpu_parity.py::test_estimate_blur) and against the oracle (blur_estimation.py:18-79)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import polyblur_ref as ref                      # the checker (tests only)
+from polyblur_amd.synthetic import synthetic_blurry_batch
+
+
+def _engine(**env):
+    from polyblur_amd.engine import Engine
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def engines():
+    return {"default": _engine(), "two_launches": _engine(PB_EST_GRAY_ROWS=0), "fused_any": _engine(PB_EST_GRAY_ROWS=2),
+            "greedy": _engine(PB_FFT_EXT_RADIX=0)}
+
+
+def opts(**kw):
+    from polyblur_amd.engine import Engine
+    return Engine.make_options(**kw)
+
+
+FIELDS = ("mags", "interp", "theta", "sigma", "rho", "kernel", "gray_min", "gray_max")
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 211, 157), (2, 1, 64, 96), (3, 3, 120, 4096), (1, 4, 75, 33), (1, 3, 36, 7680),
+                                   (2, 3, 1080, 1920)])
+def test_fused_gray_rows_is_bit_identical(engines, shape):
+    """odd heights (an unpaired last row), one / three / four channels, batches, the longest fused line (4096), and a line of
+    7680 samples that only PB_EST_GRAY_ROWS=2 fuses"""
+    B, C, H, W = shape
+    img, _ = synthetic_blurry_batch(B, C, H, W, seed0=31)
+    o = opts(c=0.362, b=0.468)
+    a = engines["two_launches"].estimate_blur(img, o)
+    for name in ("default", "fused_any"):
+        b = engines[name].estimate_blur(img, o)
+        for f in FIELDS:
+            assert np.array_equal(np.asarray(a[f]), np.asarray(b[f])), (name, f)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 4320, 64), (1, 1, 48, 7680), (1, 3, 3240, 40)])
+def test_extended_radix_plans_against_greedy_and_oracle(engines, shape):
+    B, C, H, W = shape
+    img, _ = synthetic_blurry_batch(B, C, H, W, seed0=37)
+    o = opts(c=0.362, b=0.468)
+    a = engines["greedy"].estimate_blur(img, o)
+    b = engines["default"].estimate_blur(img, o)
+    assert np.max(np.abs(np.asarray(a["mags"]) - np.asarray(b["mags"]))) < 5e-6
+    assert np.array_equal(np.asarray(a["theta"]), np.asarray(b["theta"]))
+    assert np.max(np.abs(np.asarray(a["sigma"]) - np.asarray(b["sigma"]))) < 2e-5
+    assert np.max(np.abs(np.asarray(a["rho"]) - np.asarray(b["rho"]))) < 2e-5
+    # the oracle's estimate of the same image
+    _, r = ref.estimate_gaussian_blur(img, c=0.362, b=0.468, return_info=True)
+    assert np.max(np.abs(np.asarray(b["mags"])[:, :7] - r["mags"])) < 5e-6
+    assert np.max(np.abs(np.asarray(b["sigma"]) - r["sigma"])) < 2e-5 and np.max(np.abs(np.asarray(b["rho"]) - r["rho"])) < 2e-5
