@@ -200,8 +200,19 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         const brsrc rin = plane_rsrc(ipl, a.in_plane);
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
         const int pitchb = a.in_pitch * (int)sizeof(TIn);
-        const bool inside = wy0 >= lo && wy0 + W_N <= Hp - lo && wxA >= lo && wxB + W_N <= Wp - lo && hasB;
-        if (sizeof(TIn) == 4 && inside && ((a.in_pitch | (wxA - lo)) & 3) == 0) {
+#ifdef PB_ABL_NO_BORDER      // (ablation: what the border windows cost -- wrong results)
+        const bool x_inside = true, y_inside = true;
+#else
+        const bool x_inside = wxA >= lo && wxB + W_N <= Wp - lo && hasB;
+        const bool y_inside = wy0 >= lo && wy0 + W_N <= Hp - lo;
+#endif
+        const bool inside = x_inside && y_inside;
+        // (rows beyond the image -- the first and the last row of tiles -- go through the boundary model per lane: one
+        // correction suffices for planes of at least a window's height)
+        // 16-byte pieces: both windows inside the source along x, on 16-byte boundaries; else (fp32, circular domain) a
+        // four-byte gather per lane through the boundary model -- either way global -> LDS without touching a register
+        const bool pieces = x_inside && (y_inside || Hp >= 2 * W_N) && ((a.in_pitch | (wxA - lo)) & 3) == 0;
+        if (sizeof(TIn) == 4 && (a.boundary == PB_WRAP ? true : (pieces && y_inside))) {
             // fp32 windows inside the source on 16-byte boundaries: every wave brings ITS 32 columns of both windows global ->
             // LDS in 16-byte pieces (four rows per wave instruction: 8 pieces of window A and 8 of window B per row), through
             // its quarter of the workgroup's LDS: four chunks of 32 rows -- 16 for the lower lanes, 16 for the upper --
@@ -211,11 +222,39 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             char *zw = reinterpret_cast<char *>(Z) + w * (int)(kW128Lds / 4);
             lds_char *zl = lds_ptr(zw);
             const int pc = lane & 15;
-            const unsigned vo = (unsigned)((lane >> 4) * pitchb + ((pc < 8 ? wxA : wxB - 32) - lo + 32 * w + 4 * pc) * 4);
+            const unsigned colb = (unsigned)(((pc < 8 ? wxA : wxB - 32) - lo + 32 * w + 4 * pc) * 4);
+            const unsigned vo = (unsigned)((lane >> 4) * pitchb) + colb;
+            const bool virt = a.in_kind == SRC_VIRTUAL;
             auto request = [&](int k, int buf) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)       // LDS rows 4 j .. 4 j + 3 of the chunk: lane half j >> 2, its rows 16 k + 4 (j & 3) ..
-                    dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (wy0 - lo + 64 * (j >> 2) + 16 * k + 4 * (j & 3)) * pitchb);
+                for (int j = 0; j < 8; ++j) {     // LDS rows 4 j .. 4 j + 3 of the chunk: lane half j >> 2, its rows 16 k + 4 (j & 3) ..
+                    const int p0 = wy0 + 64 * (j >> 2) + 16 * k + 4 * (j & 3);      // (padded coordinates, first of the four rows)
+                    if (y_inside) {
+                        dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (p0 - lo) * pitchb);
+                    } else {
+                        int pr = p0 + (lane >> 4);
+                        pr = pr < 0 ? pr + Hp : (pr >= Hp ? pr - Hp : pr);          // the circular domain (PB_WRAP) ...
+                        const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;   // ... of the replicate-padded plane
+                        dma16<0>(rin, zl + buf * 8192 + j * 1024, (unsigned)(row * pitchb) + colb, 0);
+                    }
+                }
+            };
+            // Windows that cross the plane's left or right border (the first and the last pair of a row of tiles: 9 % of the
+            // pairs at 4K, and they took 2.5 x the time of the others sample by sample): lane l gathers column l of window A
+            // (l < 32) or B through the boundary model, one LDS row of 256 bytes per wave instruction, its row mapped on the
+            // scalar side; the chunk then looks exactly like one that arrived in 16-byte pieces.
+            const int gx = (lane < 32 || hasB ? (lane < 32 ? wxA : wxB) : wxA) + 32 * w + (lane & 31);   // (no window B: A's samples again -- finite, never stored)
+            const int gix = map_axis(gx, a.W, a.in_kind, a.boundary, a.pad);
+            const unsigned gcol = (unsigned)(gix * (int)sizeof(TIn));
+            auto gather = [&](int k, int buf) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {    // LDS row i of the chunk: window row 16 k + i (i < 16) or 64 + 16 k + i - 16
+                    int pr = wy0 + 16 * k + (i < 16 ? i : 48 + i);
+                    while (pr < 0) pr += Hp;
+                    while (pr >= Hp) pr -= Hp;
+                    const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;
+                    dma4<0>(rin, zl + buf * 8192 + i * 256, gcol, row * pitchb);
+                }
             };
             // Both lanes of a pair read BOTH halves' rows of the chunk (LDS rows i and 16 + i of a buffer: 256 bytes each, A then
             // B) and form a + b (lower lanes) or a - b (upper lanes) themselves: the columns' forward radix-2 step without its
@@ -243,17 +282,31 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[16 * k + i] = v[16 * k + i] + tb[i] * sg;
             };
-            request(0, 0); request(1, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            pick(0, 0);
-            request(2, 0);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            pick(1, 1);
-            request(3, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            pick(2, 0);
-            wait_vm0();
-            pick(3, 1);
+            if (pieces) {
+                request(0, 0); request(1, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(0, 0);
+                request(2, 0);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(1, 1);
+                request(3, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                pick(2, 0);
+                wait_vm0();
+                pick(3, 1);
+            } else {
+                gather(0, 0); gather(1, 1);
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                pick(0, 0);
+                gather(2, 0);
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                pick(1, 1);
+                gather(3, 1);
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                pick(2, 0);
+                wait_vm0();
+                pick(3, 1);
+            }
             __syncthreads();                                        // (the transposes reuse every wave's quarter)
             r2_twiddle_fwd(v, upper);
         } else if (inside) {
@@ -326,8 +379,8 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         const brsrc ro = plane_rsrc(opl, a.out_plane);
         const float clo = a.clamp01 ? 0.f : -INFINITY, chi = a.clamp01 ? 1.f : INFINITY;
         const int rmax = min(W_N - hy, rg.y_hi - wy0);              // window rows hy .. rmax - 1 are the tile's rows inside the region
-        if (hasB && wxB + W_N - hx <= rg.x_hi && ((a.out_pitch | (wxA - oo)) & 3) == 0) {
-            // both tiles complete along x, 16-byte boundaries: every wave sends ITS 32 columns of both windows through its
+        if (((a.out_pitch | (wxA - oo) | (rg.x_hi - wxA)) & 3) == 0) {
+            // 16-byte boundaries (tiles, plane rows and the region's end): every wave sends ITS 32 columns of both windows through its
             // quarter of the LDS (written by columns, read back as 16-byte row pieces: 8 of window A, 8 of window B per row,
             // four rows per wave instruction), registers 0 .. 31 of both lane halves first, then 32 .. 63 -- 32 stores of 1 KB
             // per wave instead of 128 of 256 bytes.  The columns' inverse radix-2 step rides along: the lanes write e (lower
@@ -337,7 +390,9 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             float *zt = zw + (32 * h) * 64 + c;
             const int pc = lane & 15, lr = lane >> 4;
             const int xcol = 32 * w + 4 * (pc & 7);                 // first window column of this lane's piece
-            const bool colok = xcol >= hx && xcol < W_N - hx;
+            // (the last pair of a row of tiles: a narrower last tile, or no window B at all -- whole pieces fall away, the
+            // region ends on a piece boundary)
+            const bool colok = xcol >= hx && xcol < W_N - hx && (pc < 8 || hasB) && (pc < 8 ? wxA : wxB) + xcol + 4 <= rg.x_hi;
             const int cb = ((pc < 8 ? wxA : wxB) + xcol - oo) * (int)sizeof(TOut), rb = (wy0 - oo + lr) * opitchb;   // (rb < 0 above the plane: only for rows outside the tile)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {

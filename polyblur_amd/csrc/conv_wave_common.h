@@ -178,6 +178,10 @@ template <int IMM> __device__ __forceinline__ void dma16(brsrc r, lds_char *dst,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)dst, 16, (int)voffset, soffset, IMM, 0);
 }
 #pragma clang diagnostic pop
+// (four bytes per lane: lane l's sample lands at dst + 4 l -- a gather of one 256-byte LDS row from 64 arbitrary addresses)
+template <int IMM> __device__ __forceinline__ void dma4(brsrc r, lds_char *dst, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)dst, 4, (int)voffset, soffset, IMM, 0);
+}
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lds0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 typedef float f4v __attribute__((ext_vector_type(4)));

@@ -84,9 +84,16 @@ __device__ unsigned long long g_wf_trace[kTraceWaves * kTraceStamps];
 // shift of its input, so the transforms do not notice, and the epilogue walks registers 0 .. Ty - 1 whatever hy is: the row
 // halo is a run-time value (every row offset is scalar work); only register numbers have to be compile-time constants.
 // Columns are lanes: their halo is a per-lane predicate.
-template <bool FAST, typename TIn, typename TX, typename TOut>
+// MODE 1: interior pairs on 16-byte boundaries (pair_is_fast); MODE 2: the same structure for the border pairs of the
+// circular domain (pair_is_gen: fp32 windows gathered through the boundary model, tiles cut by the region's end, an x
+// operand that needs the replicate clamp); MODE 0: everything else, sample by sample.
+#ifdef PB_MODE_COUNT
+__device__ unsigned g_mode_count[4];
+#endif
+template <int MODE, typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, int hx, int hy,
                                           char *zb, const float *kp, unsigned long long *tr) {
+    constexpr bool FAST = MODE != 0, GEN = MODE == 2;
     const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
     PB_T(1);
     float2 *Z = reinterpret_cast<float2 *>(zb);
@@ -145,17 +152,53 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                                  "+v"(v[17 + 2 * k]), "+v"(v[24 + 2 * k]), "+v"(v[25 + 2 * k]), "+v"(v[32 + 2 * k]), "+v"(v[33 + 2 * k]), "+v"(v[40 + 2 * k]),
                                  "+v"(v[41 + 2 * k]), "+v"(v[48 + 2 * k]), "+v"(v[49 + 2 * k]), "+v"(v[56 + 2 * k]), "+v"(v[57 + 2 * k]) :: "memory");
                 };
-                request(0, 0); request(1, 1);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                pick(0, 0);
-                request(2, 0);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                pick(1, 1);
-                request(3, 1);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                pick(2, 0);
-                wait_vm0();
-                pick(3, 1);
+                bool pieces = true;
+                if constexpr (GEN) pieces = wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB && ((a.in_pitch | (wxA - lo)) & 3) == 0;
+                if (pieces) {
+                    request(0, 0); request(1, 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    pick(0, 0);
+                    request(2, 0);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    pick(1, 1);
+                    request(3, 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    pick(2, 0);
+                    wait_vm0();
+                    pick(3, 1);
+                } else if constexpr (GEN) {
+                    // Border pairs of the circular domain: the same chunks through the same two LDS buffers, but gathered four
+                    // bytes per lane through the boundary model -- lane = column of window A (one wave instruction = the A half
+                    // of an LDS row) or of window B (its other half), the row mapped on the scalar side: 128 wave instructions
+                    // that touch no register, then the same LDS reads.
+                    const unsigned gcolA = (unsigned)map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;
+                    const unsigned gcolB = (unsigned)map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;   // (no window B: A's samples again -- finite, never stored)
+                    const int base = __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp));
+                    const bool virt_in = a.in_kind == SRC_VIRTUAL;
+                    auto gather = [&](int k, int buf) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {     // LDS row i of the chunk = register 8 (i >> 1) + 2 k + (i & 1)
+                            const int r = 8 * (i >> 1) + 2 * k + (i & 1);
+                            int pr = base + r - (r >= wrap_r ? FT_N : 0);
+                            while (pr < 0) pr += Hp;
+                            while (pr >= Hp) pr -= Hp;
+                            const int so = (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb;
+                            dma4<0>(rin, zl + buf * 8192 + i * 512, gcolA, so);
+                            dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, gcolB, so);
+                        }
+                    };
+                    gather(0, 0); gather(1, 1);
+                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    pick(0, 0);
+                    gather(2, 0);
+                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    pick(1, 1);
+                    gather(3, 1);
+                    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    pick(2, 0);
+                    wait_vm0();
+                    pick(3, 1);
+                }
             } else {
                 // fp16 window (the first step, or the one-pass polynomial, of an fp16 image): a 16-byte piece is eight samples
                 // and windows start on multiples of four, so each window is fetched from the 16-byte boundary at or before
@@ -205,6 +248,52 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                 wait_vm0();
                 pick(3, 1);
             }
+        } else if (sizeof(TIn) == 4 && a.boundary == PB_WRAP) {
+            // Border pairs of the circular domain, fp32: the same chunks through the same two LDS buffers, but gathered four
+            // bytes per lane through the boundary model -- lane = column of window A (one wave instruction = the A half of an
+            // LDS row) or of window B (its other half), the row mapped on the scalar side: 128 wave instructions that touch no
+            // register, then the loader's own LDS reads (sample by sample into the registers this took 128 loads per lane
+            // and made the border pairs -- 8 % of the pairs at 4K, 15 % at 1080p -- the stragglers of every launch).
+            lds_char *zl = lds_ptr(zb);
+            const unsigned gcolA = (unsigned)map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;
+            const unsigned gcolB = (unsigned)map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;   // (no window B: A's samples again -- finite, never stored)
+            const int base = __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp));
+            const bool virt_in = a.in_kind == SRC_VIRTUAL;
+            auto gather = [&](int k, int buf) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {     // LDS row i of the chunk = register 8 (i >> 1) + 2 k + (i & 1)
+                    const int r = 8 * (i >> 1) + 2 * k + (i & 1);
+                    int pr = base + r - (r >= wrap_r ? FT_N : 0);
+                    while (pr < 0) pr += Hp;
+                    while (pr >= Hp) pr -= Hp;
+                    const int so = (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb;
+                    dma4<0>(rin, zl + buf * 8192 + i * 512, gcolA, so);
+                    dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, gcolB, so);
+                }
+            };
+            const unsigned la = lds_addr(zb) + (unsigned)lane * 4u;
+            auto pick = [&](int k, int buf) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned ad = la + (unsigned)(buf * 8192 + j * 1024);
+                    asm volatile("ds_read2_b32 %0, %1 offset1:64" : "=v"(v[8 * j + 2 * k]) : "v"(ad));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:128 offset1:192" : "=v"(v[8 * j + 2 * k + 1]) : "v"(ad));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[2 * k]), "+v"(v[2 * k + 1]), "+v"(v[8 + 2 * k]), "+v"(v[9 + 2 * k]), "+v"(v[16 + 2 * k]),
+                             "+v"(v[17 + 2 * k]), "+v"(v[24 + 2 * k]), "+v"(v[25 + 2 * k]), "+v"(v[32 + 2 * k]), "+v"(v[33 + 2 * k]), "+v"(v[40 + 2 * k]),
+                             "+v"(v[41 + 2 * k]), "+v"(v[48 + 2 * k]), "+v"(v[49 + 2 * k]), "+v"(v[56 + 2 * k]), "+v"(v[57 + 2 * k]) :: "memory");
+            };
+            gather(0, 0); gather(1, 1);
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            pick(0, 0);
+            gather(2, 0);
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            pick(1, 1);
+            gather(3, 1);
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            pick(2, 0);
+            wait_vm0();
+            pick(3, 1);
         } else if (wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && hasB) {
             const unsigned colA = (unsigned)(wxA - lo + lane) * (unsigned)sizeof(TIn), colB = colA + (unsigned)Tx * (unsigned)sizeof(TIn);
 #pragma unroll
@@ -307,33 +396,61 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
         }
         const int xso = (oy0 - xsh) * xpitchb + (oxA - xsh) * (int)sizeof(TX);
         const int oso = (oy0 - oo) * opitchb + (oxA - oo) * (int)sizeof(TOut);
+        // MODE 2 (border pairs): rows beyond the region's end fall away (tyr), whole pieces beyond its right end too (the end
+        // lies on a piece boundary: bit k of `cut`); the x operand of a tile in the pad ring is the replicate-clamped image --
+        // rows clamped per piece, and a piece left (right) of the image is the image's first (last) sample four times (the
+        // image starts and ends on piece boundaries: bits 4 + k and 8 + k of `cut`).  One register of flags per lane; the
+        // interior pairs' code (MODE 1) is unchanged.
+        const int tyr = GEN ? min(Ty, rg.y_hi - oy0) : Ty;
+        const int xw = virt ? a.W : Wp, xh = virt ? a.H : Hp;
+        int cut = 0, cxb[4] = {0, 0, 0, 0};
+        if constexpr (GEN) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cx = oxA - xsh + 4 * chk[k];              // the piece's first column in the x plane
+                if (oxA + 4 * chk[k] + 4 > rg.x_hi) cut |= 1 << k;
+                if (cx < 0) cut |= 16 << k;
+                if (cx > xw - 4) cut |= 256 << k;
+                cxb[k] = min(max(cx, 0), xw - 4) * (int)sizeof(TX);
+            }
+        }
         typename Piece4<TX>::raw xq[4][4];
         auto request = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            const int left = Ty - 8 * q;                        // rows of this round inside the tile (<= 0: none)
+            const int left = tyr - 8 * q;                       // rows of this round inside the tile (<= 0: none)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const bool ok = usex && rlk[k] < min(left, 8);
-                xq[q & 3][k] = Piece4<TX>::ld(rx, ok ? (unsigned)(rlk[k] * xpitchb + chk[k] * XP) : kNoAccess, xso + 8 * q * xpitchb);
+                if constexpr (GEN) {
+                    const bool ok = usex && rlk[k] < min(left, 8) && !(cut & (1 << k));
+                    const int xr = min(max(oy0 - xsh + 8 * q + rlk[k], 0), xh - 1);
+                    xq[q & 3][k] = Piece4<TX>::ld(rx, ok ? (unsigned)(xr * xpitchb + cxb[k]) : kNoAccess, 0);
+                } else {
+                    const bool ok = usex && rlk[k] < min(left, 8);
+                    xq[q & 3][k] = Piece4<TX>::ld(rx, ok ? (unsigned)(rlk[k] * xpitchb + chk[k] * XP) : kNoAccess, xso + 8 * q * xpitchb);
+                }
             }
         };
         // (the final clamp without a branch per piece: the bounds are infinite where the pass does not clamp)
         const float clo = cl ? 0.f : -INFINITY, chi = cl ? 1.f : INFINITY;
         auto round = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            const int left = Ty - 8 * q;
+            const int left = tyr - 8 * q;
             f4v acc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = *reinterpret_cast<const f4v *>(Zf + (8 * (q & 3) + min(rlk[k], 7)) * 128 + 4 * chk[k]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const f4v x4 = Piece4<TX>::to_f(xq[q & 3][k]);
+                f4v x4 = Piece4<TX>::to_f(xq[q & 3][k]);
+                if constexpr (GEN) {
+                    if (cut & (16 << k)) { x4.y = x4.x; x4.z = x4.x; x4.w = x4.x; }
+                    if (cut & (256 << k)) { x4.x = x4.w; x4.y = x4.w; x4.z = x4.w; }
+                }
                 f4v o;
                 o.x = fmaf(sc, acc[k].x, cfx * x4.x); o.y = fmaf(sc, acc[k].y, cfx * x4.y);
                 o.z = fmaf(sc, acc[k].z, cfx * x4.z); o.w = fmaf(sc, acc[k].w, cfx * x4.w);
                 o.x = __builtin_amdgcn_fmed3f(o.x, clo, chi); o.y = __builtin_amdgcn_fmed3f(o.y, clo, chi);
                 o.z = __builtin_amdgcn_fmed3f(o.z, clo, chi); o.w = __builtin_amdgcn_fmed3f(o.w, clo, chi);
-                const bool ok = rlk[k] < min(left, 8);
+                const bool ok = rlk[k] < min(left, 8) && !(GEN && (cut & (1 << k)));
                 Piece4<TOut>::st(ro, ok ? (unsigned)(rlk[k] * opitchb + chk[k] * OP) : kNoAccess, oso + 8 * q * opitchb, o);
             }
         };
@@ -458,6 +575,9 @@ template <typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi, int hx, int hy) {
     // (the x operand and the output may be fp16: four samples are then an 8-byte piece)
     if (sizeof(TIn) < 2 || a.epilogue != EPI_HORNER) return false;      // (an 8-bit window -- the first step of an 8-bit image -- is fetched sample by sample)
+#ifdef PB_ABL_ALLFAST       // (ablation: what the border pairs cost -- wrong results)
+    return true;
+#endif
     if (sizeof(TIn) == 2 && (a.in_pitch & 7) != 0) return false;      // (fp16 window: rows on 16-byte boundaries)
     const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
     const OutRegion rg = out_region(a);
@@ -471,6 +591,21 @@ __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi,
     return wy0 >= lo && wy0 + FT_N <= Hp - lo && wxA >= lo && wxB + FT_N <= Wp - lo && oy0 + Ty <= rg.y_hi && oxA + 2 * Tx <= rg.x_hi &&
            oy0 - xsh >= 0 && oxA - xsh >= 0 && oy0 + Ty - xsh <= xh && oxA + 2 * Tx - xsh <= xw &&
            ((a.in_pitch | a.x_pitch | a.out_pitch | (wxA - lo) | (oxA - xsh) | (oxA - oo)) & 3) == 0;
+}
+
+// Whether a border pair takes the same structure (MODE 2): fp32 windows of the circular domain (gathered through the boundary
+// model where they are not inside the source), a plain Horner epilogue, rows and the region's and the x plane's ends on
+// 16-byte boundaries.
+template <typename TIn, typename TX, typename TOut>
+__device__ __forceinline__ bool pair_is_gen(const ConvPass &a, int pxi, int hx) {
+    if (sizeof(TIn) != 4 || a.epilogue != EPI_HORNER || a.boundary != PB_WRAP) return false;
+    const int Tx = FT_N - 2 * hx;
+    const OutRegion rg = out_region(a);
+    const int Wp = a.W + 2 * a.pad;
+    const bool virt = a.x_kind == SRC_VIRTUAL;
+    const int oo = a.out_kind == OUT_INTERIOR ? a.pad : 0, xsh = virt ? a.pad : 0, xw = virt ? a.W : Wp;
+    const int oxA = rg.x_lo + 2 * pxi * Tx;
+    return xw >= 4 && ((a.x_pitch | a.out_pitch | (oxA - xsh) | (oxA - oo) | (rg.x_hi - oxA) | xw) & 3) == 0;
 }
 
 // One wave (= one workgroup) per window pair; the GRID is the job list.  The jobs are the window pairs of the images whose
@@ -543,8 +678,12 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     const float *kp = a.khat + (long)img * PB_KHAT_STRIDE;
     const pb_blur_info *info = a.info + img;
     const ConvPass af = fold_pass(a, fold);
-    if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<true, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
-    else wave_pair<false, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
+#ifdef PB_MODE_COUNT      // (debug build: how many pairs take which structure -- tools/_abl/mode_count.py)
+    if (lane == 0) atomicAdd(&g_mode_count[pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy) ? 1 : (pair_is_gen<TIn, TX, TOut>(af, pxi, hx) ? 2 : 0)], 1u);
+#endif
+    if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<1, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
+    else if (pair_is_gen<TIn, TX, TOut>(af, pxi, hx)) wave_pair<2, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
+    else wave_pair<0, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
 }
 
 // The output extent of a pass and the largest job list its records may ask for: `poly2` = the records may carry one-pass
@@ -656,3 +795,12 @@ int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
         default: return PB_ERR_UNSUPPORTED;
     }
 }
+
+#ifdef PB_MODE_COUNT
+extern "C" int pb_debug_mode_count(unsigned *host, int reset) {
+    unsigned z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mode_count), sizeof(z)) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_mode_count), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
