@@ -112,10 +112,12 @@ struct pb_ctx {
     // cost model of the general one-pass form (PolySpec.on == 2; env PB_POLY_GAIN, PB_POLY_MIN_AREA): an image takes it when
     // its composite tile has at least poly_min_area samples and -- an image that would otherwise take three tile-spectrum
     // passes -- 3 x that area is at least poly_gain x the tile area of its three-step windows (cost per output sample, in
-    // window pairs: 3 / (poly_gain x three-step tile area) against 1 / composite tile area; measured at 4K: a one-pass window
-    // costs what a three-step window costs, gain = 1; one pass over 768-sample tiles takes what three rank-1 stencil passes
-    // take)
-    float poly_gain = 1.0f;
+    // window pairs: 3 / (poly_gain x three-step tile area) against 1 / composite tile area).  A Horner step costs more than a
+    // one-pass window of the same tile -- the x operand, 8 words per sample instead of 2, two launches more: measured 0.254 ms
+    // for three steps at 40 x 40 tiles against 0.153 ms for one pass on 128 x 128 windows at 64 x 68 tiles (4K), 0.092 against
+    // 0.050 at 1080p -- hence 0.7 (swept on 32 x 1080p: 1.0 -> 6.61, 0.85 -> 6.26, 0.7 -> 6.14, 0.6 -> 6.15 ms per step); one
+    // pass over 768-sample tiles takes what three rank-1 stencil passes take
+    float poly_gain = 0.7f;
     int poly_min_area = 768;
     long poly_min_pairs128 = 350;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
@@ -181,7 +183,7 @@ enum { EPI_HORNER = 0,    // out = scale * (K*in) + coef * x   [+ clamp]
 // per image: which body evaluates a dense kernel (written on the device by khat_kernel, conv_fft.hip)
 constexpr int PB_SEL_SLOTS = 16;
 constexpr int PB_KHAT_STRIDE = 128 * 128;                  // floats of spectrum per image in "conv.khat": 64 x 64 of them, or 128 x 128 (one pass on 128 x 128 windows)
-constexpr int PB_POLY128_MIN_T = 64;                       // smallest tile side of a one-pass 128 x 128 window (bounds the job grid)
+constexpr int PB_POLY128_MIN_T = 56;                       // smallest tile side of a one-pass 128 x 128 window (bounds the job grid): composite halos up to 36 = 3 x 12, every composite there is
 constexpr int PB_POLY_MIN_TX = 24, PB_POLY_MIN_TY = 16;     // smallest tile of a one-pass window (bounds the job grid)
 
 
