@@ -1673,7 +1673,18 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
                            lds, ctx->stream, planes, gx, gy, H, W, lognb, normalize ? 1 : 0, mm,                 \
                            planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);            \
     } while (0)
-    if (ext && mode == 0) PB_COLS_EXT(0, 0);
+    // (a plan whose widest radix is 18 -- 4320 = 16 x 15 x 18, the 8K height -- runs the variant without 20 and 24: fewer
+    // registers spilled around the butterflies it does take)
+    int maxr = 0;
+    for (int i = 0; i < pl->nstage; ++i) maxr = std::max(maxr, pl->radix[i]);
+    if (ext && mode == 1 && maxr <= 18) {
+        int rc = allow_lds(ctx, grad_cols_kernel<1, 7, 1024, 18>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((grad_cols_kernel<1, 7, 1024, 18>), dim3((unsigned)((blocks + 7) / 8 * 8)), dim3(1024),
+                           lds, ctx->stream, planes, gx, gy, H, W, lognb, normalize ? 1 : 0, mm,
+                           planes_per_image, mags, n_angles, discard_sat, thr, (int)blocks, dp, ang);
+    }
+    else if (ext && mode == 0) PB_COLS_EXT(0, 0);
     else if (ext) PB_COLS_EXT(1, 7);
     else if (mode == 0 && nt == 512) {
         // (192 x 1080p planes: 2.27 -> 1.61 ms against 8-column tiles with 256 threads)

@@ -281,7 +281,7 @@ __device__ __forceinline__ void stage_any(float2 *s, int N, int lognb, int L, in
     switch (radix) {
         case 24: if constexpr (MAXR >= 24) stage<24, DIT>(s, N, lognb, L, tw); break;
         case 20: if constexpr (MAXR >= 24) stage<20, DIT>(s, N, lognb, L, tw); break;
-        case 18: if constexpr (MAXR >= 24) stage<18, DIT>(s, N, lognb, L, tw); break;
+        case 18: if constexpr (MAXR >= 18) stage<18, DIT>(s, N, lognb, L, tw); break;
         case 16: stage<16, DIT>(s, N, lognb, L, tw); break;
         case 15: stage<15, DIT>(s, N, lognb, L, tw); break;
         case 12: stage<12, DIT>(s, N, lognb, L, tw); break;
@@ -405,7 +405,7 @@ __device__ __forceinline__ void last_stage(const float2 *s, int N, int lognb, co
     switch (radix) {                                                                                           \
         case 24: if constexpr (MAXR >= 24) { CALL(24); } break;                                                \
         case 20: if constexpr (MAXR >= 24) { CALL(20); } break;                                                \
-        case 18: if constexpr (MAXR >= 24) { CALL(18); } break;                                                \
+        case 18: if constexpr (MAXR >= 18) { CALL(18); } break;                                                \
         case 16: CALL(16); break;                                                                              \
         case 15: CALL(15); break;                                                                              \
         case 12: CALL(12); break;                                                                              \
