@@ -507,7 +507,14 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
         ctx->known_sel = nullptr;
         return rc;
     };
-    if (!fft || have || !ctx->aux || ctx->prof_on) {
+    // The side stream pays where the launches that may find no work are expensive -- one workgroup per 64 x 64 tile of every
+    // plane: 6 us at 4K, 33 us for 32 x 1080p -- against two queue-to-queue waits per polynomial (~5 - 8 us each); a single
+    // image of up to 4K runs everything on the caller's stream (measured: 4K 0.738 -> 0.722 ms of device time per call, while
+    // 32 x 1080p would go from 6.09 to 6.61 ms without the side stream).
+    static const long side_min_tiles = [] { const char *e = getenv("PB_SIDE_MIN_TILES"); return e ? atol(e) : 12288L; }();
+    const long stencil_tiles = (long)((steps[0].H + 2 * steps[0].pad + 63) / 64) * ((steps[0].W + 2 * steps[0].pad + 63) / 64) * steps[0].P;
+    const bool side = ctx->aux && stencil_tiles >= side_min_tiles;
+    if (!fft || have || !side || ctx->prof_on) {
         if (fft && ctx->poly_want.on == 3) {
             float *k = nullptr; pb_fft_sel *sel = nullptr;
             const bool built = (have || ctx->khat_by_estimate) && ctx->khat_owner == steps[0].info && ctx->khat_B == B;
@@ -539,10 +546,25 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     hipStream_t main_stream = ctx->stream;
+    // Which launches stay on the caller's stream: those that probably do the work -- crossing to the side stream and back
+    // costs two queue-to-queue waits (~5 us each) on the critical path.  Where the spec admits 128 x 128 windows (images of
+    // poly_min_pairs128 window pairs or more: decided from the sizes alone, api.hip) that is the 128 x 128 launch, and the
+    // wave body's three launches join the stencil launches on the side stream; otherwise the wave body's.
+    static const int main_env = [] { const char *e = getenv("PB_MAIN_STREAM_BODY"); return e ? atoi(e) : -1; }();     // 0 = wave body, 1 = 128 x 128
+    const bool w128_main = poly_on && ctx->poly_want.on == 3 && ctx->poly_want.cost128 > 0.f && main_env != 0;
+    auto wave_steps = [&]() {
+        for (int s = 0; s < 3 && !rc; ++s) {
+            ConvPass p = steps[s];
+            p.khat = k; p.fsel = sel;
+            if (s == 0) first_step(p);
+            rc = launch_tile_spectrum(ctx, p);
+        }
+    };
     ctx->stream = ctx->aux;
     // (the composite pass touches other images than the steps' launches do: it, too, runs -- or finds no work -- beside them)
-    if (poly_on) rc = composite128(k, sel);
+    if (poly_on && !w128_main) rc = composite128(k, sel);
     if (poly_on && !fold && !rc) rc = composite(k, sel);
+    if (w128_main) wave_steps();
     for (int s = 0; s < 3 && !rc; ++s) {
         ConvPass p = steps[s];
         p.khat = k; p.fsel = sel;
@@ -551,12 +573,8 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     ctx->stream = main_stream;
     // (whatever was queued on the side stream is joined on every path out of here: later calls share the scratch planes)
     PB_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
-    for (int s = 0; s < 3 && !rc; ++s) {
-        ConvPass p = steps[s];
-        p.khat = k; p.fsel = sel;
-        if (s == 0) first_step(p);
-        rc = launch_tile_spectrum(ctx, p);
-    }
+    if (w128_main) { if (!rc) rc = composite128(k, sel); }
+    else wave_steps();
     PB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return rc;
 }
