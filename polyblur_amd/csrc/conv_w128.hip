@@ -200,12 +200,8 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         const brsrc rin = plane_rsrc(ipl, a.in_plane);
         const int lo = a.in_kind == SRC_VIRTUAL ? a.pad : 0;
         const int pitchb = a.in_pitch * (int)sizeof(TIn);
-#ifdef PB_ABL_NO_BORDER      // (ablation: what the border windows cost -- wrong results)
-        const bool x_inside = true, y_inside = true;
-#else
         const bool x_inside = wxA >= lo && wxB + W_N <= Wp - lo && hasB;
         const bool y_inside = wy0 >= lo && wy0 + W_N <= Hp - lo;
-#endif
         const bool inside = x_inside && y_inside;
         // (rows beyond the image -- the first and the last row of tiles -- go through the boundary model per lane: one
         // correction suffices for planes of at least a window's height)

@@ -87,9 +87,6 @@ __device__ unsigned long long g_wf_trace[kTraceWaves * kTraceStamps];
 // MODE 1: interior pairs on 16-byte boundaries (pair_is_fast); MODE 2: the same structure for the border pairs of the
 // circular domain (pair_is_gen: fp32 windows gathered through the boundary model, tiles cut by the region's end, an x
 // operand that needs the replicate clamp); MODE 0: everything else, sample by sample.
-#ifdef PB_MODE_COUNT
-__device__ unsigned g_mode_count[4];
-#endif
 template <int MODE, typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, int hx, int hy,
                                           char *zb, const float *kp, unsigned long long *tr) {
@@ -575,9 +572,6 @@ template <typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi, int hx, int hy) {
     // (the x operand and the output may be fp16: four samples are then an 8-byte piece)
     if (sizeof(TIn) < 2 || a.epilogue != EPI_HORNER) return false;      // (an 8-bit window -- the first step of an 8-bit image -- is fetched sample by sample)
-#ifdef PB_ABL_ALLFAST       // (ablation: what the border pairs cost -- wrong results)
-    return true;
-#endif
     if (sizeof(TIn) == 2 && (a.in_pitch & 7) != 0) return false;      // (fp16 window: rows on 16-byte boundaries)
     const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
     const OutRegion rg = out_region(a);
@@ -678,9 +672,6 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     const float *kp = a.khat + (long)img * PB_KHAT_STRIDE;
     const pb_blur_info *info = a.info + img;
     const ConvPass af = fold_pass(a, fold);
-#ifdef PB_MODE_COUNT      // (debug build: how many pairs take which structure -- tools/_abl/mode_count.py)
-    if (lane == 0) atomicAdd(&g_mode_count[pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy) ? 1 : (pair_is_gen<TIn, TX, TOut>(af, pxi, hx) ? 2 : 0)], 1u);
-#endif
     if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<1, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
     else if (pair_is_gen<TIn, TX, TOut>(af, pxi, hx)) wave_pair<2, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
     else wave_pair<0, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
@@ -795,12 +786,3 @@ int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
         default: return PB_ERR_UNSUPPORTED;
     }
 }
-
-#ifdef PB_MODE_COUNT
-extern "C" int pb_debug_mode_count(unsigned *host, int reset) {
-    unsigned z[4] = {0, 0, 0, 0};
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mode_count), sizeof(z)) != hipSuccess) return 1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_mode_count), z, sizeof(z)) != hipSuccess) return 1;
-    return 0;
-}
-#endif

@@ -1864,9 +1864,6 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
         if (rc) return rc;
     }
     ProfScope prof(ctx, PB_PROF_PARAMS);
-#ifdef PB_ABL_PARAMS_REPS
-    for (int rep = 0; rep < PB_ABL_PARAMS_REPS; ++rep)
-#endif
     hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? KH_SLICES : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, est_tiles, ksize,
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
