@@ -119,7 +119,7 @@ struct pb_ctx {
     // pass over 768-sample tiles takes what three rank-1 stencil passes take
     float poly_gain = 0.7f;
     int poly_min_area = 768;
-    long poly_min_pairs128 = 350;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels)
+    long poly_min_pairs128 = 150;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels): 720p x 3 (180 pairs: 0.385 -> 0.325 ms per call) and up; 700 x 500 x 3 (72 pairs) is slower with them (0.256 -> 0.279)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
     int est_gray_rows = 1;               // env PB_EST_GRAY_ROWS: 1 = gray + range + row transform in one launch where measured faster (fp32 planes, lines of up to 4096 samples), 2 = for any line held in LDS, 0 = never

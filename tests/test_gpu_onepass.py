@@ -21,7 +21,7 @@ from polyblur_amd.synthetic import synthetic_blurry_batch
 
 def _engine(mode):
     """a context with PB_POLY1=mode; PB_POLY_MIN_PAIRS128=0 lets images of any size take 128 x 128 windows (by default only
-    images of 350 window pairs or more do -- 1080p x 3 channels and up; tests/test_gpu_fullsize.py runs those through the default context)"""
+    images of 150 window pairs or more do -- 720p x 3 channels and up; tests/test_gpu_fullsize.py runs those through the default context)"""
     from polyblur_amd.engine import Engine
     old = {k: os.environ.get(k) for k in ("PB_POLY1", "PB_POLY_MIN_PAIRS128")}
     os.environ["PB_POLY1"] = str(mode)
