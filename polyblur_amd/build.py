@@ -17,9 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libpolyblur_hip.so"
-SOURCES = ["api.hip", "comm.hip", "conv.hip", "conv_fft.hip", "conv_big.hip", "conv_wfft.hip", "conv_w128.hip", "conv_xt.hip", "estimate.hip", "filters.hip", "nc.hip"]
+SOURCES = ["api.hip", "comm.hip", "conv.hip", "conv_fft.hip", "conv_big.hip", "conv_wfft.hip", "conv_w128.hip", "estimate.hip", "filters.hip", "nc.hip"]
 # measured experiments that are not part of the product (NOTEBOOK.md): python -m polyblur_amd.build --experimental
-EXPERIMENTAL_SOURCES = ["conv_strip.hip"]
+EXPERIMENTAL_SOURCES = ["conv_strip.hip", "conv_xt.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
 

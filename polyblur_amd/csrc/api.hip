@@ -27,6 +27,13 @@ int pb_overlap_add_impl(pb_ctx *ctx, const void *patches, void *out, int dtype, 
                         int step_h, int step_w, int n_i, int n_j, int pad_top, int pad_left, const float *win_y,
                         const float *win_x);
 
+#ifndef PB_EXPERIMENTAL
+// (conv_xt.hip -- both 1-D passes of the x-t approximation in one launch -- is a measured experiment of the --experimental
+// build: slower than the exact path it approximates.  The default build runs method='direct_separable' as two launches
+// of the general body over the two sparse records.)
+int pb_launch_conv_xt(pb_ctx *, const ConvPass &) { return PB_ERR_UNSUPPORTED; }
+#endif
+
 int pb_fail(pb_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -59,6 +66,43 @@ void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes) {
 static size_t dsize(int dtype) { return dtype == PB_F16 ? 2 : (dtype == PB_U8 ? 1 : 4); }
 static int pitch4(int w) { return (w + 3) & ~3; }
 
+// Every environment knob of the library, read ONCE per context (pb_create) into pb_ctx -- no kernel launcher looks at the
+// environment.  They exist to compare forms on the same box (bench.py's context entries, tools/), not to configure a
+// deployment: the defaults are the product.
+//   PB_DENSE_EVAL=stencil|<n>   dense kernels never take the tile-spectrum body | from n live stencil phases on (16)
+//   PB_FFT_BODY=wg|wave         which form of the tile-spectrum body runs three-step passes (wave; fp16 temporaries --
+//                               pb_options.half_temporaries -- always take the workgroup form, the only one built for them)
+//   PB_POLY1=0..3               one-pass polynomial: 0 never, 1 4-sample halo class only, 2 + 64 x 64 windows with the
+//                               composite's halos, 3 (default) + 128 x 128 windows
+//   PB_POLY_GAIN, PB_POLY_MIN_AREA, PB_POLY_COST128, PB_POLY_MIN_PAIRS128   cost model of the forms (common.h: 0.7, 768, 8, 150)
+//   PB_POLY_ALWAYS=0            never PolySpec.always (issue every launch the records might need)
+//   PB_SIDE_STREAM=0, PB_SIDE_MIN_TILES=<n>, PB_MAIN_STREAM_BODY=0|1   the side stream of launches that may find no work
+//   PB_EST_GRAY_ROWS=0|1|2      gray + range + row transform in one launch: never | fp32 lines up to 4096 | any line in LDS
+//   PB_EST_TAIL=0               the parameter kernel as a launch of its own instead of the column kernel's tail workgroups
+//   PB_FFT_EXT_RADIX=0          greedy transform plans only (radices up to 16)
+//   PB_FFT_LOGNB, PB_COLS_WIDE, PB_ROWS_NT, PB_WAVE_MIN_JOBS   shapes of the transform / wave-body launches
+//   PB_XT=2                     the x-t approximation through two launches of the general body
+//   PB_STRIP, PB_STRIP_SEG, PB_EST_OVERLAP   measured experiments, --experimental builds only
+static void pb_read_knobs(pb_ctx *ctx) {
+    auto geti = [](const char *n, int &v) { if (const char *e = getenv(n)) v = atoi(e); };
+    auto getl = [](const char *n, long &v) { if (const char *e = getenv(n)) v = atol(e); };
+    auto getf = [](const char *n, float &v) { if (const char *e = getenv(n)) v = (float)atof(e); };
+    if (const char *e = getenv("PB_DENSE_EVAL")) {
+        if (e[0] == 's') ctx->fft_min_phases = -1;
+        else if (e[0] >= '0' && e[0] <= '9') ctx->fft_min_phases = atoi(e);
+    }
+    if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
+    if (const char *e = getenv("PB_XT")) ctx->xt_two_launch = e[0] == '2';
+    geti("PB_STRIP", ctx->strip_mode); geti("PB_STRIP_SEG", ctx->strip_seg);
+    geti("PB_EST_GRAY_ROWS", ctx->est_gray_rows); geti("PB_EST_TAIL", ctx->est_tail); geti("PB_EST_OVERLAP", ctx->est_overlap);
+    geti("PB_FFT_EXT_RADIX", ctx->fft_ext_radix); geti("PB_FFT_LOGNB", ctx->fft_lognb); geti("PB_COLS_WIDE", ctx->cols_wide);
+    geti("PB_ROWS_NT", ctx->rows_nt); getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
+    geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);
+    getf("PB_POLY_COST128", ctx->poly_cost128); getl("PB_POLY_MIN_PAIRS128", ctx->poly_min_pairs128);
+    geti("PB_POLY_ALWAYS", ctx->poly_always); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
+    geti("PB_MAIN_STREAM_BODY", ctx->main_stream_body);
+}
+
 extern "C" {
 
 int pb_version(void) { return PB_VERSION; }
@@ -81,19 +125,7 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     pb_ctx *ctx = new pb_ctx();
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(stream);
-    if (const char *e = getenv("PB_DENSE_EVAL")) {              // "stencil": never the tile-spectrum body; a number: its phase threshold
-        if (e[0] == 's') ctx->fft_min_phases = -1;
-        else if (e[0] >= '0' && e[0] <= '9') ctx->fft_min_phases = atoi(e);
-    }
-    if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
-    if (const char *e = getenv("PB_STRIP")) ctx->strip_mode = atoi(e);
-    if (const char *e = getenv("PB_EST_GRAY_ROWS")) ctx->est_gray_rows = atoi(e);
-    if (const char *e = getenv("PB_FFT_EXT_RADIX")) ctx->fft_ext_radix = atoi(e);
-    if (const char *e = getenv("PB_POLY1")) ctx->poly_mode = atoi(e);
-    if (const char *e = getenv("PB_POLY_GAIN")) ctx->poly_gain = (float)atof(e);
-    if (const char *e = getenv("PB_POLY_MIN_AREA")) ctx->poly_min_area = atoi(e);
-    if (const char *e = getenv("PB_POLY_COST128")) ctx->poly_cost128 = (float)atof(e);
-    if (const char *e = getenv("PB_POLY_MIN_PAIRS128")) ctx->poly_min_pairs128 = atol(e);
+    pb_read_knobs(ctx);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
     const char *side = getenv("PB_SIDE_STREAM");
@@ -303,7 +335,8 @@ void make_steps(const Geometry &g, const void *xsrc, int x_dtype, const float *x
 }
 
 // what the spectra of a polynomial with these steps should be those of (PolySpec; conv.hip: pb_poly_spec_mode)
-PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta) {
+// gaussians: the records are (or will be) point-symmetric Gaussians the estimation itself builds on an odd ker_size grid
+PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta, bool gaussians) {
     const int mode = pb_poly_spec_mode(ctx, steps);
     if (!mode) return no_poly();
     // (128 x 128 windows need an image of some size: a workgroup takes ~38 us for its pair whatever the launch, and a 700 x 500
@@ -312,7 +345,11 @@ PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta) 
     // (396 pairs at 90 x 90 tiles: alone 4 % slower through 128 x 128 windows, in a batch of 32 10 % faster))
     const long pairs128 = (long)((steps[2].W + 179) / 180) * ((steps[2].H + 89) / 90) * steps[2].C;
     const float cost128 = pairs128 >= ctx->poly_min_pairs128 ? ctx->poly_cost128 : 0.f;
-    return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area, cost128};
+    // (every composite of a 25-tap kernel fits a 128 x 128 window -- halo <= 36, tile >= 56 -- so where those windows are admitted
+    // and every kernel is the estimation's own Gaussian, "every image takes one window pass" is a fact of the call's options and
+    // sizes: PolySpec.always, and pb_launch_conv_poly issues the two window launches only)
+    const int always = (mode == 3 && cost128 > 0.f && gaussians && ctx->poly_always) ? 1 : 0;
+    return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area, cost128, always};
 }
 
 // y = a3 K^3 x + a2 K^2 x + a1 K x + beta x by Horner, three stencil passes (deblurring.py:122-138).
@@ -325,7 +362,7 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
         // K ~= K2 after K1 (estimate.hip: sep_records_kernel).  One launch per step keeps u = K1 * t in LDS (conv_xt.hip);
         // dtype combinations it is not built for (8-bit images) -- or PB_XT=2 -- take two launches through the sparse
         // phase lists of the general body: u = K1 * t, then t' = scale (K2 * u) + coef x
-        static const bool two_launch = [] { const char *e = getenv("PB_XT"); return e && e[0] == '2'; }();
+        const bool two_launch = ctx->xt_two_launch != 0;
         const float scale[3] = {a3, 1.f, 1.f}, coef[3] = {a2, a1, beta};
         float *tmp[2] = {t1, t2};
         ConvPass p1 = base_pass(g, g.sep1, boundary), p2 = base_pass(g, g.sep2, boundary);
@@ -369,7 +406,9 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     }
     // (under the wrap boundary the three steps are one filter, deblurring.py:139-169: images for which one window pass
     // with that filter's spectrum is the cheaper form take it, pb_fft_sel.poly; the spectra are then the polynomial's)
-    ctx->poly_want = poly_spec(ctx, steps, alpha, beta);
+    // (records the estimation has just built under PolySpec.always keep that spec: their spectra are already those it asks for)
+    const bool by_est = ctx->khat_by_estimate && ctx->khat_owner == info && ctx->khat_B == g.B && ctx->poly_built.always;
+    ctx->poly_want = poly_spec(ctx, steps, alpha, beta, by_est);
     const int rc = pb_launch_conv_poly(ctx, steps);
     ctx->poly_want = no_poly();
     return rc;
@@ -613,6 +652,9 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (ksize > PB_KSIZE && (opt->edgetaping || opt->separable_approx))
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
+    // (every iteration's choices of body keep a slot of their own; whichever way the call ends, later passes on this context
+    // read and write slot 0 again, and what one-pass spec the call asked for is forgotten)
+    struct SlotGuard { pb_ctx *c; ~SlotGuard() { c->sel_slot = 0; c->poly_want = no_poly(); } } slot_guard{ctx};
     ctx->sel_slot = 0;
     Geometry g = geometry(B, C, H, W, ksize / 2);
     const bool poly_eligible = opt->boundary == PB_WRAP && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
@@ -703,7 +745,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
             const int last_out = (opt->remove_halo || opt->prefilter != PB_PREFILTER_NONE) ? PB_F32 : dst_dtype;
             ConvPass steps[3];
             make_steps(g, cur, src_dtype, nullptr, info, opt->alpha, opt->beta, opt->boundary, nullptr, nullptr, dst, last_out, 1, steps);
-            ctx->poly_want = poly_spec(ctx, steps, opt->alpha, opt->beta);
+            ctx->poly_want = poly_spec(ctx, steps, opt->alpha, opt->beta, (ksize & 1) != 0);
         }
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
         ctx->poly_want = no_poly();

@@ -45,10 +45,16 @@ struct ProfRec {
 // on 128 x 128 windows (conv_w128.hip, pb_fft_sel.poly == 2) where THAT is cheapest -- cost128 = what a 128 x 128 window pair
 // costs in units of a 64 x 64 one (four waves, longer transforms).
 // gain, min_area: the cost model of mode 2 (khat.h).
-struct PolySpec { int on; float a3, a2, a1, b; float gain; int min_area; float cost128; };
-inline PolySpec no_poly() { return PolySpec{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0.f}; }
+// always: EVERY image of the record set takes a one-pass form (64 x 64 or 128 x 128 windows, whichever the cost model prices
+// lower) -- the three-step and stencil forms are out of the model.  Asked for where the host can tell from (boundary,
+// options, image size, ker_size) alone that every composite fits a 128 x 128 window and every kernel is a point-symmetric
+// Gaussian the estimation itself builds: the polynomial then issues the two window launches and nothing else (no launch
+// that finds no work, no side stream), without the host ever reading a record back.
+struct PolySpec { int on; float a3, a2, a1, b; float gain; int min_area; float cost128; int always; };
+inline PolySpec no_poly() { return PolySpec{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0.f, 0}; }
 inline bool same_spec(const PolySpec &x, const PolySpec &y) {
-    return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b && (x.cost128 > 0.f) == (y.cost128 > 0.f)));
+    return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b && (x.cost128 > 0.f) == (y.cost128 > 0.f) &&
+                                      x.always == y.always));
 }
 
 // rf = window halo class of the workgroup form (conv_fft.hip): 4, 8 or 12 -- 0 when only the wave form can run the image
@@ -95,6 +101,7 @@ struct pb_ctx {
     int sel_slot = 0, sel_last = 0, sel_B = 0;           // "conv.fftsel" holds PB_SEL_SLOTS runs of sel_B records: the slot passes write to / read from
     const std::vector<pb_fft_sel> *known_sel = nullptr;   // the records of the pass being launched, where the host has them (sizes its job grid)
     const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)
+    int khat_slot = 0;                   // ... and the slot of "conv.fftsel" their selections were written to
     int khat_B = 0;                      // ... and how many of its records they cover (a longer run at the same address has stale tails)
     const void *khat_buf = nullptr;
     bool khat_by_estimate = false;
@@ -122,8 +129,20 @@ struct pb_ctx {
     long poly_min_pairs128 = 150;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels): 720p x 3 (180 pairs: 0.385 -> 0.325 ms per call) and up; 700 x 500 x 3 (72 pairs) is slower with them (0.256 -> 0.279)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
+    int est_tail = 1;                    // env PB_EST_TAIL: 1 = parameters and spectra are formed by tail workgroups of the column kernel (no launch of their own) where that kernel is built for it
+    int poly_always = 1;                 // env PB_POLY_ALWAYS: 0 = never PolySpec.always (every polynomial issues all the launches its records might need)
+    long side_min_tiles = 12288;         // env PB_SIDE_MIN_TILES: stencil tiles per launch from which the launches that may find no work go to the side stream
+    int main_stream_body = -1;           // env PB_MAIN_STREAM_BODY: which launch stays on the caller's stream when the others go to the side stream (0 = wave body, 1 = 128 x 128; -1 = by spec)
     int est_gray_rows = 1;               // env PB_EST_GRAY_ROWS: 1 = gray + range + row transform in one launch where measured faster (fp32 planes, lines of up to 4096 samples), 2 = for any line held in LDS, 0 = never
     int fft_ext_radix = 1;               // env PB_FFT_EXT_RADIX: 0 = greedy plans only (radices up to 16)
+    // tuning / comparison knobs of single kernels, read once in pb_create (the table of every knob: api.hip, pb_read_knobs)
+    long wave_min_jobs = 0;              // env PB_WAVE_MIN_JOBS: three-step passes of fewer window pairs than this go to the workgroup form of the tile-spectrum body
+    int fft_lognb = -1;                  // env PB_FFT_LOGNB: log2 of the complex lines per column workgroup (-1: by LDS size)
+    int cols_wide = 1;                   // env PB_COLS_WIDE: 0 = never the double-width column tile
+    int rows_nt = 0;                     // env PB_ROWS_NT: threads per row workgroup (128 / 256 / 512; 0 = by line length and grid size)
+    int xt_two_launch = 0;               // env PB_XT=2: the x-t approximation as two launches of the general body
+    int est_overlap = -1;                // env PB_EST_OVERLAP (--experimental builds): rows and columns side by side on two streams
+    int strip_seg = 0;                   // env PB_STRIP_SEG (--experimental builds): segment height of the strip body
     int strip_mode = 0;                  // env PB_STRIP: 1 = rank-1 kernels of full support take the streaming strip body (fp32 planes; --experimental builds only)
 };
 
@@ -230,6 +249,8 @@ int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p);                     // 
 bool pb_conv_fft_types(const ConvPass &p);                                   // conv_fft.hip: whether the workgroup form is built for the pass's types
 bool pb_conv_wfft_types(const ConvPass &p);
 int pb_launch_conv_w128(pb_ctx *ctx, const ConvPass &p);                     // conv_w128.hip: the one-pass polynomial on 128 x 128 windows (pb_fft_sel.poly == 2)
+bool pb_conv_w128_feasible(const ConvPass &p);                               // ... and whether its worst-case job list fits the grid
+bool pb_conv_wfft_feasible(const ConvPass &p, bool poly2, int min_area);     // conv_wfft.hip: likewise for the wave form
 bool pb_conv_w128_types(int in_dtype, int out_dtype);                                  // ... whether it is built for the pass's types
 int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps);                   // conv.hip: the PolySpec.on a polynomial with these steps may ask for
 // kernels larger than the 25 x 25 record (conv_big.hip): their taps on the ker_size grid, and one Horner step with them

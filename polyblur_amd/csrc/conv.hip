@@ -433,7 +433,11 @@ int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
     const bool fold = steps[0].out_dtype == steps[2].out_dtype;
     bool wave = ctx->poly_mode != 1 && ctx->fft_wave && (fold || pb_conv_wfft_types(pc));
     for (int s = 0; s < 3; ++s) wave = wave && pb_conv_wfft_types(steps[s]);
-    if (wave) return (ctx->poly_mode >= 3 && ctx->poly_cost128 > 0.f && pb_conv_w128_types(pc.in_dtype, pc.out_dtype)) ? 3 : 2;
+    // (job lists sized for the smallest one-pass tiles must fit the grid: a batch too large for them keeps the forms whose
+    // lists are shorter -- three Horner steps in the end -- instead of failing the call)
+    if (wave && !pb_conv_wfft_feasible(pc, true, ctx->poly_min_area)) wave = false;
+    if (wave) return (ctx->poly_mode >= 3 && ctx->poly_cost128 > 0.f && pb_conv_w128_types(pc.in_dtype, pc.out_dtype) &&
+                      pb_conv_w128_feasible(pc)) ? 3 : 2;
     return (fold || pb_conv_fft_types(pc)) ? 1 : 0;
 }
 
@@ -511,7 +515,24 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     // plane: 6 us at 4K, 33 us for 32 x 1080p -- against two queue-to-queue waits per polynomial (~5 - 8 us each); a single
     // image of up to 4K runs everything on the caller's stream (measured: 4K 0.738 -> 0.722 ms of device time per call, while
     // 32 x 1080p would go from 6.09 to 6.61 ms without the side stream).
-    static const long side_min_tiles = [] { const char *e = getenv("PB_SIDE_MIN_TILES"); return e ? atol(e) : 12288L; }();
+    // PolySpec.always (records of the estimation, nothing the host has read back): every image takes one window pass, on 64 x 64
+    // or on 128 x 128 windows -- two launches on the caller's stream, each skipping the other's images, and nothing else.
+    if (poly_on && ctx->poly_want.always && !have) {
+        float *k = nullptr; pb_fft_sel *sel = nullptr;
+        const bool built = ctx->khat_by_estimate && ctx->khat_owner == steps[0].info && ctx->khat_B == B;
+        int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !built);
+        if (rc) return rc;
+        rc = composite128(k, sel);
+        if (rc) return rc;
+        ConvPass pc = steps[0];
+        pc.out_dtype = steps[2].out_dtype;
+        if (pb_conv_wfft_types(pc)) return composite(k, sel);
+        ConvPass p = steps[0];                                   // (the composite's types are not built: the first step's launch takes them along)
+        p.khat = k; p.fsel = sel;
+        first_step(p);
+        return launch_tile_spectrum(ctx, p);
+    }
+    const long side_min_tiles = ctx->side_min_tiles;
     const long stencil_tiles = (long)((steps[0].H + 2 * steps[0].pad + 63) / 64) * ((steps[0].W + 2 * steps[0].pad + 63) / 64) * steps[0].P;
     const bool side = ctx->aux && stencil_tiles >= side_min_tiles;
     if (!fft || have || !side || ctx->prof_on) {
@@ -550,7 +571,7 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     // costs two queue-to-queue waits (~5 us each) on the critical path.  Where the spec admits 128 x 128 windows (images of
     // poly_min_pairs128 window pairs or more: decided from the sizes alone, api.hip) that is the 128 x 128 launch, and the
     // wave body's three launches join the stencil launches on the side stream; otherwise the wave body's.
-    static const int main_env = [] { const char *e = getenv("PB_MAIN_STREAM_BODY"); return e ? atoi(e) : -1; }();     // 0 = wave body, 1 = 128 x 128
+    const int main_env = ctx->main_stream_body;     // 0 = wave body, 1 = 128 x 128
     const bool w128_main = poly_on && ctx->poly_want.on == 3 && ctx->poly_want.cost128 > 0.f && main_env != 0;
     auto wave_steps = [&]() {
         for (int s = 0; s < 3 && !rc; ++s) {

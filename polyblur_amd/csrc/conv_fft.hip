@@ -351,9 +351,12 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
     const int rcb = pb_khat_buffers(ctx, B, &k, &s);
     if (rcb) return rcb;
     // (spectra of other records, of fewer records than this pass covers, or of the kernel where the pass wants the polynomial's)
-    if (!ctx->khat_owner || ctx->khat_owner != info || ctx->khat_B != B || !same_spec(ctx->poly_built, ctx->poly_want)) launch = true;
+    // (... or selections written to another slot than the one this pass reads)
+    if (!ctx->khat_owner || ctx->khat_owner != info || ctx->khat_B != B || !same_spec(ctx->poly_built, ctx->poly_want) ||
+        ctx->khat_slot != ctx->sel_slot % PB_SEL_SLOTS) launch = true;
     if (launch) {
         ctx->khat_owner = info; ctx->khat_B = B; ctx->khat_by_estimate = false; ctx->poly_built = ctx->poly_want;
+        ctx->khat_slot = ctx->sel_slot % PB_SEL_SLOTS;
         ProfScope prof(ctx, PB_PROF_PARAMS);
         hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases,
                            ctx->poly_want);

@@ -298,7 +298,7 @@ int pb_launch_conv_strip(pb_ctx *ctx, const ConvPass &p) {
     long target = (2048 + (long)g.strips_x * p.P - 1) / ((long)g.strips_x * p.P);
     if (target < 1) target = 1;
     int seg_h = (int)((oh + target - 1) / target);
-    static const int forced = [] { const char *e = getenv("PB_STRIP_SEG"); return e ? atoi(e) : 0; }();
+    const int forced = ctx->strip_seg;
     if (forced > 0) seg_h = forced;
     if (seg_h < 64) seg_h = 64;
     if (seg_h > oh) seg_h = oh;

@@ -496,6 +496,16 @@ int launch_w128_typed(pb_ctx *ctx, const ConvPass &p, const W128Geom &g, long gr
 
 bool pb_conv_w128_types(int in_dtype, int out_dtype) { return in_dtype >= 0 && in_dtype <= 2 && out_dtype >= 0 && out_dtype <= 2; }
 
+// Whether the job list of a launch sized for the smallest tiles (records the host has not read) stays within the grid
+// (pb_poly_spec_mode asks before it admits 128 x 128 windows: an oversized batch keeps the other forms instead of failing).
+bool pb_conv_w128_feasible(const ConvPass &p) {
+    const int oh = (p.out_kind == OUT_INTERIOR) ? p.H : p.H + 2 * p.pad, ow = (p.out_kind == OUT_INTERIOR) ? p.W : p.W + 2 * p.pad;
+    const int t = PB_POLY128_MIN_T;
+    const long nj = (long)(((ow + t - 1) / t + 1) / 2) * ((oh + t - 1) / t);
+    const long groups = 8L * ((nj + 7) / 8) * p.P;
+    return groups > 0 && groups <= (1L << 23);
+}
+
 // The one-pass polynomial of the images whose record selects 128 x 128 windows (pb_fft_sel.poly == 2): from the first step's
 // input to the last step's output (p: the composite pass -- scale 1, no x operand, the last step's clamp).
 int pb_launch_conv_w128(pb_ctx *ctx, const ConvPass &p) {

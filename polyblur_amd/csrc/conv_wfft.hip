@@ -722,6 +722,12 @@ extern "C" int pb_debug_wf_trace(unsigned long long *host, int n_waves) {
 }
 #endif
 
+// (as pb_conv_w128_feasible: the largest job list a pass with one-pass images of `min_area`-sample tiles may need)
+bool pb_conv_wfft_feasible(const ConvPass &p, bool poly2, int min_area) {
+    WGeom g; long per_max = 0, pairs12 = 0;
+    return wfft_geometry(p, poly2, (float)min_area, g, per_max, pairs12);
+}
+
 bool pb_conv_wfft_types(const ConvPass &p) {
     switch (p.in_dtype * 9 + p.x_dtype * 3 + p.out_dtype) {
         case 0: case 1: case 3: case 4: case 12: case 13: case 24: case 26: case 6: case 8: case 2: return true;
@@ -737,7 +743,7 @@ bool pb_conv_wfft_types(const ConvPass &p) {
 // mostly one window pass now, the call is faster through this form alone (0.29 ms; 1080p 0.45 against 0.53).
 // PB_WAVE_MIN_JOBS=n in the environment sends passes of fewer than n pairs to the workgroup form again.
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
-    static const long min_jobs = [] { const char *e = getenv("PB_WAVE_MIN_JOBS"); return e ? atol(e) : 0L; }();
+    const long min_jobs = ctx->wave_min_jobs;
     if (!pb_conv_wfft_types(p)) return PB_ERR_UNSUPPORTED;
     const bool poly2 = p.poly != 0 && ctx->poly_built.on >= 2;
     const float min_area = (float)ctx->poly_min_area;      // (the smallest one-pass tile the cost model of khat.h admits)

@@ -1457,9 +1457,8 @@ template <typename K> int allow_lds(pb_ctx *ctx, K kernel, size_t bytes) {
 // the same waves per CU, but half as many 128-byte lines requested per useful byte of the column segments
 // (measured, 4K: 73.7 -> 68.5 us; 8 x 1080p: 132 -> 122 us; 512 threads on the narrow tile: 95 us; one 700x500 image,
 // whose 44 narrow tiles already leave most CUs idle: 31.7 -> 35.9 us, hence the workgroup-count condition).
-int pick_lognb(const FftPlan *pl, int W, int P, bool wide_ok, int *threads) {
-    static int forced = -2;
-    if (forced == -2) { const char *e = getenv("PB_FFT_LOGNB"); forced = e ? atoi(e) : -1; }
+int pick_lognb(pb_ctx *ctx, const FftPlan *pl, int W, int P, bool wide_ok, int *threads) {
+    const int forced = ctx->fft_lognb;
     if (fft_lds_bytes(pl, 1) > kMaxLds) {          // lines through global memory (grad_cols_long_kernel): 8-column tiles
         int lognb = 2;
         while (lognb > 0 && (2 << (lognb - 1)) >= W * 2) --lognb;
@@ -1470,7 +1469,7 @@ int pick_lognb(const FftPlan *pl, int W, int P, bool wide_ok, int *threads) {
     while (lognb > 0 && fft_lds_bytes(pl, 1 << lognb) > 80 * 1024) --lognb;
     while (lognb > 0 && (2 << (lognb - 1)) >= W * 2) --lognb;
     int nt = NT;
-    static const bool wide_off = getenv("PB_COLS_WIDE") && atoi(getenv("PB_COLS_WIDE")) == 0;
+    const bool wide_off = ctx->cols_wide == 0;
     if (wide_ok && !wide_off && forced < 0 && !pl->bluestein_m && pl->nstage >= 2 &&
         fft_lds_bytes(pl, 2 << lognb) <= 140 * 1024 && (long)P * (W / (4 << lognb)) >= 200) {   // still fills the chip
         ++lognb;
@@ -1560,7 +1559,7 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     // chains, and 256 threads -- one butterfly per thread and stage, held to 96 registers so that five such workgroups
     // still fit a CU -- shorten every chain: 41.0 -> 33.4 us at 4K, 17.4 -> 15.8 us at 700 x 500.  Larger grids are
     // throughput-bound and keep 128 threads (8 x 1080p: 63.7 us against 70.0 with 256).
-    static const int force_nt = [] { const char *e = getenv("PB_ROWS_NT"); return e ? atoi(e) : 0; }();
+    const int force_nt = ctx->rows_nt;
     const bool one_round = blocks <= 256L * 5;
     if (!fused) PB_ROWS(256, false);
     else if (!plan_ext(pl) && lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_ROWS(128, true);
@@ -1602,7 +1601,7 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     } while (0)
 #define PB_GROWS_C(T, NTH) do { if (C == 3) PB_GROWS(T, 3, NTH); else PB_GROWS(T, 0, NTH); } while (0)
 #define PB_GROWS_T(NTH) PB_GROWS_C(float, NTH)
-    static const int force_nt = [] { const char *e = getenv("PB_ROWS_NT"); return e ? atoi(e) : 0; }();
+    const int force_nt = ctx->rows_nt;
     const bool one_round = blocks <= 256L * 5;                      // (as launch_rows)
     // (lines above 40 KB of LDS -- 8K rows -- leave room for two or three workgroups per CU: 512 threads each keep the
     // CU's SIMDs supplied, PB_ROWS_NT=256 to compare)
@@ -1626,7 +1625,7 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     if (!pl) return PB_ERR_NOMEM;
     const bool ext = plan_ext(pl);
     int nt = NT;
-    const int lognb = pick_lognb(pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt);
+    const int lognb = pick_lognb(ctx, pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt);
     const size_t lds = fft_lds_bytes(pl, 1 << lognb);
     const bool through_memory = fft_lds_bytes(pl, 1) > kMaxLds;
     if (through_memory && !pb_fft_length_supported(H))
@@ -1740,13 +1739,13 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     const long HW = (long)H * W;
     const FftPlan *plh = pb_get_plan(ctx, H);
     if (!plh) return PB_ERR_NOMEM;
-    const int est_lognb = pick_lognb(plh, W, B, opt->n_angles == 6, nullptr);                   // as launch_cols
+    const int est_lognb = pick_lognb(ctx, plh, W, B, opt->n_angles == 6, nullptr);                   // as launch_cols
     const int col_tiles = (W + (2 << est_lognb) - 1) / (2 << est_lognb);
     // (see below: transforms side by side + a maxima pass; an experiment that measured SLOWER -- 0.90 against 0.85 ms per 4K call,
     // 0.35 against 0.32 ms at 700 x 500: the column workgroups take a CU's whole LDS, so the row workgroups do not run beside
     // them, and the maxima pass and the fork / join come on top -- and is only in the --experimental build, behind PB_EST_OVERLAP=1)
 #ifdef PB_EXPERIMENTAL      // (python -m polyblur_amd.build --experimental)
-    static const int overlap_env = [] { const char *e = getenv("PB_EST_OVERLAP"); return e ? atoi(e) : -1; }();
+    const int overlap_env = ctx->est_overlap;
     const bool lines_in_lds = pb_fft_length_supported(H) == 1 && pb_fft_length_supported(W) == 1;
     const bool overlap = ctx->aux && !ctx->prof_on && lines_in_lds && overlap_env > 0;
 #else
@@ -1869,7 +1868,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
                        ctx->fft_min_phases, ctx->poly_want);
     PB_LAUNCH_CHECK();
-    if (khat) { ctx->khat_owner = dev_info; ctx->khat_B = B; ctx->khat_by_estimate = true; ctx->poly_built = ctx->poly_want; }
+    if (khat) { ctx->khat_owner = dev_info; ctx->khat_B = B; ctx->khat_by_estimate = true; ctx->poly_built = ctx->poly_want; ctx->khat_slot = ctx->sel_slot % PB_SEL_SLOTS; }
     return PB_OK;
 }
 

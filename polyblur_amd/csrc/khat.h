@@ -207,7 +207,9 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     if (tid < 2 * (K1 + 2 * PD)) s_mp[tid / (K1 + 2 * PD)][tid % (K1 + 2 * PD)] = 0.f;
     if (tid < 2 * (K2 + 2 * PD)) s_m2[tid / (K2 + 2 * PD)][tid % (K2 + 2 * PD)] = 0.f;
     PB_PT(20);
-    const bool symm = __syncthreads_and(sym) && min_phases >= 0;
+    // (PolySpec.always: the host vouches for point-symmetric taps -- the estimation's own Gaussians -- and has no other launch
+    // to fall back on; taps that compare unequal there are NaNs, which the one-pass form turns into the same zeros)
+    const bool symm = (__syncthreads_and(sym) || ps.always) && min_phases >= 0;
     // The window halo of the tile-spectrum body, per axis.  The spectrum below holds EVERY tap of the record's box; the halo
     // only has to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error
     // of at most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero
@@ -294,7 +296,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         // with records built on the device every surplus workgroup is dispatched to find that out)
         const float ak = (float)((KH_FT_N - 2 * hxk) * (KH_FT_N - 2 * hyk));
         // cost of each form in 64 x 64 window pairs per output sample (a stencil evaluation counts like one pass at min_area)
-        const float c3 = use3 ? 3.f / (ps.gain * ak) : 1.f / (float)ps.min_area;
+        const float c3 = ps.always ? INFINITY : (use3 ? 3.f / (ps.gain * ak) : 1.f / (float)ps.min_area);
         float c64 = INFINITY, c128 = INFINITY;
         if (txp >= PB_POLY_MIN_TX && typ >= PB_POLY_MIN_TY && txp * typ >= ps.min_area) c64 = 1.f / (float)(txp * typ);
         const int tx8 = 2 * KH_FT_N - 2 * hxp, ty8 = 2 * KH_FT_N - 2 * hyp;
