@@ -78,7 +78,8 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //   PB_POLY_ALWAYS=0            never PolySpec.always (issue every launch the records might need)
 //   PB_SIDE_STREAM=0, PB_SIDE_MIN_TILES=<n>, PB_MAIN_STREAM_BODY=0|1   the side stream of launches that may find no work
 //   PB_EST_GRAY_ROWS=0|1|2      gray + range + row transform in one launch: never | fp32 lines up to 4096 | any line in LDS
-//   PB_EST_TAIL=0               the parameter kernel as a launch of its own instead of the column kernel's tail workgroups
+//   PB_EST_LEAN=0               the parameter kernel forms the whole record before the spectra (no short chain)
+//   PB_DT_ROWS_REG=0            the domain-transform row pass through global memory instead of registers
 //   PB_FFT_EXT_RADIX=0          greedy transform plans only (radices up to 16)
 //   PB_FFT_LOGNB, PB_COLS_WIDE, PB_ROWS_NT, PB_WAVE_MIN_JOBS   shapes of the transform / wave-body launches
 //   PB_XT=2                     the x-t approximation through two launches of the general body
@@ -94,7 +95,7 @@ static void pb_read_knobs(pb_ctx *ctx) {
     if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
     if (const char *e = getenv("PB_XT")) ctx->xt_two_launch = e[0] == '2';
     geti("PB_STRIP", ctx->strip_mode); geti("PB_STRIP_SEG", ctx->strip_seg);
-    geti("PB_EST_GRAY_ROWS", ctx->est_gray_rows); geti("PB_EST_TAIL", ctx->est_tail); geti("PB_EST_OVERLAP", ctx->est_overlap);
+    geti("PB_EST_GRAY_ROWS", ctx->est_gray_rows); geti("PB_EST_LEAN", ctx->est_lean); geti("PB_DT_ROWS_REG", ctx->dt_rows_reg); geti("PB_EST_OVERLAP", ctx->est_overlap);
     geti("PB_FFT_EXT_RADIX", ctx->fft_ext_radix); geti("PB_FFT_LOGNB", ctx->fft_lognb); geti("PB_COLS_WIDE", ctx->cols_wide);
     geti("PB_ROWS_NT", ctx->rows_nt); getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
     geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);

@@ -1023,6 +1023,47 @@ __device__ float block_sum(float v, float *red) {
     return s;
 }
 
+// The ker_size x ker_size Gaussian of (theta, sigma, rho) in the 25 x 25 record (blur_estimation.py:189-232), normalised:
+// into sk (LDS) and, where given, into the record's taps in global memory.  Called by all NT threads of a block (barriers
+// inside; sk is NOT yet visible to the other threads on return).
+__device__ __forceinline__ void gaussian_taps(float *sk, float *gk, float theta, float sg, float rh, int ksize, int shift, float *red) {
+    const int tid = threadIdx.x;
+    const float th = -theta;
+    const float c = cosf(th), s = sinf(th);
+    const float i1 = 1.f / (sg * sg), i2 = 1.f / (rh * rh);
+    const float a00 = c * c * i1 + s * s * i2;
+    const float a01 = s * c * (i1 - i2);
+    const float a11 = c * c * i2 + s * s * i1;
+    float e[3];
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int idx = tid + q * NT;
+        e[q] = 0.f;
+        if (idx < PB_KSIZE * PB_KSIZE) {
+            const int iy = idx / PB_KSIZE - PB_KRAD, ix = idx % PB_KSIZE - PB_KRAD;
+            // A ker_size x ker_size kernel (blur_estimation.py:222) sits in the 25 x 25 record whose tap (iy, ix)
+            // multiplies the sample (iy, ix) away from the output.  Odd sizes: centred, |offset| <= ker_size / 2.
+            // EVEN sizes: the reference's grid arange(k) - (k - 1) // 2 = -k/2+1 .. k/2 is off-centre, and where the
+            // taps land differs by method -- F.conv2d's 'same' padding (filters.py:46) puts k/2 - 1 samples in front
+            // and k/2 behind and correlates: tap G(u) at offset u = -k/2+1 .. k/2; 'fft' rolls the kernel array by
+            // k // 2 and convolves (filters.py:268-273): the same offsets, but entry i sits at offset k/2 - i, i.e.
+            // tap G(1 - u) = G(u - 1) at offset u -- the Gaussian centred on offset +1 (shift).
+            const int lo = (ksize & 1) ? -(ksize / 2) : -(ksize / 2) + 1, hi = ksize / 2;
+            const float Y = (float)(iy - shift), X = (float)(ix - shift);
+            const float quad = (X * a00 + Y * a01) * X + (X * a01 + Y * a11) * Y;
+            e[q] = (iy >= lo && iy <= hi && ix >= lo && ix <= hi) ? expf(-0.5f * quad) : 0.f;
+            part += e[q];
+        }
+    }
+    const float total = block_sum(part, red);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int idx = tid + q * NT;
+        if (idx < PB_KSIZE * PB_KSIZE) { sk[idx] = e[q] / total; if (gk) gk[idx] = sk[idx]; }
+    }
+}
+
 // Fills kernel (unless from_taps), marginals, autocorrelations, separability and radius of one
 // record.  Called by all NT threads of a block.
 // shift: an EVEN ker_size under the wrap boundary ('fft') -- see the tap formula below.
@@ -1035,43 +1076,8 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
     const int tid = threadIdx.x;
     __syncthreads();                                    // (a previous call's readers of the shared arrays are done)
     if (!from_taps) {
-        // blur_estimation.py:189-232
         // par (LDS): theta, sigma, rho as the caller has just computed them -- no round trip through the global record
-        const float th = -(par ? par[0] : info->theta);
-        const float sg = par ? par[1] : info->sigma, rh = par ? par[2] : info->rho;
-        const float c = cosf(th), s = sinf(th);
-        const float i1 = 1.f / (sg * sg), i2 = 1.f / (rh * rh);
-        const float a00 = c * c * i1 + s * s * i2;
-        const float a01 = s * c * (i1 - i2);
-        const float a11 = c * c * i2 + s * s * i1;
-        float e[3];
-        float part = 0.f;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int idx = tid + q * NT;
-            e[q] = 0.f;
-            if (idx < PB_KSIZE * PB_KSIZE) {
-                const int iy = idx / PB_KSIZE - PB_KRAD, ix = idx % PB_KSIZE - PB_KRAD;
-                // A ker_size x ker_size kernel (blur_estimation.py:222) sits in the 25 x 25 record whose tap (iy, ix)
-                // multiplies the sample (iy, ix) away from the output.  Odd sizes: centred, |offset| <= ker_size / 2.
-                // EVEN sizes: the reference's grid arange(k) - (k - 1) // 2 = -k/2+1 .. k/2 is off-centre, and where the
-                // taps land differs by method -- F.conv2d's 'same' padding (filters.py:46) puts k/2 - 1 samples in front
-                // and k/2 behind and correlates: tap G(u) at offset u = -k/2+1 .. k/2; 'fft' rolls the kernel array by
-                // k // 2 and convolves (filters.py:268-273): the same offsets, but entry i sits at offset k/2 - i, i.e.
-                // tap G(1 - u) = G(u - 1) at offset u -- the Gaussian centred on offset +1 (shift).
-                const int lo = (ksize & 1) ? -(ksize / 2) : -(ksize / 2) + 1, hi = ksize / 2;
-                const float Y = (float)(iy - shift), X = (float)(ix - shift);
-                const float quad = (X * a00 + Y * a01) * X + (X * a01 + Y * a11) * Y;
-                e[q] = (iy >= lo && iy <= hi && ix >= lo && ix <= hi) ? expf(-0.5f * quad) : 0.f;
-                part += e[q];
-            }
-        }
-        const float total = block_sum(part, red);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int idx = tid + q * NT;
-            if (idx < PB_KSIZE * PB_KSIZE) { sk[idx] = e[q] / total; info->kernel[idx] = sk[idx]; }
-        }
+        gaussian_taps(sk, info->kernel, par ? par[0] : info->theta, par ? par[1] : info->sigma, par ? par[2] : info->rho, ksize, shift, red);
     } else {
         for (int idx = tid; idx < PB_KSIZE * PB_KSIZE; idx += NT) sk[idx] = info->kernel[idx];
     }
@@ -1203,7 +1209,15 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
                                                          float c, float b, int support, float force_theta_deg,
                                                          int tiles_per_image, int ksize, int shift,
                                                          const float2 *__restrict__ part, int blocks_per_image, unsigned *mm_out,
-                                                         float *khat, pb_fft_sel *fsel, int min_phases, const PolySpec ps) {
+                                                         float *khat, pb_fft_sel *fsel, int min_phases, const PolySpec ps, int lean) {
+    // lean (PolySpec.always under full support: every image takes a one-pass form, nobody reads the record's stencil parts
+    // before the kernel ends): the grid is KH_SLICES_LEAN + 1 workgroups per image.  Workgroups 0 .. KH_SLICES_LEAN - 1 walk
+    // the SHORT chain -- maxima, interpolation, (theta, sigma, rho), taps, halos, choice of window, their slice of the spectrum
+    // -- and write nothing of the record; workgroup KH_SLICES_LEAN forms the whole record (marginals, autocorrelations, phase
+    // lists ...) beside them, off the critical path: the same taps from the same instructions.
+    // (tools/params_trace.py, 4K: the chain to the stored spectrum 48.6 k shader cycles with the record in it and 16 slices,
+    // 35.6 k without the record, 27.6 k with 64 slices; the record workgroup ends at 25.2 k)
+    const bool lean_wg = lean && (int)blockIdx.y < KH_SLICES_LEAN, rec_wg = !lean_wg;
     __shared__ float red[NT / 64];
     __shared__ float s_mags[PB_MAX_ANGLES], s_interp[PB_MAX_INTERP];
     __shared__ float s_lo[NT / 64], s_hi[NT / 64];
@@ -1286,12 +1300,12 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
             rng_lo = lo; rng_hi = hi;
             // (a constant image: the reference's 0 / 0 makes every sample NaN; the maxima of NaN samples are 0 here as there)
             rng_inv = hi > lo ? 1.f / (hi - lo) : 0.f;
-            if (threadIdx.x == 0) { mm_out[2 * blockIdx.x] = pb_f2ord(lo); mm_out[2 * blockIdx.x + 1] = pb_f2ord(hi); }
+            if (threadIdx.x == 0 && rec_wg) { mm_out[2 * blockIdx.x] = pb_f2ord(lo); mm_out[2 * blockIdx.x + 1] = pb_f2ord(hi); }
         }
         if (threadIdx.x < PB_MAX_ANGLES) {
             const float v = (int)threadIdx.x < na ? s_part[threadIdx.x * 16] * rng_inv : 0.f;
             s_mags[threadIdx.x] = v;
-            info->mags[threadIdx.x] = v;
+            if (rec_wg) info->mags[threadIdx.x] = v;
         }
     }
     __syncthreads();
@@ -1305,7 +1319,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
                 if (k < na) v += wreg[k] * s_mags[k];
         }
         s_interp[threadIdx.x] = v;
-        info->interp[threadIdx.x] = v;
+        if (rec_wg) info->interp[threadIdx.x] = v;
     }
     __syncthreads();
     PB_PT(2);
@@ -1337,18 +1351,35 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
             s_par[1] = sqrtf(fminf(fmaxf(cc / (m_n * m_n + 1e-8f) - bb, 0.09f), 16.0f));
             s_par[2] = sqrtf(fminf(fmaxf(cc / (m_o * m_o + 1e-8f) - bb, 0.09f), 16.0f));
             s_par[0] = (float)theta_deg * 3.14159274101257324f / 180.0f;
-            info->theta = s_par[0];
-            info->sigma = s_par[1];
-            info->rho = s_par[2];
-            info->i_min = i_min;
-            info->gray_min = part ? rng_lo : pb_ord2f(mm[2 * blockIdx.x]);
-            info->gray_max = part ? rng_hi : pb_ord2f(mm[2 * blockIdx.x + 1]);
+            if (rec_wg) {
+                info->theta = s_par[0];
+                info->sigma = s_par[1];
+                info->rho = s_par[2];
+                info->i_min = i_min;
+                info->gray_min = part ? rng_lo : pb_ord2f(mm[2 * blockIdx.x]);
+                info->gray_max = part ? rng_hi : pb_ord2f(mm[2 * blockIdx.x + 1]);
+            }
         }
     }
     __syncthreads();
     PB_PT(3);
+    if (lean_wg) {
+        // the taps and nothing else of the record (full support: what lies outside the record's radius is exactly zero, so the
+        // box mask of khat_body changes nothing; phase count and separability only price forms PolySpec.always has no use for)
+        __shared__ float sk_lean[PB_KSIZE * PB_KSIZE];
+        gaussian_taps(sk_lean, nullptr, s_par[0], s_par[1], s_par[2], ksize, shift, red);
+        __syncthreads();
+        PB_PT(4);
+        const RecLds rlean{sk_lean, PB_KRAD, 0, 0};
+        khat_body<KH_SLICES_LEAN>(nullptr, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps, &rlean, true);
+        return;
+    }
     RecLds rl;
     finish_record(info, support, false, red, ksize, s_par, shift, &rl);
+    if (lean) {                                      // (the record workgroup of a lean grid: the one fact of the selection only it knows)
+        if (threadIdx.x == 0) fsel[blockIdx.x].strip = (rl.separable != 0 && rl.radius > 8) ? 1 : 0;
+        return;
+    }
     // The spectrum of the kernel just built and the image's choice of body for the reblurring passes (khat.h): the grid is
     // KH_SLICES workgroups per image, every one of which has formed the whole record above (a few microseconds of
     // redundant latency-bound work, identical values) and now forms its slice -- one launch less on every iteration's
@@ -1862,11 +1893,13 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
         rc = pb_khat_buffers(ctx, B, &khat, &fsel);
         if (rc) return rc;
     }
+    // (PolySpec.always under full support: the short chain to the spectra, the record beside it -- see the kernel)
+    const int lean = (khat && ctx->poly_want.always && opt->support == PB_SUPPORT_FULL && ctx->est_lean) ? 1 : 0;
     ProfScope prof(ctx, PB_PROF_PARAMS);
-    hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? KH_SLICES : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
+    hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? (lean ? KH_SLICES_LEAN + 1 : KH_SLICES) : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, est_tiles, ksize,
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
-                       ctx->fft_min_phases, ctx->poly_want);
+                       ctx->fft_min_phases, ctx->poly_want, lean);
     PB_LAUNCH_CHECK();
     if (khat) { ctx->khat_owner = dev_info; ctx->khat_B = B; ctx->khat_by_estimate = true; ctx->poly_built = ctx->poly_want; ctx->khat_slot = ctx->sel_slot % PB_SEL_SLOTS; }
     return PB_OK;

@@ -370,6 +370,106 @@ __global__ __launch_bounds__(NT) void dt_rows_fused_kernel(const TJ *J, const TI
     }
 }
 
+// ---- the row pass with the row in registers (round 5) -------------------------------------------------------------------
+// A row of W <= 64 NCH samples of C channels is NCH x C values per lane: the wave reads its row ONCE (every load of the row in
+// flight together), runs the left-to-right recurrence chunk by chunk, then the right-to-left one on the registers, and
+// writes the row once -- where dt_rows_fused_kernel writes the intermediate row, reads it back and reads the joint image a
+// second time (4.9 words per sample through HBM on 64 x 1080p against the 2 of one read and one write:
+// profiles/r04_bench_cfg3_traffic.json).  Only for J == in (the pipeline's call, domain_transform.py:45-47 with joint=None):
+// the neighbour differences |J[i] - J[i-1]| then come from the registers too (lane - 1, or lane 63 of the previous chunk).
+// The recurrences, their operands and the order in which scan_affine composes them are those of dt_rows_fused_kernel: the
+// right-to-left pass runs on lane-reversed values (lane l <-> sample base + 63 - l), exactly as that kernel lays them out --
+// bit-identical results (tests/test_gpu_parity.py::test_dt_rows_register_form).
+template <typename TIN, int C, int NCH>
+__global__ __launch_bounds__(NT) void dt_rows_reg_kernel(const TIN *in, float *F, int H, int W, float ratio, float log_a, long rows_total) {
+    const int lane = threadIdx.x & 63;
+    const long row_id = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);   // over B*H: one wave = one row, all channels
+    if (row_id >= rows_total) return;
+    const long b = row_id / H;
+    const int r = (int)(row_id - b * H);
+    const long HW = (long)H * W, off = (b * C * H + r) * (long)W;
+    const TIN *x0 = in + off;
+    float *f = F + off;
+    const int nch = (W + 63) >> 6;
+    float x[NCH][C], v[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int i = 64 * k + lane;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[k][c] = (k < nch && i < W) ? pb_ld(x0 + c * HW + i) : 0.f;
+    }
+    // ---- left -> right
+    float carry[C], last[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { carry[c] = 0.f; last[c] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (k < nch) {
+            const int base = 64 * k, i = base + lane;
+            float dx = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float left = __shfl_up(x[k][c], 1);
+                if (lane == 0) left = last[c];                               // (sample base - 1: lane 63 of the previous chunk)
+                last[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[k][c]), 63));
+                if (i < W && i > 0) dx += fabsf(x[k][c] - left);
+            }
+            float vv = 1.f;
+            if (i < W) vv = expf((1.f + ratio * dx) * log_a);
+            v[k] = vv;
+            float ma = (i == 0 || i >= W) ? 0.f : vv, mb[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) mb[c] = (i == 0 || i >= W) ? x[k][c] : (1.f - vv) * x[k][c];
+            if (i >= W) {
+                ma = 1.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) mb[c] = 0.f;
+            }
+            scan_affine<C>(ma, mb);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float y = fmaf(ma, carry[c], mb[c]);
+                x[k][c] = y;
+                carry[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), base + 63 >= W ? (W - 1) - base : 63));
+            }
+        } else {
+            v[k] = 1.f;
+        }
+    }
+    // ---- right -> left, on lane-reversed values: lane l <-> sample i = base + 63 - l; its weight is V[i + 1]
+#pragma unroll
+    for (int c = 0; c < C; ++c) carry[c] = 0.f;
+    float vnext0 = 1.f;                                                  // V[first sample of the chunk to the right]
+#pragma unroll
+    for (int k = NCH - 1; k >= 0; --k) {
+        if (k < nch) {
+            const int base = 64 * k, i = base + (63 - lane);
+            float xr[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) xr[c] = __shfl(x[k][c], 63 - lane);
+            float vr = __shfl(v[k], (64 - lane) & 63);                       // V[base + 64 - l], l >= 1
+            if (lane == 0) vr = vnext0;
+            vnext0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 0));
+            const float vv = (i + 1 < W) ? vr : 1.f;
+            float ma = (i >= W - 1) ? 0.f : vv, mb[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) mb[c] = (i >= W - 1) ? xr[c] : (1.f - vv) * xr[c];
+            if (i >= W) {
+                ma = 1.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) mb[c] = 0.f;
+            }
+            scan_affine<C>(ma, mb);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float y = fmaf(ma, carry[c], mb[c]);
+                if (i < W) f[c * HW + i] = y;
+                carry[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63));  // sample `base`, the left-most of this chunk
+            }
+        }
+    }
+}
+
 constexpr int DT_UF = 8;
 template <typename TJ, int C>
 __global__ __launch_bounds__(NT) void dt_cols_fused_kernel(const TJ *__restrict__ J, float *__restrict__ F, int H, int W,
@@ -525,7 +625,13 @@ static int dt_filter_fused(pb_ctx *ctx, const T *in, const T *J, float *out, int
         const float a = (float)std::exp(-std::sqrt(2.0) / sigma_i);
         const float log_a = std::log(a);
         const dim3 rgrid((unsigned)((rows_total + 3) / 4)), cgrid((unsigned)((cols_total + NT - 1) / NT));
-        if (i == 0)
+        // (the first iteration of a filter guided by its own input, rows of up to 2048 samples: the row lives in registers)
+        const bool reg_rows = i == 0 && J == in && W <= 2048 && ctx->dt_rows_reg;
+        if (reg_rows && W <= 1024)
+            hipLaunchKernelGGL((dt_rows_reg_kernel<T, C, 16>), rgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a, rows_total);
+        else if (reg_rows)
+            hipLaunchKernelGGL((dt_rows_reg_kernel<T, C, 32>), rgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a, rows_total);
+        else if (i == 0)
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, T, C>), rgrid, dim3(NT), 0, ctx->stream, J, in, out, H, W, ratio, log_a, rows_total);
         else
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, float, C>), rgrid, dim3(NT), 0, ctx->stream, J, out, out, H, W, ratio, log_a, rows_total);

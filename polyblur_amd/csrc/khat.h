@@ -48,6 +48,7 @@ static __device__ const double kSin64[64] = {
     -0.38268343236509039, -0.2902846772544625, -0.19509032201612872, -0.098017140329560506
 };
 constexpr int KH_SLICES = 16;          // workgroups per image: each forms the spectrum at 4 of the 64 (8 of the 128) x positions
+constexpr int KH_SLICES_LEAN = 64;     // ... of the parameter kernel's short chain (estimate.hip): 1 of the 64 (2 of the 128) -- the last phase, one output per thread, was 10.6 k of that chain's 35.6 k cycles at 16 slices (tools/params_trace.py)
 
 // What khat_body needs of a record, for a caller that has just formed it and still holds it in LDS (estimate.hip's
 // parameter kernel): no wait for the record's stores to land, no read back.
@@ -127,13 +128,15 @@ static __device__ const double kSin128[128] = {
 // lane half h, i.e. frequency fy = 2 K(g) + h with K(g) = (g >> 3) + 8 (g & 7) the 64-point transform's register order -- and
 // register `reg` of lane half hh holds fx = 2 K(reg) + hh.  Slice s of KH_SLICES = 16 forms registers 4 s .. 4 s + 3 (8 fx
 // values).  sk: the taps in LDS (zero outside the record's box); both transforms' 1/128 folded in.  Called by all KH_THREADS.
-__device__ __forceinline__ void khat128_body(const float *sk, float *out, int slice, const PolySpec ps) {
-    constexpr int NU = PB_KRAD + 1, NX = 2 * 64 / KH_SLICES, RPS = 64 / KH_SLICES;      // fx values / registers per slice
+// c8 / s8: cos / sin (2 pi m / 128) in LDS, m = 0 .. 127 (the caller fills them -- early, so that their trip through memory
+// is not on the chain -- and has passed a barrier since).
+template <int SL>
+__device__ __forceinline__ void khat128_body(const float *sk, float *out, int slice, const PolySpec ps, const double *c8, const double *s8) {
+    constexpr int NU = PB_KRAD + 1, NX = 2 * 64 / SL, RPS = 64 / SL;      // fx values / registers per slice
+    static_assert(RPS >= 1, "at most 64 slices");
     __shared__ double2 G8[NU * NX];
-    __shared__ double c8[128], s8[128];
     const int tid = threadIdx.x;
-    if (tid < 128) { c8[tid] = kCos128[tid]; s8[tid] = kSin128[tid]; }
-    __syncthreads();
+    PB_PT(27);
     auto K64 = [](int g) { return (g >> 3) + 8 * (g & 7); };
     if (tid < NU * NX) {
         const int u = tid / NX + PB_KRAD, xi = tid % NX, reg = RPS * slice + (xi >> 1), fx = 2 * K64(reg) + (xi & 1);
@@ -147,6 +150,7 @@ __device__ __forceinline__ void khat128_body(const float *sk, float *out, int sl
         G8[tid] = make_double2(ar, ai);
     }
     __syncthreads();
+    PB_PT(28);
     for (int idx = tid; idx < NX * 128; idx += KH_THREADS) {
         const int xi = idx >> 7, s = idx & 127, fy = 2 * K64(s >> 1) + (s & 1);
         double ar = 0.5 * G8[xi].x;
@@ -180,9 +184,12 @@ template <typename F> __device__ __forceinline__ int tail_radius(F m, int n, flo
 // Called by all KH_THREADS threads of a workgroup: slice `slice` (0 .. KH_SLICES - 1) of the spectrum of `info`'s taps,
 // and (slice 0) the image's choice of body.  The record may have been written by this same workgroup just before (global
 // memory, then a barrier): it is read through the vector path.
+// lean: the caller is a short-chain workgroup of the parameter kernel (estimate.hip): `strip` is the record workgroup's to write.
+template <int SL = KH_SLICES>
 __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, pb_fft_sel *sel, int min_phases, int slice,
-                                          const PolySpec ps = no_poly(), const RecLds *rl = nullptr) {
-    constexpr int NR = PB_KRAD + 1, PXS = KH_FT_N / KH_SLICES;
+                                          const PolySpec ps = no_poly(), const RecLds *rl = nullptr, bool lean = false) {
+    constexpr int NR = PB_KRAD + 1, PXS = KH_FT_N / SL;
+    __shared__ double c8[128], s8[128];
     constexpr int K1 = PB_KSIZE, K2 = 2 * PB_KSIZE - 1, K3 = 3 * PB_KSIZE - 2;
     __shared__ double2 G[NR * PXS];
     __shared__ double cs[KH_FT_N], sn[KH_FT_N];
@@ -194,7 +201,12 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     const int R = rl ? rl->radius : info->radius;
     const int separable = rl ? rl->separable : info->separable;
     if (tid < KH_FT_N) { cs[tid] = kCos64[tid]; sn[tid] = kSin64[tid]; }
+    if (ps.on == 3 && tid >= 64 && tid < 192) { c8[tid - 64] = kCos128[tid - 64]; s8[tid - 64] = kSin128[tid - 64]; }   // (for khat128_body: requested here, met by the barriers below)
     bool sym = true;
+    // (the short chain: the taps are the caller's LDS array as it is -- full support, nothing outside the box to mask -- and
+    // point-symmetric by construction, PolySpec.always)
+    const float *skp = lean ? rl->taps : sk;
+    if (!lean)
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
         const bool in = abs(u) <= R && abs(v) <= R;
@@ -226,12 +238,12 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     if (tid < K1) {
         float a = 0.f;
 #pragma unroll
-        for (int u = 0; u < K1; ++u) a += fabsf(sk[u * K1 + tid]);
+        for (int u = 0; u < K1; ++u) a += fabsf(skp[u * K1 + tid]);
         s_m[0][tid] = a; s_mp[0][PD + tid] = a;
     } else if (tid >= 64 && tid < 64 + K1) {
         float a = 0.f;
 #pragma unroll
-        for (int v = 0; v < K1; ++v) a += fabsf(sk[(tid - 64) * K1 + v]);
+        for (int v = 0; v < K1; ++v) a += fabsf(skp[(tid - 64) * K1 + v]);
         s_m[1][tid - 64] = a; s_mp[1][PD + tid - 64] = a;
     }
     __syncthreads();
@@ -309,11 +321,12 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         sel->use_fft = use ? 1 : 0;
         sel->rf = poly ? (ps.on == 1 ? 12 : 0) : Rh;
         sel->hx = poly ? hxp : hxk; sel->hy = poly ? hyp : hyk;
-        sel->strip = (separable != 0 && R > 8) ? 1 : 0; sel->poly = poly128 ? 2 : (poly ? 1 : 0);
+        if (!lean) sel->strip = (separable != 0 && R > 8) ? 1 : 0;
+        sel->poly = poly128 ? 2 : (poly ? 1 : 0);
         sel->pad_[0] = 0; sel->pad_[1] = 0;
     }
     PB_PT(23);
-    if (poly128) { khat128_body(sk, out, slice, ps); PB_PT(22); return; }
+    if (poly128) { khat128_body<SL>(skp, out, slice, ps, c8, s8); PB_PT(22); return; }
     if (!use) return;
     // the kernel is point-symmetric: rows 12 - u and 12 + u of the first sum are complex conjugates, so only rows 12 .. 24
     // are formed and the second sum is  G[12] + 2 sum_{u > 12} Re(G[u] e^{i phi_u}); this workgroup's x positions only
@@ -324,7 +337,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
 #pragma unroll 5
         for (int v = 0; v < PB_KSIZE; ++v) {
             const int m = (fx * (v - PB_KRAD)) & 63;
-            const double k = (double)sk[u * PB_KSIZE + v];
+            const double k = (double)skp[u * PB_KSIZE + v];
             ar += k * cs[m]; ai += k * sn[m];
         }
         G[tid] = make_double2(ar, ai);

@@ -1,0 +1,118 @@
+"""Round-5 forms against the forms they replace (same box, same inputs, through the C ABI).
+
+* the parameter kernel's SHORT chain (PB_EST_LEAN, csrc/estimate.hip: blur_params_kernel): the workgroups that form the
+  spectra no longer form the record first -- record, selection and output must not change by a bit
+  (blur_estimation.py:138-232);
+* PolySpec.always (PB_POLY_ALWAYS, csrc/conv.hip: pb_launch_conv_poly): two window launches per polynomial and nothing else
+  for large images under the wrap boundary -- against the call that issues every launch its records might need, and
+  against the oracle (deblurring.py:139-169);
+* the domain-transform row pass with the row in registers (PB_DT_ROWS_REG, csrc/filters.hip: dt_rows_reg_kernel): bit-identical
+  to the pass through global memory (domain_transform.py:56-85)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import polyblur_ref as ref                      # the checker (tests only)
+from polyblur_amd.synthetic import synthetic_blurry_batch
+
+
+def _engine(**env):
+    from polyblur_amd.engine import Engine
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def engines():
+    return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
+            "dt_global": _engine(PB_DT_ROWS_REG=0)}
+
+
+KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
+FIELDS = ("mags", "interp", "theta", "sigma", "rho", "kernel", "gray_min", "gray_max", "separable", "radius", "nphase", "kx", "ky")
+
+
+def _run(eng, x, **kw):
+    """(output, per-iteration records: a structured array (n_iter, B) of pb_blur_info)"""
+    return eng.polyblur(x, eng.make_options(**kw), want_info=True)
+
+
+@pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 1080, 1920), np.float32), ((1, 3, 736, 1290), np.float16),
+                                         ((1, 1, 1600, 2000), np.float32)])
+def test_short_chain_and_two_launches_change_nothing(engines, shape, dtype):
+    """images of 150 window pairs and more (the class PolySpec.always covers): the default call, the call whose parameter
+    kernel forms the whole record first, and the call that issues every launch are bit-identical -- output, records
+    (stencil parts included: the record workgroup forms them beside the short chain) and selections"""
+    B, C, H, W = shape
+    x, _ = synthetic_blurry_batch(B, C, H, W, seed0=91)
+    x = x.astype(dtype)
+    outs = {}
+    for name in ("default", "full_record", "every_launch"):
+        out, infos = _run(engines[name], x, n_iter=3, **KW)
+        sels = [engines[name].body_selection(B, k).copy() for k in range(3)]
+        outs[name] = (out, infos, sels)
+    a = outs["default"]
+    for name in ("full_record", "every_launch"):
+        b = outs[name]
+        assert np.array_equal(a[0], b[0]), name
+        for ia, ib in zip(a[1], b[1]):
+            for f in FIELDS:
+                assert np.array_equal(np.asarray(ia[f]), np.asarray(ib[f])), (name, f)
+    # every image took a one-pass form in the default call, on the windows the model priced lower
+    for k in range(3):
+        s = a[2][k]
+        assert (s[:, 0] == 1).all() and (s[:, 3] != 0).all(), s
+        # (the call that issues every launch keeps the stencil / three-step forms in its model: where it, too, chose one pass,
+        # the windows and halos agree)
+        t = outs["every_launch"][2][k]
+        same = t[:, 3] != 0
+        assert np.array_equal(s[same][:, 3:6], t[same][:, 3:6])
+        assert np.array_equal(s[:, 2], outs["full_record"][2][k][:, 2])              # `strip`: the record workgroup's word
+    # ... and the oracle agrees (fp32: 2e-5 after three iterations, identical theta sequence; fp16 I/O: 1e-3)
+    want, winfos = ref.polyblur_deblurring(x.astype(np.float32), n_iter=3, return_info=True, **KW)
+    tol = 2e-5 if dtype == np.float32 else 1e-3
+    assert np.abs(a[0].astype(np.float32) - want).max() < tol
+    for ia, iw in zip(a[1], winfos):
+        assert np.array_equal(np.asarray(ia["theta"], np.float32).reshape(-1), np.asarray(iw["theta"], np.float32).reshape(-1))
+
+
+def test_wide_rank1_kernels_take_one_pass_too(engines):
+    """sigma = rho = 4 (a flat image region: the clamp of blur_estimation.py:171-185): the widest composite there is (halo 36)
+    -- under PolySpec.always it runs on 128 x 128 windows with 56 x 56 tiles instead of three stencil passes"""
+    yy, xx = np.meshgrid(np.arange(800, dtype=np.float64), np.arange(1400, dtype=np.float64), indexing="ij")
+    g = 0.5 + 0.4 * np.sin(2 * np.pi * xx / 1400) * np.cos(2 * np.pi * yy / 800)                  # periodic, no edges: the gradient
+    x = np.stack([g, 0.9 * g, 0.8 * g])[None].astype(np.float32)                                  # maxima are ~0.005 -> sigma = rho = 4
+    out, infos = _run(engines["default"], x, n_iter=2, **KW)
+    assert float(infos[0]["sigma"][0]) == 4.0 and float(infos[0]["rho"][0]) == 4.0, (infos[0]["sigma"], infos[0]["rho"])
+    s = engines["default"].body_selection(1, 0)
+    assert s[0, 0] == 1 and s[0, 3] == 2, s
+    want = ref.polyblur_deblurring(x, n_iter=2, **KW)
+    assert np.abs(out - want).max() < 2e-5
+    out2, _ = _run(engines["every_launch"], x, n_iter=2, **KW)
+    assert np.abs(out - out2).max() < 5e-6                                              # (another form: rounding only)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 37, 203), (1, 3, 90, 1920), (1, 1, 33, 1024), (3, 3, 5, 2048), (1, 3, 17, 64), (2, 1, 9, 2)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_dt_rows_register_form(engines, shape, dtype):
+    """ragged tails, exactly-full chunks, the widest row the register form takes (2048), two-sample rows; fp32 and fp16"""
+    rng = np.random.default_rng(23)
+    x = rng.random(shape, dtype=np.float32).astype(dtype)
+    a = engines["default"].dt_recursive_filter(x, 2.0, 0.8, 1)
+    b = engines["dt_global"].dt_recursive_filter(x, 2.0, 0.8, 1)
+    assert np.array_equal(a, b)
+    tol = 5e-6 if dtype == np.float32 else 1e-3
+    assert np.abs(a.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
+    a3 = engines["default"].dt_recursive_filter(x, 6.0, 0.4, 3)                          # (later iterations: the in-place pass)
+    assert np.array_equal(a3, engines["dt_global"].dt_recursive_filter(x, 6.0, 0.4, 3))
