@@ -19,9 +19,14 @@ the timed region is bracketed by a barrier + device synchronise on both sides an
 reported.
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
-  roofline      -- the dominant kernel (the stencil pass): algorithmic bytes per launch / average launch
-                   duration, from hipEvents on the engine's stream around every launch of a second, identical
-                   run of the K steps (the headline `value` is timed without the per-launch events)
+  roofline      -- the dominant kernel class (the reblurring pass), from hipEvents on the engine's stream around every
+                   launch of a second, identical run of the K steps (the headline `value` is timed without them).
+                   `achieved` / `frac` are SURVEY 8d's ALGORITHMIC bytes (8 words per sample and polynomial, whatever
+                   the form) per launch / average launch duration -- the contract's figure, an equivalent rate;
+                   `hbm_min` = the bytes the forms that ran HAVE to move (2 words for a one-pass polynomial, 3 per
+                   iteration end to end) over the same times: the physical HBM fraction; `issue` = vector
+                   instructions issued per SIMD cycle (rocprofv3 PMC passes, profiles/); `bound` says which of them
+                   the kernel is near
   parity        -- the step's output against the oracle on the same image (N == 1): max-abs difference and
                    whether the per-iteration theta sequences are identical; the run FAILS above tolerance
   cpu_baseline  -- the NumPy oracle (a port of the reference's CPU path) timed on this box's host cores on
@@ -302,7 +307,7 @@ def main():
     achieved = alg_bytes_per_launch / (conv_avg_ms * 1e-3) / 1e9 if conv_n else 0.0
     # HBM-side bytes per launch of the same kernel from the rocprofv3 PMC passes of this same command
     # (tools/profile_bench.sh -> profiles/*_traffic.json; separate runs, FETCH_SIZE x2 on gfx950)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, cands = None, None, []
     try:
         import glob
         import hashlib
@@ -331,6 +336,8 @@ def main():
         pass
     roofline = dict(bound="hbm", kernel=dom_kernel + " (stencil pass; taps as estimated, full 25x25 support)",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    basis="SURVEY 8d algorithmic bytes: 8 words per sample and polynomial whatever the form (an EQUIVALENT three-pass "
+                          "rate, not bytes moved: see hbm_min for the physical HBM fraction)",
                     traffic=traffic, traffic_source=traffic_src, launches=conv_n, avg_launch_ms=round(conv_avg_ms, 5),
                     launches_per_polynomial=round(launches_per_poly, 3),
                     algorithmic_bytes_per_launch=int(alg_bytes_per_launch),
@@ -416,12 +423,61 @@ def main():
             roofline["body"] = dict(tile_spectrum_images=sum(spectrum), of=len(spectrum), per_iteration=per_it,
                                     working_launches_per_polynomial=round(sum(work) / max(len(work), 1), 2),
                                     stencil_multiply_adds_per_sample_it_replaces=round(sum(macs) / len(macs), 1),
-                                    note="algorithmic bytes are SURVEY 8d's 8 words per sample and polynomial whatever the form: a "
-                                         "one-pass polynomial moves 2 of them through HBM (read x, write y), so `achieved` can exceed what "
-                                         "any three-pass evaluation could reach; launches_per_polynomial counts every launch issued -- with "
-                                         "device-built records the two later steps' launches of a one-pass polynomial are issued and find no "
-                                         "work; context.end_to_end_three_step_form is the same call with PB_POLY1=0, "
-                                         "context.end_to_end_dense_stencil_body through the 2-D stencil body")
+                                    note="")
+            roofline["body"]["note"] = ("launches_per_polynomial counts every launch issued; under PolySpec.always (wrap boundary, no edgetaper, "
+                                        "images of 150 window pairs and more) a polynomial issues the 128x128 and the 64x64 window launch and nothing "
+                                        "else -- the one whose images the other one has finds no work; context.end_to_end_three_step_form is the same "
+                                        "call with PB_POLY1=0, context.end_to_end_dense_stencil_body through the 2-D stencil body")
+            # ---- what the forms that ran HAVE to move through HBM (the physical fraction) -------------------------------------
+            # a one-pass polynomial reads x and writes y: 2 words per sample; a three-step one SURVEY 8d's 8.  End to end one
+            # more read of the image per iteration (the estimation): 3 words where every polynomial is one pass.  Word sizes are
+            # the stored types: the caller's type at either end of the call, fp32 between iterations (and around the options).
+            n_it, opts_on = cfg["n_iter"], bool(cfg["opts"])
+            moved_poly = moved_e2e = 0.0
+            for k, pi in enumerate(per_it):
+                rd = s if (k == 0 and not cfg["opts"].get("prefiltering")) else 4
+                wr = s if (k == n_it - 1 and not opts_on) else 4
+                one_n, other_n = pi.get("one_pass_images", 0), pi.get("three_step_images", 0) + pi.get("stencil_images", 0)
+                per_img = 3 * H * W
+                moved_poly += per_img * (one_n * (rd + wr) + other_n * (3 * rd + 16 + wr))      # three steps: x read 3 times, t1 / t2 (fp32) written and read, y
+                moved_e2e += per_img * (one_n + other_n) * (s if k == 0 else 4)                                          # the estimation's read of the image
+            moved_e2e += moved_poly
+            conv_ms_step = conv_ms / args.steps
+            roofline["hbm_min"] = dict(
+                polynomial=dict(bytes_per_step=int(moved_poly), achieved=round(moved_poly / (conv_ms_step * 1e-3) / 1e9, 1), unit="GB/s",
+                                frac=round(moved_poly / (conv_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                note="bytes the reblurring launches have to move (read x, write y per one-pass polynomial) / their summed duration per step"),
+                end_to_end=dict(bytes_per_step=int(moved_e2e), achieved=round(moved_e2e * world / (ms_per_step * 1e-3) / 1e9, 1), unit="GB/s",
+                                frac=round(moved_e2e / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                note="+ one read of the image per iteration for the estimation (gray and its x derivative, one fp32 plane each, "
+                                     "are written and read once more: on-chip candidates, not counted); options' stages not counted"))
+            ceiling = (roofline.get("copy_ceiling_GBps") or {}).get("read2_write1")
+            if ceiling and achieved > ceiling:
+                roofline["bound"] = "latency/issue"
+                roofline["bound_note"] = ("the SURVEY-8d equivalent rate (%.0f GB/s) is above what a 2-read-1-write copy reaches on this box (%.0f GB/s): the "
+                                          "byte model no longer bounds a kernel that moves %.2f of its 8 words -- it is %.0f %% of HBM peak by bytes moved "
+                                          "(hbm_min), and what bounds it is the window transforms' dependent chains at 2 waves per SIMD (issue)"
+                                          % (achieved, ceiling, 8.0 * moved_poly / max(8.0 * 4 * samples * n_it, 1), 100 * roofline["hbm_min"]["polynomial"]["frac"]))
+            # ---- issue side: vector instructions per SIMD cycle, from the SQ pass of profiles/ (same sources) ------------------
+            try:
+                tj = json.load(open(cands[-1])) if traffic is not None else None
+                if tj and tj.get("sq") and tj.get("time"):
+                    doms = ("conv_wfft_kernel<", "conv_w128_kernel<")
+                    insts = sum(v.get("SQ_INSTS_VALU", 0) * tj["traffic"].get(k, {}).get("launches", 0) for k, v in tj["sq"].items() if k.startswith(doms))
+                    ns = sum(v.get("total_ns", 0) for k, v in tj["time"].items() if k.startswith(doms))
+                    launches_t = sum(v.get("calls", 0) for k, v in tj["time"].items() if k.startswith(doms))
+                    launches_c = sum(tj["traffic"].get(k, {}).get("launches", 0) for k in tj["sq"] if k.startswith(doms))
+                    clock = float(tj.get("clock_ghz") or 2.4)
+                    if insts and ns and launches_t == launches_c:
+                        per_cycle = insts / (ns * 1e-9 * 1024 * clock * 1e9)
+                        roofline["issue"] = dict(valu_instructions_per_simd_cycle=round(per_cycle, 4), peak=0.5, frac=round(per_cycle / 0.5, 4),
+                                                 valu_instructions_per_launch=int(insts / max(launches_c, 1)), launches_profiled=int(launches_c),
+                                                 clock_ghz=clock, source=os.path.basename(cands[-1]),
+                                                 note="SQ_INSTS_VALU of the class's launches / (their duration x 1024 SIMDs x clock); a wave64 vector "
+                                                      "instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md): peak 0.5 -- packed fp32 "
+                                                      "and LDS / memory instructions occupy issue slots beyond this count")
+            except Exception:
+                pass
         else:
             tflops = 2.0 * samples * (sum(macs) / len(macs)) / (conv_avg_ms * 1e-3) / 1e12 if conv_n else 0.0
             roofline["valu"] = dict(achieved=round(tflops, 1), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
@@ -429,16 +485,25 @@ def main():
                                     note="stencil bodies: multiply-adds issued / launch time; "
                                          "context.inner_loop_rank1_* is the HBM-bound separable case")
 
-    def inner_loop(theta_deg, sigma, rho, support, reps=20):
-        buf = eng.make_kernels([sigma] * B, [rho] * B, [np.deg2rad(np.float32(theta_deg))] * B, support=support,
-                               name="bench.info")
+    def inner_loop(theta_deg, sigma, rho, support, reps=20, e_=None):
+        en = e_ or eng
+        buf = en.make_kernels([sigma] * B, [rho] * B, [np.deg2rad(np.float32(theta_deg))] * B, support=support,
+                              name="bench.info")
         o = torch.empty_like(x)
-        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        ms = eng.time_inner_loop(x.data_ptr(), o.data_ptr(), capi.PB_F32 if s == 4 else capi.PB_F16, x.shape, buf.ptr,
+        en.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ms = en.time_inner_loop(x.data_ptr(), o.data_ptr(), capi.PB_F32 if s == 4 else capi.PB_F16, x.shape, buf.ptr,
                                  KW["alpha"], KW["beta"], capi.PB_WRAP, reps)
         gbs = 8.0 * s * samples / (ms * 1e-3) / 1e9
-        return dict(ms=round(ms, 4), achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / HBM_PEAK_GBS, 4),
-                    mp_per_s=round(B * H * W / 1e6 / (ms * 1e-3), 1))
+        # what the records' form moves: 2 words for a one-pass polynomial (pb_body_selection of the pass just timed), else 8
+        try:
+            sel = (e_ or eng).body_selection(B, -1)
+            words = float(np.mean([2.0 if (r[0] == 1 and r[3] != 0) else 8.0 for r in sel]))
+            form = "one window pass" if words == 2.0 else ("three Horner steps" if words == 8.0 else "mixed")
+        except Exception:
+            words, form = 8.0, "?"
+        moved = words * s * samples / (ms * 1e-3) / 1e9
+        return dict(ms=round(ms, 4), form=form, equivalent_three_pass_GBps=round(gbs, 1), moved_GBps=round(moved, 1),
+                    frac_of_8TBps_by_bytes_moved=round(moved / HBM_PEAK_GBS, 4), mp_per_s=round(B * H * W / 1e6 / (ms * 1e-3), 1))
 
     if not args.no_context and not from_root:
         side.update({
@@ -478,6 +543,10 @@ def main():
                 ms_3 = 1e3 * dt_3 / args.steps
                 side["end_to_end_three_step_form"] = dict(ms_per_step=round(ms_3, 4), mp_per_s=round(B * H * W / 1e6 / (ms_3 * 1e-3), 1),
                                                           max_abs_vs_default=float((out3.float() - out.float()).abs().max()))
+                # the north star's LITERAL kernel: separable taps through the rank-1 stencil body with LDS line staging (three
+                # launches, one Horner step each -- csrc/conv.hip), which the engine no longer picks for these records
+                side["inner_loop_rank1_stencil_body"] = dict(inner_loop(0.0, 2.0, 1.0, capi.PB_SUPPORT_FULL, e_=eng3),
+                                                             note="PB_POLY1=0: rank-1 taps through conv_tile_kernel, 8 words per sample moved")
             finally:
                 eng3.close()
         # the same call with every dense kernel through the 2-D stencil body (pb_set_dense_eval: PB_DENSE_STENCIL)
@@ -490,6 +559,16 @@ def main():
             eng.set_dense_eval("auto", capi.PB_DENSE_MIN_PHASES)
         ms_st = 1e3 * dt_st / args.steps
         side["end_to_end_dense_stencil_body"] = dict(ms_per_step=round(ms_st, 4), mp_per_s=round(B * H * W / 1e6 / (ms_st * 1e-3), 1))
+        # the reference's own choice of method on a GPU (main.py:109-112): the zero boundary; and the edgetaper option
+        for name, kw_x in (("end_to_end_method_direct", dict(kw, method="direct")), ("end_to_end_edgetaping", dict(kw, edgetaping=True))):
+            try:
+                for _ in range(2):
+                    polyblur_deblurring(x, **kw_x)
+                dt_x, _ = timed(args.steps, lambda: polyblur_deblurring(x, **kw_x))
+                ms_x = 1e3 * dt_x / args.steps
+                side[name] = dict(ms_per_step=round(ms_x, 4), mp_per_s=round(B * H * W / 1e6 / (ms_x * 1e-3), 1))
+            except Exception as e:                               # a labelled extra must not cost the run its line
+                side[name] = dict(error="%s: %s" % (type(e).__name__, str(e)[:200]))
         # the opt-in x-t separable APPROXIMATION of the oblique kernels (method='direct_separable', zero boundary):
         # its speed, and its distance to the exact zero-boundary result on this image
         sep_kw = dict(kw, method="direct_separable")
@@ -565,6 +644,7 @@ def main():
         "ms_per_step_device": (dict(median=round(step_ms[len(step_ms) // 2], 4), min=round(step_ms[0], 4), max=round(step_ms[-1], 4),
                                     n=len(step_ms), note="one event between steps, device time; `value` is the contract's total / K")
                                if step_ms else None),
+        "value_at_median_step": (round(mp_per_step / (step_ms[len(step_ms) // 2] * 1e-3), 1) if step_ms and world == 1 else None),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": desc, "name": args.config, "mode": args.mode, "images_per_gpu": B, "height": H, "width": W,
                    "parallelism": "images sharded, no data-path collective" if not from_root else

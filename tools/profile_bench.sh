@@ -5,7 +5,7 @@
 #   gpurun -- 'bash tools/profile_bench.sh r04 cfg3'     another BASELINE config (per-GPU share): <tag>_bench_cfg3_*
 # (every pass under `timeout`: a failed pass must not hang the box; counters in their own runs, never with the trace domains)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 CFG=${2:-cfg2}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -16,8 +16,8 @@ CMD="python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline -
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $CMD > /dev/null 2> "$OUT/pmc_fetch.log"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- $CMD > /dev/null 2> "$OUT/pmc_write.log"
-if [ "$CFG" = cfg2 ]; then
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_sq" -o pmc -- $CMD > /dev/null 2> "$OUT/pmc_sq.log"
+if true; then
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -o pmc -- $CMD > /dev/null 2> "$OUT/pmc_sq.log"
 fi
 python tools/rocprof_summary.py "$OUT" "$NAME"
 if [ "$CFG" = cfg2 ]; then

@@ -62,9 +62,22 @@ for k in sorted(set(fetch) | set(write)):
                       hbm_bytes_per_launch=int((2 * fk + wk) * 1024))
 sq = {}
 for c in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
-          "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"):
+          "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"):
     for k, (v, n) in counter_avg("pmc_sq", c).items():
         sq.setdefault(k, {})[c] = round(v)
+# per-kernel time of the traced run beside the counters (bench.py's roofline.issue divides one by the other), and the clock
+# the long kernels ran at: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+times = {short(r.get("Name", "")): dict(calls=int(r.get("Calls") or 0), total_ns=int(r.get("TotalDurationNs") or 0)) for r in rows}
+clock = None
+try:
+    num = den = 0.0
+    for k, v in sq.items():
+        t = times.get(k)
+        if t and t["calls"] and v.get("GRBM_GUI_ACTIVE") and t["total_ns"] / t["calls"] > 20000:
+            num += v["GRBM_GUI_ACTIVE"] / 8.0 * t["calls"]; den += t["total_ns"]
+    clock = round(num / den, 3) if den else None
+except Exception:
+    clock = None
 import hashlib, subprocess
 def conv_sources_hash():
     """sha256 over the reblurring pass's sources: bench.py refuses HBM-traffic numbers taken from other code"""
@@ -79,6 +92,6 @@ except Exception:
     sha = os.environ.get("PB_GIT_SHA", "?")
 json.dump(dict(tag=tag, git=os.environ.get("PB_GIT_SHA", sha), conv_sources_sha256_16=conv_sources_hash(), note="per-launch averages over every launch of the profiled bench.py run; "
                              "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction)",
-               traffic=traffic, sq=sq), open(os.path.join(root, tag + "_traffic.json"), "w"), indent=1)
+               traffic=traffic, sq=sq, time=times, clock_ghz=clock), open(os.path.join(root, tag + "_traffic.json"), "w"), indent=1)
 print(open(os.path.join(root, tag + "_kernel_stats.csv")).read() if stats else "no stats csv found")
 print(json.dumps({k: v for k, v in traffic.items() if "conv" in k}, indent=1))
