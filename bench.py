@@ -300,7 +300,8 @@ def main():
         # (the one-pass polynomial on 128 x 128 windows, conv_w128_kernel, carries the same event tag: one class)
         dom_kernel = "conv_wfft_kernel + conv_w128_kernel" if os.environ.get("PB_FFT_BODY", "wave") != "wg" and not cfg["opts"].get("half_temporaries") else "conv_fft_kernel"
     # one polynomial application = (2s + 3s + 3s) bytes per sample, spread over its launches
-    calls_per_step = B if from_root else 1                       # from_root deblurs image by image as they arrive
+    from polyblur_amd.distributed import default_chunk
+    calls_per_step = -(-B // default_chunk(B * world, world, 0)) if (from_root and world > 1) else 1   # from_root deblurs chunk by chunk as they arrive
     launches_per_poly = max(conv_n / (args.steps * cfg["n_iter"] * calls_per_step), 1e-9)
     alg_bytes_per_launch = 8.0 * s * (samples / calls_per_step) / launches_per_poly
     conv_avg_ms = conv_ms / max(conv_n, 1)

@@ -349,17 +349,30 @@ int pb_comm_scatter(pb_comm *comm, const void *root_batch, void *shard, int dtyp
 int pb_comm_gather(pb_comm *comm, const void *shard, void *root_batch, int dtype, int B, int C, int H, int W, int root);
 /* The overlapped form of scatter -> deblur -> gather (what polyblur_amd/distributed.py:deblur_from_root does over
  * torch.distributed; the reference's analogue is the sequential patch-group loop of deblurring.py:310-336): the batch
- * lives on `root`, travels image by image -- exchange step t is one grouped ncclSend / ncclRecv operation on a stream of
- * its own in which the root sends image t of every peer's shard and receives result t - 2 from every peer --, every
- * rank deblurs image t - 1 meanwhile (pb_polyblur_batch, one image per call), and the results land in root_out on the
- * root.  Called by every rank with the same B, C, H, W, dtype, options and root; root_batch / root_out are read /
- * written on the root only (NULL elsewhere).  Returns with the context's stream behind every transfer.
- * pb_comm_plan_steps / pb_comm_plan state the order of a step's operations (ops[3 i + 0..2] = { 1 send | 0 recv, peer,
- * image index }, at most 2 (world - 1) of them), the order both sides enumerate them in -- host-only, no GPU needed.   */
+ * lives on `root` and travels in CHUNKS of k consecutive images -- exchange step t is one grouped ncclSend / ncclRecv
+ * operation on a stream of its own in which the root sends chunk t of every peer's shard and receives result chunk t - 2
+ * from every peer --, every rank deblurs chunk t - 1 meanwhile (ONE pb_polyblur_batch call of k images: a lone 1080p image
+ * costs twice what it costs inside a batch), and the results land in root_out on the root.  Called by every rank with the
+ * same B, C, H, W, dtype, options, root and chunk; root_batch / root_out are read / written on the root only (NULL
+ * elsewhere).  Returns with the context's stream behind every transfer.  k: pb_comm_set_chunk (0 = pb_comm_default_chunk
+ * = about sqrt(largest peer shard / 2): 4 for 32 images per GPU, 1 for one).
+ *   On an error between two steps (a failed pb_polyblur_batch, a HIP error) every remaining step is still posted -- moving
+ * buffers whose content no longer matters -- so that no peer is left waiting for a matching send / recv; the first error
+ * is returned once the exchange stream has been joined.
+ *   EXPERIMENTAL for world > 1: the exchange has run over gloo (2 and 3 ranks, bit-exact) and in a world of one on an
+ * MI355X; no grouped ncclSend / ncclRecv of it has executed on two GPUs yet (tests/test_gpu_rccl.py runs it on first
+ * contact with a node that shows more than one).
+ * pb_comm_plan_steps(_chunked) / pb_comm_plan(_chunked) state the order of a step's operations -- chunked: ops[4 i + 0..3] =
+ * { 1 send | 0 recv, peer, first image, images }; image by image (k = 1): ops[3 i + 0..2] = { 1 send | 0 recv, peer, image
+ * index } -- at most 2 (world - 1) of them, the order both sides enumerate them in; host-only, no GPU needed.   */
 int pb_comm_deblur_from_root(pb_comm *comm, const void *root_batch, void *root_out, int dtype, int B, int C, int H, int W,
                              const pb_options *opt, int root);
+int pb_comm_set_chunk(pb_comm *comm, int chunk);
+int pb_comm_default_chunk(int B, int world, int root);
 int pb_comm_plan_steps(int B, int world, int root);
 int pb_comm_plan(int B, int world, int root, int rank, int step, int *ops, int *n_ops);
+int pb_comm_plan_steps_chunked(int B, int world, int root, int chunk);
+int pb_comm_plan_chunked(int B, int world, int root, int rank, int step, int chunk, int *ops, int *n_ops);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,8 @@ SYMBOLS = [
     "pb_fft_length_supported", "pb_make_separable_kernels", "pb_set_dense_eval",
     "pb_body_selection",
     "pb_comm_shard", "pb_comm_unique_id", "pb_comm_init", "pb_comm_destroy", "pb_comm_scatter", "pb_comm_gather",
-    "pb_comm_deblur_from_root", "pb_comm_plan_steps", "pb_comm_plan",
+    "pb_comm_deblur_from_root", "pb_comm_plan_steps", "pb_comm_plan", "pb_comm_set_chunk", "pb_comm_default_chunk",
+    "pb_comm_plan_steps_chunked", "pb_comm_plan_chunked",
 ]
 PROF_TAGS = ["conv", "gray", "grad_rows", "grad_cols", "params", "halo", "prefilter", "other", "conv_fused", "conv_fft"]
 
@@ -152,6 +153,10 @@ def load_library():
             "pb_comm_deblur_from_root": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, C.POINTER(pb_options), ci]),
             "pb_comm_plan_steps": (ci, [ci, ci, ci]),
             "pb_comm_plan": (ci, [ci, ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]),
+            "pb_comm_set_chunk": (ci, [vp, ci]),
+            "pb_comm_default_chunk": (ci, [ci, ci, ci]),
+            "pb_comm_plan_steps_chunked": (ci, [ci, ci, ci, ci]),
+            "pb_comm_plan_chunked": (ci, [ci, ci, ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]),
         }
         for name in SYMBOLS:
             fn = getattr(lib, name)           # AttributeError if the library does not export it

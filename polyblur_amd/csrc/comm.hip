@@ -9,7 +9,10 @@
 // RCCL is loaded with dlopen when the first communicator is made: the engine itself does not depend on librccl.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -69,6 +72,7 @@ struct pb_comm {
     // pb_comm_deblur_from_root: the exchange runs on a stream of its own beside the context's (compute) stream
     hipStream_t xs = nullptr;
     hipEvent_t ev_ready = nullptr, ev_all = nullptr, ev_arrived[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
+    int chunk = 0;       // images per exchange step of pb_comm_deblur_from_root (pb_comm_set_chunk); 0 = pb_comm_default_chunk
 };
 
 namespace {
@@ -191,13 +195,15 @@ static int exchange(pb_comm *c, const void *root_batch_in, void *root_batch_out,
     return PB_OK;
 }
 
-// ---- the overlapped pattern: image by image, transfers beside the compute --------------------------------------------
-// Exchange step t is ONE grouped operation in which the root sends image t of every peer's shard and receives result
-// t - 2 from every peer: its xGMI links carry traffic concurrently, and every peer has image t arriving and result t - 2
-// leaving while it deblurs image t - 1.  Both sides enumerate a step's operations in the same order (no tags: RCCL
-// ignores them) -- pb_comm_plan is that order, the one polyblur_amd/distributed.py:exchange_plan states in Python (the two
-// are compared for every (B, world, root, rank, step) on the CPU).
-int pb_comm_plan_steps(int B, int world, int root) {
+// ---- the overlapped pattern: chunk by chunk, transfers beside the compute ---------------------------------------------
+// Exchange step t is ONE grouped operation in which the root sends chunk t (k consecutive images) of every peer's shard
+// and receives result chunk t - 2 from every peer: its xGMI links carry traffic concurrently, and every peer has chunk t
+// arriving and result t - 2 leaving while it deblurs chunk t - 1 as one batch of k images.  Both sides enumerate a step's
+// operations in the same order (no tags: RCCL ignores them) -- pb_comm_plan_chunked is that order, the one
+// polyblur_amd/distributed.py:exchange_plan states in Python (the two are compared for every (B, world, root, rank, step, k) on
+// the CPU).  k = 1 is the image-by-image exchange of rounds 2 - 4; a lone 1080p call costs twice what an image costs inside
+// a batch, hence pb_comm_default_chunk ~ sqrt(shard / 2).  UNMEASURED on more than one GPU (one-GPU lease).
+int pb_comm_default_chunk(int B, int world, int root) {
     if (B < 0 || world < 1 || root < 0 || root >= world) return PB_ERR_BADARG;
     int mx = 0;
     for (int r = 0; r < world; ++r) {
@@ -206,22 +212,53 @@ int pb_comm_plan_steps(int B, int world, int root) {
         pb_comm_shard(B, world, r, &f, &n);
         if (n > mx) mx = n;
     }
-    return mx > 0 ? mx + 2 : 0;
+    int k = 1;
+    while (2 * (k + 1) * (k + 1) <= mx) ++k;
+    return k;
 }
 
-// ops[3 i + 0..2] = { 1 send / 0 recv, peer, image index }; at most 2 (world - 1) operations on the root, 2 elsewhere
-int pb_comm_plan(int B, int world, int root, int rank, int step, int *ops, int *n_ops) {
-    if (B < 0 || world < 1 || root < 0 || root >= world || rank < 0 || rank >= world || step < 0 || !ops || !n_ops) return PB_ERR_BADARG;
+int pb_comm_plan_steps_chunked(int B, int world, int root, int chunk) {
+    if (B < 0 || world < 1 || root < 0 || root >= world || chunk < 1) return PB_ERR_BADARG;
+    int mx = 0;
+    for (int r = 0; r < world; ++r) {
+        if (r == root) continue;
+        int f = 0, n = 0;
+        pb_comm_shard(B, world, r, &f, &n);
+        if (n > mx) mx = n;
+    }
+    return mx > 0 ? (mx + chunk - 1) / chunk + 2 : 0;
+}
+int pb_comm_plan_steps(int B, int world, int root) { return pb_comm_plan_steps_chunked(B, world, root, 1); }
+
+// ops[4 i + 0..3] = { 1 send / 0 recv, peer, first image, images }; at most 2 (world - 1) operations on the root, 2 elsewhere
+int pb_comm_plan_chunked(int B, int world, int root, int rank, int step, int chunk, int *ops, int *n_ops) {
+    if (B < 0 || world < 1 || root < 0 || root >= world || rank < 0 || rank >= world || step < 0 || chunk < 1 || !ops || !n_ops) return PB_ERR_BADARG;
     int n = 0;
     for (int r = 0; r < world; ++r) {
         if (r == root || (rank != root && r != rank)) continue;
         int lo = 0, cnt = 0;
         pb_comm_shard(B, world, r, &lo, &cnt);
         const int hi = lo + cnt, peer = rank == root ? r : root;
-        if (lo + step < hi) { ops[3 * n] = rank == root ? 1 : 0; ops[3 * n + 1] = peer; ops[3 * n + 2] = lo + step; ++n; }
-        if (step >= 2 && lo + step - 2 < hi) { ops[3 * n] = rank == root ? 0 : 1; ops[3 * n + 1] = peer; ops[3 * n + 2] = lo + step - 2; ++n; }
+        const long a = (long)lo + (long)step * chunk, b = (long)lo + (long)(step - 2) * chunk;
+        if (a < hi) { ops[4 * n] = rank == root ? 1 : 0; ops[4 * n + 1] = peer; ops[4 * n + 2] = (int)a; ops[4 * n + 3] = (int)std::min<long>(chunk, hi - a); ++n; }
+        if (step >= 2 && b < hi) { ops[4 * n] = rank == root ? 0 : 1; ops[4 * n + 1] = peer; ops[4 * n + 2] = (int)b; ops[4 * n + 3] = (int)std::min<long>(chunk, hi - b); ++n; }
     }
     *n_ops = n;
+    return PB_OK;
+}
+// (the image-by-image plan: ops[3 i + 0..2] = { 1 send / 0 recv, peer, image index })
+int pb_comm_plan(int B, int world, int root, int rank, int step, int *ops, int *n_ops) {
+    if (world < 1 || !ops || !n_ops) return PB_ERR_BADARG;
+    std::vector<int> o4(8 * (size_t)world);
+    const int rc = pb_comm_plan_chunked(B, world, root, rank, step, 1, o4.data(), n_ops);
+    if (rc) return rc;
+    for (int i = 0; i < *n_ops; ++i) { ops[3 * i] = o4[4 * i]; ops[3 * i + 1] = o4[4 * i + 1]; ops[3 * i + 2] = o4[4 * i + 2]; }
+    return PB_OK;
+}
+
+int pb_comm_set_chunk(pb_comm *c, int chunk) {
+    if (!c || chunk < 0) return PB_ERR_BADARG;
+    c->chunk = chunk;
     return PB_OK;
 }
 
@@ -242,78 +279,94 @@ int pb_comm_deblur_from_root(pb_comm *c, const void *root_batch, void *root_out,
     if (!r) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "pb_comm: librccl.so could not be loaded");
     int rc = make_exchange_stream(c);
     if (rc) return rc;
-    const int nsteps = pb_comm_plan_steps(B, c->world, root);
-    std::vector<int> ops(6 * (size_t)c->world);
+    const int k = c->chunk > 0 ? c->chunk : pb_comm_default_chunk(B, c->world, root);
+    const int nsteps = pb_comm_plan_steps_chunked(B, c->world, root, k);
+    std::vector<int> ops(8 * (size_t)c->world);
+    // every buffer the steps will name exists BEFORE anything is posted: a rank that bailed out between two steps would leave
+    // its peers' grouped operations hanging on their streams
+    char *in_ring[3] = {nullptr, nullptr, nullptr}, *out_ring[3] = {nullptr, nullptr, nullptr};
+    if (c->rank != root && cnt > 0) {
+        for (int i = 0; i < 3; ++i) {
+            const std::string a = "comm.in" + std::to_string(i), b = "comm.out" + std::to_string(i);
+            in_ring[i] = static_cast<char *>(pb_scratch(ctx, a.c_str(), ib * k));
+            out_ring[i] = static_cast<char *>(pb_scratch(ctx, b.c_str(), ib * k));
+            if (!in_ring[i] || !out_ring[i]) return PB_ERR_NOMEM;
+        }
+    }
     // whatever produced the batch (or last used the ring buffers) on the compute stream comes first
     PB_HIP(hipEventRecord(c->ev_ready, ctx->stream));
     PB_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
-    auto post = [&](int step, char *const *recv_ring, char *const *send_ring) -> int {
+    // From here on every step IS posted whatever fails in between -- a compute error, a HIP error: the first one is kept and
+    // returned at the end, the remaining steps still move their (then meaningless) buffers, so that no peer is left waiting
+    // for a matching send / recv; and the compute stream is joined behind the exchange stream on every way out.
+    int first_err = PB_OK;
+    std::string first_msg;
+    auto keep = [&](int e) { if (e && !first_err) { first_err = e; first_msg = ctx->err; } };
+    auto post = [&](int step) -> int {
         int n = 0;
-        pb_comm_plan(B, c->world, root, c->rank, step, ops.data(), &n);
+        pb_comm_plan_chunked(B, c->world, root, c->rank, step, k, ops.data(), &n);
         if (!n) return PB_OK;
         ncclResult_t e = r->GroupStart();
         for (int i = 0; i < n && e == 0; ++i) {
-            const int send = ops[3 * i], peer = ops[3 * i + 1], k = ops[3 * i + 2];
+            const int send = ops[4 * i], peer = ops[4 * i + 1], a = ops[4 * i + 2];
+            const size_t count = (size_t)ops[4 * i + 3] * img;
             if (c->rank == root) {
-                if (send) e = r->Send(static_cast<const char *>(root_batch) + (size_t)k * ib, img, nccl_type(dtype), peer, c->comm, c->xs);
-                else e = r->Recv(static_cast<char *>(root_out) + (size_t)k * ib, img, nccl_type(dtype), peer, c->comm, c->xs);
+                if (send) e = r->Send(static_cast<const char *>(root_batch) + (size_t)a * ib, count, nccl_type(dtype), peer, c->comm, c->xs);
+                else e = r->Recv(static_cast<char *>(root_out) + (size_t)a * ib, count, nccl_type(dtype), peer, c->comm, c->xs);
             } else {
-                if (send) e = r->Send(send_ring[(k - lo) % 3], img, nccl_type(dtype), peer, c->comm, c->xs);
-                else e = r->Recv(recv_ring[(k - lo) % 3], img, nccl_type(dtype), peer, c->comm, c->xs);
+                const int slot = ((a - lo) / k) % 3;
+                if (send) e = r->Send(out_ring[slot], count, nccl_type(dtype), peer, c->comm, c->xs);
+                else e = r->Recv(in_ring[slot], count, nccl_type(dtype), peer, c->comm, c->xs);
             }
         }
         const ncclResult_t e2 = r->GroupEnd();
         if (e != 0 || e2 != 0) return pb_fail(ctx, PB_ERR_HIP, "RCCL exchange step %d failed: %s", step, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "");
         return PB_OK;
     };
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess) keep(pb_fail(ctx, PB_ERR_HIP, "%s failed: %s (pb_comm_deblur_from_root)", what, hipGetErrorString(e)));
+    };
+    auto compute = [&](const char *src, char *dst, int n) {
+        if (first_err) return;                                   // (after a failure: move buffers, compute nothing)
+        keep(pb_polyblur_batch(ctx, src, dst, dtype, n, C, H, W, opt, nullptr));
+    };
     if (c->rank == root) {
-        // the root's own shard is spread over the steps; its transfers read root_batch and write other images of root_out
+        // the root's own shard is spread over the steps, one batch per step; its transfers read root_batch and write other
+        // images of root_out
         const int per_step = nsteps ? (cnt + nsteps - 1) / nsteps : cnt;
         int done = 0;
         for (int t = 0; t < nsteps; ++t) {
-            rc = post(t, nullptr, nullptr);
-            if (rc) return rc;
-            for (int j = 0; j < per_step && done < cnt; ++j, ++done) {
-                rc = pb_polyblur_batch(ctx, static_cast<const char *>(root_batch) + (size_t)(lo + done) * ib,
-                                       static_cast<char *>(root_out) + (size_t)(lo + done) * ib, dtype, 1, C, H, W, opt, nullptr);
-                if (rc) return rc;
+            keep(post(t));
+            const int n = std::min(per_step, cnt - done);
+            if (n > 0) {
+                compute(static_cast<const char *>(root_batch) + (size_t)(lo + done) * ib, static_cast<char *>(root_out) + (size_t)(lo + done) * ib, n);
+                done += n;
             }
         }
-        for (; done < cnt; ++done) {
-            rc = pb_polyblur_batch(ctx, static_cast<const char *>(root_batch) + (size_t)(lo + done) * ib,
-                                   static_cast<char *>(root_out) + (size_t)(lo + done) * ib, dtype, 1, C, H, W, opt, nullptr);
-            if (rc) return rc;
-        }
+        if (done < cnt)
+            compute(static_cast<const char *>(root_batch) + (size_t)(lo + done) * ib, static_cast<char *>(root_out) + (size_t)(lo + done) * ib, cnt - done);
     } else {
-        // ring of three: arriving / in work / leaving
-        char *in_ring[3], *out_ring[3];
-        for (int i = 0; i < 3; ++i) {
-            const std::string a = "comm.in" + std::to_string(i), b = "comm.out" + std::to_string(i);
-            in_ring[i] = static_cast<char *>(pb_scratch(ctx, a.c_str(), ib));
-            out_ring[i] = static_cast<char *>(pb_scratch(ctx, b.c_str(), ib));
-            if (!in_ring[i] || !out_ring[i]) return PB_ERR_NOMEM;
-        }
+        const int nchunks = (cnt + k - 1) / k;
         for (int t = 0; t < nsteps; ++t) {
-            // step t sends the result of image t - 2 (deblurred in step t - 1) and receives image t into the buffer image
+            // step t sends the results of chunk t - 2 (deblurred in step t - 1) and receives chunk t into the buffer chunk
             // t - 3 was deblurred from: both computes are behind ev_done of the younger one
-            if (t >= 2 && t - 2 < cnt) PB_HIP(hipStreamWaitEvent(c->xs, c->ev_done[(t - 2) % 3], 0));
-            rc = post(t, in_ring, out_ring);
-            if (rc) return rc;
-            PB_HIP(hipEventRecord(c->ev_arrived[t % 3], c->xs));
-            const int i = t - 1;                                    // image i arrived in step t - 1: deblur it now
-            if (i >= 0 && i < cnt) {
-                // (out_ring[i % 3] last held result i - 3, sent in step i - 1: complete before step i's event)
-                PB_HIP(hipStreamWaitEvent(ctx->stream, c->ev_arrived[i % 3], 0));
-                rc = pb_polyblur_batch(ctx, in_ring[i % 3], out_ring[i % 3], dtype, 1, C, H, W, opt, nullptr);
-                if (rc) return rc;
-                PB_HIP(hipEventRecord(c->ev_done[i % 3], ctx->stream));
+            if (t >= 2 && t - 2 < nchunks) hip_ok(hipStreamWaitEvent(c->xs, c->ev_done[(t - 2) % 3], 0), "hipStreamWaitEvent");
+            keep(post(t));
+            hip_ok(hipEventRecord(c->ev_arrived[t % 3], c->xs), "hipEventRecord");
+            const int i = t - 1;                                    // chunk i arrived in step t - 1: deblur it now
+            if (i >= 0 && i < nchunks) {
+                // (out_ring[i % 3] last held result chunk i - 3, sent in step i - 1: complete before step i's event)
+                hip_ok(hipStreamWaitEvent(ctx->stream, c->ev_arrived[i % 3], 0), "hipStreamWaitEvent");
+                compute(in_ring[i % 3], out_ring[i % 3], std::min(k, cnt - i * k));
+                hip_ok(hipEventRecord(c->ev_done[i % 3], ctx->stream), "hipEventRecord");
             }
         }
     }
     // the call returns with the compute stream behind every transfer (the root's output batch is complete there)
-    PB_HIP(hipEventRecord(c->ev_all, c->xs));
-    PB_HIP(hipStreamWaitEvent(ctx->stream, c->ev_all, 0));
-    return PB_OK;
+    hip_ok(hipEventRecord(c->ev_all, c->xs), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(ctx->stream, c->ev_all, 0), "hipStreamWaitEvent");
+    if (first_err) ctx->err = first_msg;
+    return first_err;
 }
 
 int pb_comm_scatter(pb_comm *c, const void *root_batch, void *shard, int dtype, int B, int C, int H, int W, int root) {

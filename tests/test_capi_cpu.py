@@ -158,6 +158,41 @@ def test_comm_exchange_plan_matches_the_python_layer(lib):
     assert lib.pb_comm_plan_steps(4, 2, 2) < 0 and lib.pb_comm_plan(4, 2, 0, 2, 0, ops, ctypes.byref(n)) != 0
 
 
+def test_comm_chunked_plan_matches_the_python_layer(lib):
+    """the same for exchange steps of k images (pb_comm_plan_chunked / pb_comm_plan_steps_chunked / pb_comm_default_chunk
+    against exchange_plan(..., chunk) / exchange_steps(..., chunk) / default_chunk): every (B, world, root, rank, step, k);
+    every image of a peer's shard travels out exactly once and comes back exactly once, two steps later"""
+    from polyblur_amd.distributed import default_chunk, exchange_plan, exchange_steps, shard_bounds
+    ops = (ctypes.c_int * (4 * 2 * 8))()
+    n = ctypes.c_int()
+    for B in (1, 2, 5, 9, 33, 64, 256):
+        for world in (1, 2, 3, 8):
+            for root in sorted({0, world - 1}):
+                assert lib.pb_comm_default_chunk(B, world, root) == default_chunk(B, world, root)
+                for k in sorted({1, 2, 3, 7, default_chunk(B, world, root)}):
+                    steps = lib.pb_comm_plan_steps_chunked(B, world, root, k)
+                    assert steps == exchange_steps(B, world, root, k)
+                    out, back = [], []
+                    for step in range(steps + 1):
+                        lists = {}
+                        for rank in range(world):
+                            assert lib.pb_comm_plan_chunked(B, world, root, rank, step, k, ops, ctypes.byref(n)) == 0
+                            got = [("send" if ops[4 * i] else "recv", ops[4 * i + 1], ops[4 * i + 2], ops[4 * i + 3]) for i in range(n.value)]
+                            want = [(o[0], o[1], o[2], o[3] if len(o) > 3 else 1) for o in exchange_plan(B, world, root, rank, step, k)]
+                            assert got == want, (B, world, root, rank, step, k)
+                            lists[rank] = got
+                        for peer in range(world):
+                            if peer != root:
+                                mirror = [("recv" if kind == "send" else "send", root, a, c) for kind, p, a, c in lists[root] if p == peer]
+                                assert mirror == lists[peer]
+                        out += [i for kind, p, a, c in lists[root] if kind == "send" for i in range(a, a + c)]
+                        back += [i for kind, p, a, c in lists[root] if kind == "recv" for i in range(a, a + c)]
+                    peers = sorted(i for r in range(world) if r != root for i in range(*shard_bounds(B, world, r)))
+                    assert sorted(out) == peers and sorted(back) == peers
+    assert lib.pb_comm_default_chunk(256, 8, 0) == 4 and lib.pb_comm_default_chunk(8, 8, 0) == 1      # BASELINE configs 4 and 5
+    assert lib.pb_comm_plan_steps_chunked(4, 2, 0, 0) < 0
+
+
 def test_line_length_tiers(lib):
     """include/polyblur_hip.h: 1 = whole lines in LDS, 2 = through a line buffer in device memory, 0 = not taken"""
     want = {1: 0, 2: 1, 4096: 1, 8191: 1, 8192: 1, 8200: 2, 20480: 1, 20736: 2, 40001: 2, 65536: 2, 65537: 0, 9000: 1, 12000: 1, 12001: 2}

@@ -118,3 +118,95 @@ def test_c_abi_deblur_from_root_world_of_one():
     assert lib.pb_comm_deblur_from_root(comm, None, C.c_void_p(out.data_ptr()), capi.PB_F32, 3, 3, 120, 168, C.byref(o), 0) != 0   # the root passes the batch
     assert lib.pb_comm_deblur_from_root(comm, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), 7, 3, 3, 120, 168, C.byref(o), 0) != 0  # unknown dtype
     assert lib.pb_comm_destroy(comm) == 0
+
+
+# ---- more than one GPU: the first contact of the world > 1 branches with hardware ---------------------------------------
+# (the lease of rounds 1 - 5 shows ONE MI355X, so these are skipped there; the driver's multi-GPU tier runs them)
+_TWO_RANK = r'''
+import ctypes as C, json, os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+from polyblur_amd import polyblur_deblurring, _capi as capi
+from polyblur_amd.distributed import deblur_from_root, default_chunk
+from polyblur_amd.engine import get_engine
+from polyblur_amd.synthetic import synthetic_blurry_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank); dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", device_id=dev)
+kw = dict(n_iter=2, c=0.362, b=0.468, alpha=6, beta=1)
+res = {}
+eng = get_engine(rank)
+eng.set_stream(torch.cuda.current_stream(rank).cuda_stream)
+# the C ABI communicator: rank 0 makes the id, everybody gets it through torch.distributed (any channel would do)
+ident = torch.zeros(128, dtype=torch.uint8)
+if rank == 0:
+    buf = C.create_string_buffer(128)
+    assert eng.lib.pb_comm_unique_id(buf) == 0
+    ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+ident = ident.to(dev); dist.broadcast(ident, 0); ident_b = bytes(ident.cpu().numpy().tobytes())
+comm = C.c_void_p()
+eng._check(eng.lib.pb_comm_init(C.byref(comm), eng.ctx, rank, world, ident_b))
+for B, root, chunk in %(cases)r:
+    H, W = 120, 168
+    x_np = synthetic_blurry_batch(B, 3, H, W, seed0=40 + B)[0]
+    x = torch.from_numpy(x_np).to(dev) if rank == root else None
+    # (1) the Python layer over torch.distributed
+    got = deblur_from_root(x, (B, 3, H, W), torch.float32, device=dev, root=root, chunk=chunk, **kw)
+    # (2) the C ABI over its own communicator
+    out = torch.zeros((B, 3, H, W), device=dev) if rank == root else None
+    o = eng.make_options(**kw)
+    eng._check(eng.lib.pb_comm_set_chunk(comm, 0 if chunk is None else chunk))
+    eng._check(eng.lib.pb_comm_deblur_from_root(comm, C.c_void_p(x.data_ptr()) if rank == root else None,
+                                                C.c_void_p(out.data_ptr()) if rank == root else None, capi.PB_F32, B, 3, H, W, C.byref(o), root))
+    eng.synchronize()
+    if rank == root:
+        # every image what it gets in a call of its own (bit-identical: what an image gets does not depend on its batch)
+        want = torch.cat([polyblur_deblurring(x[i:i + 1], **kw) for i in range(B)])
+        res["%%d/%%d/%%s" %% (B, root, chunk)] = [bool(torch.equal(got, want)), bool(torch.equal(out, want))]
+    dist.barrier()
+eng._check(eng.lib.pb_comm_destroy(comm))
+gathered = [None] * world
+dist.all_gather_object(gathered, res)
+if rank == 0:
+    merged = {}
+    for g in gathered:
+        merged.update(g)
+    print(json.dumps({"world": world, "results": merged}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the lease shows one (world > 1 stays unmeasured until a node shows more)")
+def test_two_ranks_from_root_python_and_c_abi(tmp_path):
+    """uneven shards (5 over 2), B < world (1 over 2), root != 0, image by image and in chunks: deblur_from_root and
+    pb_comm_deblur_from_root under torch.distributed.run with 2 ranks over RCCL, bit-equal to the unsharded calls"""
+    cases = [(5, 0, 1), (5, 1, 2), (1, 0, None), (1, 1, 1), (9, 0, None), (8, 1, 3)]
+    script = tmp_path / "two_ranks.py"
+    script.write_text(_TWO_RANK % dict(repo=REPO, cases=cases))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = _line(r.stdout)
+    assert res["world"] == 2 and len(res["results"]) == len(cases)
+    assert all(all(v) for v in res["results"].values()), res
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs")
+def test_bench_two_ranks_resident_and_from_root():
+    """bench.py the way the driver starts it at N = 2: the resident line, and the from-root mode (chunked exchange)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in ([], ["--mode", "from_root", "--config", "cfg4", "--batch", "4"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                            "--no-cpu-baseline", "--no-context", "--no-parity"] + extra, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = _line(r.stdout)
+        assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
