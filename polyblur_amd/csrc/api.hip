@@ -75,6 +75,7 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //   PB_POLY1=0..3               one-pass polynomial: 0 never, 1 4-sample halo class only, 2 + 64 x 64 windows with the
 //                               composite's halos, 3 (default) + 128 x 128 windows
 //   PB_POLY_GAIN, PB_POLY_MIN_AREA, PB_POLY_COST128, PB_POLY_MIN_PAIRS128   cost model of the forms (common.h: 0.7, 768, 8, 150)
+//   PB_POLY_PADDED=0            the polynomial after an edgetaper keeps three Horner steps
 //   PB_POLY_ALWAYS=0            never PolySpec.always (issue every launch the records might need)
 //   PB_SIDE_STREAM=0, PB_SIDE_MIN_TILES=<n>, PB_MAIN_STREAM_BODY=0|1   the side stream of launches that may find no work
 //   PB_EST_GRAY_ROWS=0|1|2      gray + range + row transform in one launch: never | fp32 lines up to 4096 | any line in LDS
@@ -100,7 +101,7 @@ static void pb_read_knobs(pb_ctx *ctx) {
     geti("PB_ROWS_NT", ctx->rows_nt); getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
     geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);
     getf("PB_POLY_COST128", ctx->poly_cost128); getl("PB_POLY_MIN_PAIRS128", ctx->poly_min_pairs128);
-    geti("PB_POLY_ALWAYS", ctx->poly_always); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
+    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
     geti("PB_MAIN_STREAM_BODY", ctx->main_stream_body);
 }
 
@@ -255,6 +256,8 @@ struct Geometry {
     // ker_size above 25: the taps on the ker_size grid (conv_big.hip), rebuilt after every estimation
     const float *big_taps = nullptr;
     int big_ksize = 0;
+    // the records are point-symmetric Gaussians the estimation of THIS call builds on an odd ker_size grid (PolySpec.always)
+    bool est_gaussians = false;
 };
 
 Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
@@ -409,7 +412,7 @@ int run_polynomial(pb_ctx *ctx, const Geometry &g, const void *xsrc, int x_dtype
     // with that filter's spectrum is the cheaper form take it, pb_fft_sel.poly; the spectra are then the polynomial's)
     // (records the estimation has just built under PolySpec.always keep that spec: their spectra are already those it asks for)
     const bool by_est = ctx->khat_by_estimate && ctx->khat_owner == info && ctx->khat_B == g.B && ctx->poly_built.always;
-    ctx->poly_want = poly_spec(ctx, steps, alpha, beta, by_est);
+    ctx->poly_want = poly_spec(ctx, steps, alpha, beta, by_est || g.est_gaussians);
     const int rc = pb_launch_conv_poly(ctx, steps);
     ctx->poly_want = no_poly();
     return rc;
@@ -444,10 +447,11 @@ int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtyp
         return run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, dst, dst_dtype,
                               final_clamp);
     float *y = static_cast<float *>(pb_scratch(ctx, "inv.y", sizeof(float) * g.P * g.HW));
-    float *ox = static_cast<float *>(pb_scratch(ctx, "inv.ox", sizeof(float) * g.P * g.HW));
-    if (!y || !ox) return PB_ERR_NOMEM;
+    if (!y) return PB_ERR_NOMEM;
     int rc = run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, y, PB_F32, 0);
     if (rc) return rc;
+    float *ox = static_cast<float *>(pb_scratch(ctx, "inv.ox", sizeof(float) * g.P * g.HW));
+    if (!ox) return PB_ERR_NOMEM;
     rc = pb_fourier_gradients_impl(ctx, y, g.P, g.H, g.W, ox, nullptr);     // only gout_x is used (deblurring.py:174)
     if (rc) return rc;
     if (xpadded)
@@ -659,6 +663,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     ctx->sel_slot = 0;
     Geometry g = geometry(B, C, H, W, ksize / 2);
     const bool poly_eligible = opt->boundary == PB_WRAP && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
+    g.est_gaussians = (ksize & 1) && ksize <= PB_KSIZE && !opt->separable_approx;
     const long n = (long)g.P * g.HW;
     const int n_iter = opt->n_iter;
     if (n_iter == 0) {

@@ -129,6 +129,7 @@ struct pb_ctx {
     long poly_min_pairs128 = 150;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels): 720p x 3 (180 pairs: 0.385 -> 0.325 ms per call) and up; 700 x 500 x 3 (72 pairs) is slower with them (0.256 -> 0.279)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
+    int poly_padded = 1;                 // env PB_POLY_PADDED: 0 = a polynomial whose operand is a padded plane (after an edgetaper) keeps three Horner steps
     int est_lean = 1;                    // env PB_EST_LEAN: 0 = the parameter kernel always forms the whole record before the spectra
     int dt_rows_reg = 1;                 // env PB_DT_ROWS_REG: 0 = the domain-transform row pass always through global memory (dt_rows_fused_kernel)
     int poly_always = 1;                 // env PB_POLY_ALWAYS: 0 = never PolySpec.always (every polynomial issues all the launches its records might need)

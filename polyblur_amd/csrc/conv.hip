@@ -425,7 +425,9 @@ int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
     if (ctx->poly_mode == 0 || ctx->fft_min_phases < 0) return 0;
     for (int s = 0; s < 3; ++s)
         if (steps[s].boundary != PB_WRAP || steps[s].epilogue != EPI_HORNER || !fft_pass_ok(steps[s])) return 0;
-    if (steps[0].in_kind != SRC_VIRTUAL) return 0;      // (after an edgetaper the x operand is a padded plane: three steps)
+    // (after an edgetaper the polynomial's operand is the padded, tapered plane: the window loaders read padded planes like
+    // virtual ones -- every Horner step but the first always did -- PB_POLY_PADDED=0: three steps there, as in rounds 3 - 4)
+    if (steps[0].in_kind != SRC_VIRTUAL && !ctx->poly_padded) return 0;
     // who runs the one pass: the first step's launch where it stores the type the last step stores (ConvPass.poly = 2), else
     // a composite launch from the first step's input to the last step's output -- whose types must be built
     ConvPass pc = steps[0];

@@ -36,7 +36,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -116,3 +116,25 @@ def test_dt_rows_register_form(engines, shape, dtype):
     assert np.abs(a.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
     a3 = engines["default"].dt_recursive_filter(x, 6.0, 0.4, 3)                          # (later iterations: the in-place pass)
     assert np.array_equal(a3, engines["dt_global"].dt_recursive_filter(x, 6.0, 0.4, 3))
+
+
+@pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 800, 1000), np.float16), ((1, 3, 200, 300), np.float32)])
+def test_edgetaper_copies_and_one_pass(engines, shape, dtype):
+    """edgetaping=True: the blends copy every tile pair on which alpha is exactly 1 (edgetaper.py:10-23: everything further than
+    24 samples from the padded border), and the polynomial that follows takes ONE window pass from the padded, tapered plane
+    where the image is large enough -- against three Horner steps there (rounding only), and against the oracle"""
+    B, C, H, W = shape
+    x, _ = synthetic_blurry_batch(B, C, H, W, seed0=12)
+    x = x.astype(dtype)
+    kw = dict(KW, n_iter=2, edgetaping=True)
+    a, ia = _run(engines["default"], x, **kw)
+    b, ib = _run(engines["taper_three_steps"], x, **kw)
+    tol = 2e-5 if dtype == np.float32 else 1e-3
+    assert np.abs(a.astype(np.float32) - b.astype(np.float32)).max() < (5e-6 if dtype == np.float32 else 1e-3)
+    want, winfos = ref.polyblur_deblurring(x.astype(np.float32), return_info=True, **kw)
+    assert np.abs(a.astype(np.float32) - want).max() < tol
+    for i, w in zip(ia, winfos):
+        assert np.array_equal(np.asarray(i["theta"], np.float32).reshape(-1), np.asarray(w["theta"], np.float32).reshape(-1))
+    if H >= 720:                                                       # (150 window pairs and more: the one-pass class)
+        s = engines["default"].body_selection(B, 1)
+        assert (s[:, 0] == 1).all() and (s[:, 3] != 0).all(), s
