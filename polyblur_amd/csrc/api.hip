@@ -75,6 +75,8 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //   PB_POLY1=0..3               one-pass polynomial: 0 never, 1 4-sample halo class only, 2 + 64 x 64 windows with the
 //                               composite's halos, 3 (default) + 128 x 128 windows
 //   PB_POLY_GAIN, PB_POLY_MIN_AREA, PB_POLY_COST128, PB_POLY_MIN_PAIRS128   cost model of the forms (common.h: 0.7, 768, 8, 150)
+//   PB_ZERO_RING_ASIDE=0        ... its first two ring steps behind the window pass instead of beside it (side stream)
+//   PB_ZERO_RING=0              method='direct' keeps three Horner steps over the whole image
 //   PB_POLY_PADDED=0            the polynomial after an edgetaper keeps three Horner steps
 //   PB_POLY_ALWAYS=0            never PolySpec.always (issue every launch the records might need)
 //   PB_SIDE_STREAM=0, PB_SIDE_MIN_TILES=<n>, PB_MAIN_STREAM_BODY=0|1   the side stream of launches that may find no work
@@ -101,7 +103,7 @@ static void pb_read_knobs(pb_ctx *ctx) {
     geti("PB_ROWS_NT", ctx->rows_nt); getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
     geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);
     getf("PB_POLY_COST128", ctx->poly_cost128); getl("PB_POLY_MIN_PAIRS128", ctx->poly_min_pairs128);
-    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
+    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); geti("PB_ZERO_RING", ctx->zero_ring); geti("PB_ZERO_RING_ASIDE", ctx->zero_ring_aside); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
     geti("PB_MAIN_STREAM_BODY", ctx->main_stream_body);
 }
 
@@ -353,6 +355,8 @@ PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta, 
     // and every kernel is the estimation's own Gaussian, "every image takes one window pass" is a fact of the call's options and
     // sizes: PolySpec.always, and pb_launch_conv_poly issues the two window launches only)
     const int always = (mode == 3 && cost128 > 0.f && gaussians && ctx->poly_always) ? 1 : 0;
+    // (under the zero boundary only that class takes one pass: interior by the window pass, frame by three ring steps)
+    if (steps[0].boundary != PB_WRAP && !always) return no_poly();
     return PolySpec{mode, alpha / 2 - beta + 2, 3 * beta - alpha - 6, 5 - 3 * beta + alpha / 2, beta, ctx->poly_gain, ctx->poly_min_area, cost128, always};
 }
 
@@ -662,7 +666,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     struct SlotGuard { pb_ctx *c; ~SlotGuard() { c->sel_slot = 0; c->poly_want = no_poly(); } } slot_guard{ctx};
     ctx->sel_slot = 0;
     Geometry g = geometry(B, C, H, W, ksize / 2);
-    const bool poly_eligible = opt->boundary == PB_WRAP && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
+    const bool poly_eligible = (opt->boundary == PB_WRAP || ctx->zero_ring) && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
     g.est_gaussians = (ksize & 1) && ksize <= PB_KSIZE && !opt->separable_approx;
     const long n = (long)g.P * g.HW;
     const int n_iter = opt->n_iter;

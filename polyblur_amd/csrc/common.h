@@ -45,6 +45,8 @@ struct ProfRec {
 // on 128 x 128 windows (conv_w128.hip, pb_fft_sel.poly == 2) where THAT is cheapest -- cost128 = what a 128 x 128 window pair
 // costs in units of a 64 x 64 one (four waves, longer transforms).
 // gain, min_area: the cost model of mode 2 (khat.h).
+// always == 2 (with on == 0; pb_build_khat_ring): the kernel's own spectrum, and every point-symmetric kernel takes the
+// three-step window form whatever its phase count or rank (the ring steps of a zero-boundary polynomial have no other launch).
 // always: EVERY image of the record set takes a one-pass form (64 x 64 or 128 x 128 windows, whichever the cost model prices
 // lower) -- the three-step and stencil forms are out of the model.  Asked for where the host can tell from (boundary,
 // options, image size, ker_size) alone that every composite fits a 128 x 128 window and every kernel is a point-symmetric
@@ -129,6 +131,8 @@ struct pb_ctx {
     long poly_min_pairs128 = 150;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels): 720p x 3 (180 pairs: 0.385 -> 0.325 ms per call) and up; 700 x 500 x 3 (72 pairs) is slower with them (0.256 -> 0.279)
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
+    int zero_ring_aside = 1;             // env PB_ZERO_RING_ASIDE: 0 = the ring steps of a zero-boundary polynomial all behind its window pass on the caller's stream
+    int zero_ring = 1;                   // env PB_ZERO_RING: 0 = a polynomial under the zero boundary (method='direct') keeps three Horner steps over the whole image
     int poly_padded = 1;                 // env PB_POLY_PADDED: 0 = a polynomial whose operand is a padded plane (after an edgetaper) keeps three Horner steps
     int est_lean = 1;                    // env PB_EST_LEAN: 0 = the parameter kernel always forms the whole record before the spectra
     int dt_rows_reg = 1;                 // env PB_DT_ROWS_REG: 0 = the domain-transform row pass always through global memory (dt_rows_fused_kernel)
@@ -234,6 +238,9 @@ struct ConvPass {
                          // composite pass, written to out2 with scale 1, coef 0 and clamp2 (same output type as `out`)
     void *out2;  int out2_kind;  int out2_pitch;  long out2_plane;  int clamp2;
     int no_fft;          // this pass keeps the stencil bodies (pb_launch_conv_poly: some step of the polynomial does not suit the other)
+    int ring;            // 0: every tile.  1 / 2 / 3: Horner step 1 / 2 / 3 of the BORDER RING of a zero-boundary polynomial whose interior
+                         // one window pass has done (pb_launch_conv_poly): only the window pairs the frame of outputs within 24 samples of
+                         // the padded border depends on (conv_wfft.hip: ring_live)
 };
 
 int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
@@ -241,6 +248,7 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p);
 int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps);
 int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // conv_xt.hip
 int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch);
+int pb_build_khat_ring(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel);   // conv_fft.hip: the kernels' OWN spectra, every symmetric kernel on three-step windows, in a second scratch set
 int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel);   // the scratch alone (the estimation fills it itself)
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // conv.hip: after the host (re)built these records
 void pb_forget_records(pb_ctx *ctx, const void *info, int B);                 // B records at info are about to be rewritten; nullptr: all

@@ -423,8 +423,11 @@ static int launch_tile_spectrum(pb_ctx *ctx, const ConvPass &p) {
 // within the 4-sample halo class only (either form); 0 = never (ctx->poly_mode == 0, or a step the form does not suit).
 int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
     if (ctx->poly_mode == 0 || ctx->fft_min_phases < 0) return 0;
+    // (the zero boundary, method='direct': one window pass for the interior plus three ring steps -- pb_launch_conv_poly --
+    // where PolySpec.always holds; the caller drops the spec otherwise)
     for (int s = 0; s < 3; ++s)
-        if (steps[s].boundary != PB_WRAP || steps[s].epilogue != EPI_HORNER || !fft_pass_ok(steps[s])) return 0;
+        if ((steps[s].boundary != PB_WRAP && !(steps[s].boundary == PB_ZERO && ctx->zero_ring)) || steps[s].boundary != steps[0].boundary ||
+            steps[s].epilogue != EPI_HORNER || !fft_pass_ok(steps[s])) return 0;
     // (after an edgetaper the polynomial's operand is the padded, tapered plane: the window loaders read padded planes like
     // virtual ones -- every Horner step but the first always did -- PB_POLY_PADDED=0: three steps there, as in rounds 3 - 4)
     if (steps[0].in_kind != SRC_VIRTUAL && !ctx->poly_padded) return 0;
@@ -524,15 +527,57 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
         const bool built = ctx->khat_by_estimate && ctx->khat_owner == steps[0].info && ctx->khat_B == B;
         int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !built);
         if (rc) return rc;
+        // The zero boundary: the window pass is the polynomial of the zero-EXTENDED image, which is the three-step result
+        // (every step truncated to the padded domain, filters.py:40-49) everywhere but within 24 samples of the padded border
+        // -- 12 of the image's.  That frame is recomputed by three Horner steps over the ring of window pairs it depends on
+        // (conv_wfft.hip: ring_live; the kernels' own spectra in a second scratch set), the last of which overwrites the
+        // frame's tiles of the output.  A ring step is a race of single window pairs (one or two rounds of ~20 us whatever
+        // its size), so the first two -- which touch neither the output nor the first set of spectra -- run on the side
+        // stream BESIDE the window pass; only the third waits for both.
+        const bool zero = steps[0].boundary == PB_ZERO;
+        const bool ring_aside = zero && ctx->aux && !ctx->prof_on && ctx->zero_ring_aside;
+        auto ring_steps = [&](int s0, int s1, float *k2, pb_fft_sel *sel2) -> int {
+            int e = PB_OK;
+            for (int s = s0; s < s1 && !e; ++s) {
+                ConvPass p = steps[s];
+                p.khat = k2; p.fsel = sel2; p.ring = s + 1; p.poly = 0;
+                e = pb_launch_conv_wfft(ctx, p);
+                if (e == PB_ERR_UNSUPPORTED) e = pb_fail(ctx, PB_ERR_UNSUPPORTED, "zero-boundary ring: the wave form does not take this pass");
+            }
+            return e;
+        };
+        float *k2 = nullptr; pb_fft_sel *sel2 = nullptr;
+        int rc_side = PB_OK;
+        if (ring_aside) {
+            PB_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            PB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->aux;
+            rc_side = pb_build_khat_ring(ctx, steps[0].info, B, &k2, &sel2);
+            if (!rc_side) rc_side = ring_steps(0, 2, k2, sel2);
+            ctx->stream = main_stream;
+            PB_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
+        }
         rc = composite128(k, sel);
-        if (rc) return rc;
         ConvPass pc = steps[0];
         pc.out_dtype = steps[2].out_dtype;
-        if (pb_conv_wfft_types(pc)) return composite(k, sel);
-        ConvPass p = steps[0];                                   // (the composite's types are not built: the first step's launch takes them along)
-        p.khat = k; p.fsel = sel;
-        first_step(p);
-        return launch_tile_spectrum(ctx, p);
+        if (!rc) {
+            if (pb_conv_wfft_types(pc)) rc = composite(k, sel);
+            else {
+                ConvPass p = steps[0];                           // (the composite's types are not built: the first step's launch takes them along)
+                p.khat = k; p.fsel = sel;
+                first_step(p);
+                rc = launch_tile_spectrum(ctx, p);
+            }
+        }
+        if (ring_aside) PB_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));     // (joined on every way out)
+        if (rc || rc_side || !zero) return rc ? rc : rc_side;
+        if (!ring_aside) {
+            rc = pb_build_khat_ring(ctx, steps[0].info, B, &k2, &sel2);
+            if (!rc) rc = ring_steps(0, 2, k2, sel2);
+            if (rc) return rc;
+        }
+        return ring_steps(2, 3, k2, sel2);
     }
     const long side_min_tiles = ctx->side_min_tiles;
     const long stencil_tiles = (long)((steps[0].H + 2 * steps[0].pad + 63) / 64) * ((steps[0].W + 2 * steps[0].pad + 63) / 64) * steps[0].P;

@@ -366,6 +366,22 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
     return PB_OK;
 }
 
+// The kernels' own spectra (not the polynomial's) and halos in a SECOND scratch set, every point-symmetric kernel on the
+// three-step window form: what the border ring of a zero-boundary polynomial runs its three Horner steps with while the
+// first set holds the polynomial's spectra of the interior's one window pass (pb_launch_conv_poly).  One launch, not cached.
+int pb_build_khat_ring(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel) {
+    float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat2", sizeof(float) * PB_KHAT_STRIDE * (size_t)B));
+    pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel2", sizeof(pb_fft_sel) * (size_t)B));
+    if (!k || !s) return PB_ERR_NOMEM;
+    PolySpec ps = no_poly();
+    ps.always = 2;
+    ProfScope prof(ctx, PB_PROF_PARAMS);
+    hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases, ps);
+    PB_LAUNCH_CHECK();
+    *khat = k; *sel = s;
+    return PB_OK;
+}
+
 bool pb_conv_fft_feasible(const ConvPass &p) { FftGeom g; return fft_geometry(p, g); }
 
 bool pb_conv_fft_types(const ConvPass &p) {

@@ -208,7 +208,7 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         // 16-byte pieces: both windows inside the source along x, on 16-byte boundaries; else (fp32, circular domain) a
         // four-byte gather per lane through the boundary model -- either way global -> LDS without touching a register
         const bool pieces = x_inside && (y_inside || Hp >= 2 * W_N) && ((a.in_pitch | (wxA - lo)) & 3) == 0;
-        if (sizeof(TIn) == 4 && (a.boundary == PB_WRAP ? true : (pieces && y_inside))) {
+        if (sizeof(TIn) == 4) {                                     // (either boundary model: rows and columns outside the zero boundary's domain are out-of-range offsets, which write zeros)
             // fp32 windows inside the source on 16-byte boundaries: every wave brings ITS 32 columns of both windows global ->
             // LDS in 16-byte pieces (four rows per wave instruction: 8 pieces of window A and 8 of window B per row), through
             // its quarter of the workgroup's LDS: four chunks of 32 rows -- 16 for the lower lanes, 16 for the upper --
@@ -220,7 +220,7 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             const int pc = lane & 15;
             const unsigned colb = (unsigned)(((pc < 8 ? wxA : wxB - 32) - lo + 32 * w + 4 * pc) * 4);
             const unsigned vo = (unsigned)((lane >> 4) * pitchb) + colb;
-            const bool virt = a.in_kind == SRC_VIRTUAL;
+            const bool virt = a.in_kind == SRC_VIRTUAL, wrapb = a.boundary == PB_WRAP;
             auto request = [&](int k, int buf) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {     // LDS rows 4 j .. 4 j + 3 of the chunk: lane half j >> 2, its rows 16 k + 4 (j & 3) ..
@@ -229,9 +229,10 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
                         dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (p0 - lo) * pitchb);
                     } else {
                         int pr = p0 + (lane >> 4);
-                        pr = pr < 0 ? pr + Hp : (pr >= Hp ? pr - Hp : pr);          // the circular domain (PB_WRAP) ...
+                        if (wrapb) pr = pr < 0 ? pr + Hp : (pr >= Hp ? pr - Hp : pr);   // the circular domain (PB_WRAP) ...
+                        const bool ok = pr >= 0 && pr < Hp;                             // (PB_ZERO: zeros outside the padded domain)
                         const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;   // ... of the replicate-padded plane
-                        dma16<0>(rin, zl + buf * 8192 + j * 1024, (unsigned)(row * pitchb) + colb, 0);
+                        dma16<0>(rin, zl + buf * 8192 + j * 1024, ok ? (unsigned)(row * pitchb) + colb : kNoAccess, 0);
                     }
                 }
             };
@@ -241,15 +242,15 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             // scalar side; the chunk then looks exactly like one that arrived in 16-byte pieces.
             const int gx = (lane < 32 || hasB ? (lane < 32 ? wxA : wxB) : wxA) + 32 * w + (lane & 31);   // (no window B: A's samples again -- finite, never stored)
             const int gix = map_axis(gx, a.W, a.in_kind, a.boundary, a.pad);
-            const unsigned gcol = (unsigned)(gix * (int)sizeof(TIn));
+            const unsigned gcol = gix >= 0 ? (unsigned)(gix * (int)sizeof(TIn)) : kNoAccess;
             auto gather = [&](int k, int buf) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {    // LDS row i of the chunk: window row 16 k + i (i < 16) or 64 + 16 k + i - 16
                     int pr = wy0 + 16 * k + (i < 16 ? i : 48 + i);
-                    while (pr < 0) pr += Hp;
-                    while (pr >= Hp) pr -= Hp;
-                    const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;
-                    dma4<0>(rin, zl + buf * 8192 + i * 256, gcol, row * pitchb);
+                    if (wrapb) { while (pr < 0) pr += Hp; while (pr >= Hp) pr -= Hp; }
+                    const bool ok = pr >= 0 && pr < Hp;
+                    const int row = ok ? (virt ? min(max(pr - a.pad, 0), a.H - 1) : pr) : 0;
+                    dma4<0>(rin, zl + buf * 8192 + i * 256, ok ? gcol : kNoAccess, row * pitchb);
                 }
             };
             // Both lanes of a pair read BOTH halves' rows of the chunk (LDS rows i and 16 + i of a buffer: 256 bytes each, A then

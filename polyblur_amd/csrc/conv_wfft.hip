@@ -168,20 +168,24 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                     // bytes per lane through the boundary model -- lane = column of window A (one wave instruction = the A half
                     // of an LDS row) or of window B (its other half), the row mapped on the scalar side: 128 wave instructions
                     // that touch no register, then the same LDS reads.
-                    const unsigned gcolA = (unsigned)map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;
-                    const unsigned gcolB = (unsigned)map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;   // (no window B: A's samples again -- finite, never stored)
-                    const int base = __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp));
+                    // (the zero boundary: a column or a row outside the padded domain is an out-of-range offset -- the request
+                    // returns zeros, the bounds check being on the lane's offset)
+                    const bool wrapb = a.boundary == PB_WRAP;
+                    const int mxa = map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad);
+                    const int mxb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad);   // (no window B: A's samples again -- finite, never stored)
+                    const unsigned gcolA = mxa >= 0 ? (unsigned)mxa * 4u : kNoAccess, gcolB = mxb >= 0 ? (unsigned)mxb * 4u : kNoAccess;
+                    const int base = wrapb ? __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp)) : oy0;
                     const bool virt_in = a.in_kind == SRC_VIRTUAL;
                     auto gather = [&](int k, int buf) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {     // LDS row i of the chunk = register 8 (i >> 1) + 2 k + (i & 1)
                             const int r = 8 * (i >> 1) + 2 * k + (i & 1);
                             int pr = base + r - (r >= wrap_r ? FT_N : 0);
-                            while (pr < 0) pr += Hp;
-                            while (pr >= Hp) pr -= Hp;
-                            const int so = (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb;
-                            dma4<0>(rin, zl + buf * 8192 + i * 512, gcolA, so);
-                            dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, gcolB, so);
+                            if (wrapb) { while (pr < 0) pr += Hp; while (pr >= Hp) pr -= Hp; }
+                            const bool ok = pr >= 0 && pr < Hp;
+                            const int so = ok ? (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb : 0;
+                            dma4<0>(rin, zl + buf * 8192 + i * 512, ok ? gcolA : kNoAccess, so);
+                            dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, ok ? gcolB : kNoAccess, so);
                         }
                     };
                     gather(0, 0); gather(1, 1);
@@ -245,27 +249,29 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                 wait_vm0();
                 pick(3, 1);
             }
-        } else if (sizeof(TIn) == 4 && a.boundary == PB_WRAP) {
-            // Border pairs of the circular domain, fp32: the same chunks through the same two LDS buffers, but gathered four
+        } else if (sizeof(TIn) == 4) {
+            // Border pairs (the circular domain, or the zero boundary's), fp32: the same chunks through the same two LDS buffers, but gathered four
             // bytes per lane through the boundary model -- lane = column of window A (one wave instruction = the A half of an
             // LDS row) or of window B (its other half), the row mapped on the scalar side: 128 wave instructions that touch no
             // register, then the loader's own LDS reads (sample by sample into the registers this took 128 loads per lane
             // and made the border pairs -- 8 % of the pairs at 4K, 15 % at 1080p -- the stragglers of every launch).
             lds_char *zl = lds_ptr(zb);
-            const unsigned gcolA = (unsigned)map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;
-            const unsigned gcolB = (unsigned)map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad) * 4u;   // (no window B: A's samples again -- finite, never stored)
-            const int base = __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp));
+            const bool wrapb = a.boundary == PB_WRAP;
+            const int mxa = map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad);
+            const int mxb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad);   // (no window B: A's samples again -- finite, never stored)
+            const unsigned gcolA = mxa >= 0 ? (unsigned)mxa * 4u : kNoAccess, gcolB = mxb >= 0 ? (unsigned)mxb * 4u : kNoAccess;
+            const int base = wrapb ? __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp)) : oy0;
             const bool virt_in = a.in_kind == SRC_VIRTUAL;
             auto gather = [&](int k, int buf) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {     // LDS row i of the chunk = register 8 (i >> 1) + 2 k + (i & 1)
                     const int r = 8 * (i >> 1) + 2 * k + (i & 1);
                     int pr = base + r - (r >= wrap_r ? FT_N : 0);
-                    while (pr < 0) pr += Hp;
-                    while (pr >= Hp) pr -= Hp;
-                    const int so = (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb;
-                    dma4<0>(rin, zl + buf * 8192 + i * 512, gcolA, so);
-                    dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, gcolB, so);
+                    if (wrapb) { while (pr < 0) pr += Hp; while (pr >= Hp) pr -= Hp; }
+                    const bool ok = pr >= 0 && pr < Hp;
+                    const int so = ok ? (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb : 0;
+                    dma4<0>(rin, zl + buf * 8192 + i * 512, ok ? gcolA : kNoAccess, so);
+                    dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, ok ? gcolB : kNoAccess, so);
                 }
             };
             const unsigned la = lds_addr(zb) + (unsigned)lane * 4u;
@@ -592,7 +598,7 @@ __device__ __forceinline__ bool pair_is_fast(const ConvPass &a, int ty, int pxi,
 // 16-byte boundaries.
 template <typename TIn, typename TX, typename TOut>
 __device__ __forceinline__ bool pair_is_gen(const ConvPass &a, int pxi, int hx) {
-    if (sizeof(TIn) != 4 || a.epilogue != EPI_HORNER || a.boundary != PB_WRAP) return false;
+    if (sizeof(TIn) != 4 || a.epilogue != EPI_HORNER) return false;      // (either boundary model: the gather maps it per lane and row)
     const int Tx = FT_N - 2 * hx;
     const OutRegion rg = out_region(a);
     const int Wp = a.W + 2 * a.pad;
@@ -640,6 +646,23 @@ __device__ __forceinline__ void copy_pair(const ConvPass &a, int plane, int ty, 
     for (int r = y0; r < y1; ++r)
         for (int c = x0 + lane; c < x1; c += 64)
             pb_st(opl + (long)(r - oo) * a.out_pitch + (c - oo), pb_ld(xpl + (long)(r - xsh) * a.x_pitch + (c - xsh)));
+}
+
+// The border ring of a zero-boundary polynomial (ConvPass.ring = Horner step 1 / 2 / 3).  Under the zero boundary the three
+// steps differ from the one window pass with the polynomial's spectrum only where a step's truncation to the padded domain
+// (filters.py:40-49: F.conv2d pads every step's operand with zeros) is within reach: outputs within 24 samples of the padded
+// border.  Step 3 therefore recomputes the pairs whose output rectangle comes within 24 samples of the border; they lie
+// within 24 + Ty (24 + 2 Tx along x: pairs) of it and read t2 12 further; step 2 the pairs that come within 36 + Ty
+// (36 + 2 Tx), which lie within 36 + 2 Ty (36 + 4 Tx) and read t1 12 further; step 1 the pairs that come within 48 + 2 Ty
+// (48 + 4 Tx).  Every sample a live pair reads was written by a live pair of the step before.
+__device__ __forceinline__ bool ring_live(const ConvPass &a, int ty, int pxi, int hx, int hy) {
+    const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
+    const OutRegion rg = out_region(a);
+    const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
+    const int y0 = rg.y_lo + ty * Ty, y1 = min(y0 + Ty, rg.y_hi), x0 = rg.x_lo + 2 * pxi * Tx, x1 = min(x0 + 2 * Tx, rg.x_hi);
+    const int dy = min(y0, Hp - y1), dx = min(x0, Wp - x1);
+    const int m = 3 - a.ring;                                    // 0 for step 3, 1 for step 2, 2 for step 1
+    return dy < 24 + 12 * m + m * Ty || dx < 24 + 12 * m + 2 * m * Tx;
 }
 
 // One wave (= one workgroup) per window pair; the GRID is the job list.  The jobs are the window pairs of the images whose
@@ -711,6 +734,7 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     const int plane = img * C + pl;
     const float *kp = a.khat + (long)img * PB_KHAT_STRIDE;
     const pb_blur_info *info = a.info + img;
+    if (a.ring && !ring_live(a, ty, pxi, hx, hy)) return;
     const ConvPass af = fold_pass(a, fold);
     if (taper_is_copy(af, ty, pxi, hx, hy)) { copy_pair<TX, TOut>(af, plane, ty, pxi, hx, hy); return; }
     if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<1, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);

@@ -221,7 +221,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     PB_PT(20);
     // (PolySpec.always: the host vouches for point-symmetric taps -- the estimation's own Gaussians -- and has no other launch
     // to fall back on; taps that compare unequal there are NaNs, which the one-pass form turns into the same zeros)
-    const bool symm = (__syncthreads_and(sym) || ps.always) && min_phases >= 0;
+    const bool symm = (__syncthreads_and(sym) || ps.always == 1) && min_phases >= 0;
     // The window halo of the tile-spectrum body, per axis.  The spectrum below holds EVERY tap of the record's box; the halo
     // only has to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error
     // of at most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero
@@ -293,7 +293,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     const int Rh = max(4, (max(s_h[0], s_h[1]) + 3) & ~3);          // the workgroup form's class (same halo on both axes)
     const bool dense = symm && separable == 0;
     // (windows with the 4-sample halo need 8 phases more to beat the stencil body, whose tile is then cheapest: measured)
-    const bool use3 = dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0);
+    const bool use3 = ps.always == 2 ? symm : (dense && nph >= min_phases + (R <= 4 && min_phases > 0 ? 8 : 0));
     // One-pass polynomial.  Mode 1: a kernel within the 4-sample halo class, whatever its phase count and whether rank-1 or
     // not -- the polynomial of a rank-1 kernel is not rank-1, its spectrum is as good as any -- (composite class 12: both
     // bodies).  Mode 2 (wave form only): wherever one pass over windows with the composite's halos costs less than what the
@@ -308,7 +308,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         // with records built on the device every surplus workgroup is dispatched to find that out)
         const float ak = (float)((KH_FT_N - 2 * hxk) * (KH_FT_N - 2 * hyk));
         // cost of each form in 64 x 64 window pairs per output sample (a stencil evaluation counts like one pass at min_area)
-        const float c3 = ps.always ? INFINITY : (use3 ? 3.f / (ps.gain * ak) : 1.f / (float)ps.min_area);
+        const float c3 = ps.always == 1 ? INFINITY : (use3 ? 3.f / (ps.gain * ak) : 1.f / (float)ps.min_area);
         float c64 = INFINITY, c128 = INFINITY;
         if (txp >= PB_POLY_MIN_TX && typ >= PB_POLY_MIN_TY && txp * typ >= ps.min_area) c64 = 1.f / (float)(txp * typ);
         const int tx8 = 2 * KH_FT_N - 2 * hxp, ty8 = 2 * KH_FT_N - 2 * hyp;

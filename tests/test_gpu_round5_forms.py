@@ -7,7 +7,10 @@
   for large images under the wrap boundary -- against the call that issues every launch its records might need, and
   against the oracle (deblurring.py:139-169);
 * the domain-transform row pass with the row in registers (PB_DT_ROWS_REG, csrc/filters.hip: dt_rows_reg_kernel): bit-identical
-  to the pass through global memory (domain_transform.py:56-85)."""
+  to the pass through global memory (domain_transform.py:56-85);
+* method='direct' (the zero boundary, filters.py:40-49; the reference's own choice on a GPU, main.py:109-112) as one window
+  pass plus three Horner steps over the border ring (PB_ZERO_RING, csrc/conv.hip + conv_wfft.hip: ring_live) against three
+  steps over the whole image, and against the oracle."""
 import os
 
 import numpy as np
@@ -36,7 +39,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "direct_three_steps": _engine(PB_ZERO_RING=0)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -138,3 +141,42 @@ def test_edgetaper_copies_and_one_pass(engines, shape, dtype):
     if H >= 720:                                                       # (150 window pairs and more: the one-pass class)
         s = engines["default"].body_selection(B, 1)
         assert (s[:, 0] == 1).all() and (s[:, 3] != 0).all(), s
+
+
+@pytest.mark.parametrize("shape,dtype,extra", [((1, 3, 720, 1280), np.float32, {}), ((2, 3, 1080, 1920), np.float32, {}),
+                                               ((1, 3, 736, 1290), np.float16, {}), ((1, 1, 1000, 1500), np.float32, dict(ker_size=13)),
+                                               ((1, 3, 800, 1200), np.float32, dict(remove_halo=True)), ((1, 3, 700, 1100), np.float32, dict(edgetaping=True))])
+def test_zero_boundary_ring(engines, shape, dtype, extra):
+    """the frame within 12 samples of the image border is where the truncation of every Horner step to the padded domain
+    matters: it must come out as from three steps over the whole image (rounding only: the interior is one window pass
+    instead of three), and the oracle's method='direct' must be matched end to end -- also with a smaller kernel grid
+    (pad 6), with halo masking behind the polynomial and with an edgetaper before it"""
+    B, C, H, W = shape
+    x, _ = synthetic_blurry_batch(B, C, H, W, seed0=77)
+    x = x.astype(dtype)
+    from polyblur_amd import _capi as capi
+    kw = dict(KW, n_iter=2, boundary=capi.PB_ZERO, **extra)
+    a, ia = _run(engines["default"], x, **kw)
+    b, ib = _run(engines["direct_three_steps"], x, **kw)
+    d = np.abs(a.astype(np.float32) - b.astype(np.float32))
+    assert d.max() < (5e-6 if dtype == np.float32 else 1e-3), (d.max(), np.unravel_index(d.argmax(), d.shape))
+    want, winfos = ref.polyblur_deblurring(x.astype(np.float32), n_iter=2, method="direct", return_info=True, **KW, **extra)
+    e = np.abs(a.astype(np.float32) - want)
+    assert e.max() < (2e-5 if dtype == np.float32 else 1e-3), (e.max(), np.unravel_index(e.argmax(), e.shape))
+    for i, w in zip(ia, winfos):
+        assert np.array_equal(np.asarray(i["theta"], np.float32).reshape(-1), np.asarray(w["theta"], np.float32).reshape(-1))
+    if not extra.get("edgetaping") and C == 3:                              # (150 window pairs and more: the class that takes one pass)
+        s0 = engines["default"].body_selection(B, 0)
+        assert (s0[:, 0] == 1).all() and (s0[:, 3] != 0).all(), s0       # the interior took a one-pass form
+
+
+def test_zero_boundary_ring_strong_blur(engines):
+    """a strongly blurred image (sigma ~ 3.5: composite halos up to 36, three-step halos 12): the widest ring there is"""
+    from polyblur_amd import _capi as capi
+    from polyblur_amd.synthetic import synthetic_blurry_image
+    x = np.stack([synthetic_blurry_image(3, 900, 1300, 5, blur=(3.5, 2.5, 48.0))[0]])
+    kw = dict(KW, n_iter=2, boundary=capi.PB_ZERO)
+    a, _ = _run(engines["default"], x, **kw)
+    b, _ = _run(engines["direct_three_steps"], x, **kw)
+    assert np.abs(a - b).max() < 5e-6
+    assert np.abs(a - ref.polyblur_deblurring(x, n_iter=2, method="direct", **KW)).max() < 2e-5
