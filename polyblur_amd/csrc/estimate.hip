@@ -16,9 +16,10 @@
 
 #include "common.h"
 #include "fft.h"
-// Debug build only (tools/build_variant.sh ... "-DPB_PARAMS_TRACE" estimate.hip): shader-clock stamps of the parameter
-// kernel's phases, first workgroup (tools/params_trace.py)
-#ifdef PB_PARAMS_TRACE
+// Lab build only (tools/build_variant.sh ptrace "-DPB_EXPERIMENTAL -DPB_PARAMS_TRACE" estimate.hip conv_fft.hip): shader-clock
+// stamps of the parameter kernel's phases, first workgroup (tools/params_trace.py).  Not in the product build, nor in a plain
+// --experimental one.
+#if defined(PB_EXPERIMENTAL) && defined(PB_PARAMS_TRACE)
 __device__ unsigned long long g_params_trace[32];
 #ifdef PB_PT_WANT       // (with it: the kernel body runs twice and the stamps are those of repetition PB_PT_WANT -- 1 = warm instruction cache)
 __device__ int g_pt_rep;

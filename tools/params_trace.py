@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the estimation's parameter kernel (debug build: tools/build_variant.sh ptrace "-DPB_PARAMS_TRACE" estimate.hip
+"""Phase stamps of the estimation's parameter kernel (debug build: tools/build_variant.sh ptrace "-DPB_EXPERIMENTAL -DPB_PARAMS_TRACE" estimate.hip
 conv_fft.hip; POLYBLUR_HIP_LIB=tools/_abl/lib_ptrace.so python tools/params_trace.py).  Shader-clock cycles, first workgroup."""
 import ctypes as C
 import sys
