@@ -170,8 +170,9 @@ void pb_default_options(pb_options *opt);        /* the functional API's default
  * the others and rank-1 kernels keep the stencil bodies (fp32 planes: one wave per window pair, conv_wfft.hip; fp16 and
  * 8-bit planes, and passes too small to fill the chip: one workgroup per pair, conv_fft.hip).  Replaces nothing in the reference: both are
  * evaluations of filters.convolve2d (filters.py:14-49).  Environment default: PB_DENSE_EVAL=stencil | <min_phases>.
- * (PB_STRIP=1 in the environment sends rank-1 kernels of full support on fp32 planes through the streaming strip body,
- * conv_strip.hip: an experiment measured slower than the tile body; same results to fp32 rounding.)
+ * (PB_STRIP=1 -- rank-1 kernels of full support through the streaming strip body, conv_strip.hip, an experiment measured
+ * slower than the tile body -- exists in `python -m polyblur_amd.build --experimental` builds only; the default library
+ * ignores it.  INTEGRATION.md section 5 lists every environment knob.)
  * With the wrap boundary and no edgetaper the three Horner steps of an image's polynomial are ONE filter,
  * a3 K^3 + a2 K^2 + a1 K + b -- the reference's own 'fft' form, deblurring.py:139-169.  The engine measures that filter's
  * halo per axis and takes the polynomial as one window pass with the polynomial's spectrum wherever that costs less than
