@@ -15,6 +15,23 @@
 #include <cstdlib>
 
 #include "common.h"
+// Lab build only (tools/build_variant.sh ltrace "-DPB_EXPERIMENTAL -DPB_LINES_TRACE" estimate.hip): wall-clock stamps (100 MHz)
+// of the fused line transform's stages, by thread 0 of workgroups 0, 1/4, 1/2 and the last of the launch -- the first eight
+// slots the row kernel's, the next eight the column kernel's (tools/lines_trace.py).
+#if defined(PB_EXPERIMENTAL) && defined(PB_LINES_TRACE)
+__device__ unsigned long long g_lines_trace[2 * 4 * 8];
+__device__ __forceinline__ void pb_lines_stamp(int i) {
+    if (threadIdx.x != 0) return;
+    const int kernel = blockDim.x >= 512 ? 1 : 0;                  // (4K: 256-thread row workgroups, 1024-thread column workgroups)
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    const int w = b == 0 ? 0 : (b == g / 4 ? 1 : (b == g / 2 ? 2 : (b == g - 9 ? 3 : -1)));
+    if (w >= 0) g_lines_trace[(kernel * 4 + w) * 8 + i] = wall_clock64();
+}
+#define PB_FT(i) pb_lines_stamp(i)
+extern "C" int pb_debug_lines_trace(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lines_trace), sizeof(unsigned long long) * 64);
+}
+#endif
 #include "fft.h"
 // Lab build only (tools/build_variant.sh ptrace "-DPB_EXPERIMENTAL -DPB_PARAMS_TRACE" estimate.hip conv_fft.hip): shader-clock
 // stamps of the parameter kernel's phases, first workgroup (tools/params_trace.py).  Not in the product build, nor in a plain

@@ -25,6 +25,12 @@
 #pragma once
 #include "common.h"
 
+// (lab builds: PB_FT(i) stamps the stages of spectral_derivative_fused -- estimate.hip defines it under
+// -DPB_EXPERIMENTAL -DPB_LINES_TRACE, tools/lines_trace.py reads the stamps)
+#ifndef PB_FT
+#define PB_FT(i)
+#endif
+
 namespace pbfft {
 
 
@@ -426,28 +432,35 @@ __device__ __forceinline__ bool fused_plan(const DevPlan &p) { return p.line_n =
 template <int MAXR = 16, class IO>
 __device__ __forceinline__ void spectral_derivative_fused(float2 *s, const DevPlan &p, int lognb, IO &io) {
     const int last = p.nstage - 1;
+    PB_FT(0);
 #define PB_FIRST(R) first_stage<R>(s, p.n, lognb, p.tw, io)
     PB_FFT_RADIX_SWITCH(p.radix[0], PB_FIRST)
 #undef PB_FIRST
+    PB_FT(1);
     __syncthreads();
+    PB_FT(2);
     int L = p.n / p.radix[0];
     for (int i = 1; i < last; ++i) {
         stage_any<false, MAXR>(s, p.n, lognb, L, p.radix[i], p.tw);
         L /= p.radix[i];
         __syncthreads();
     }
+    PB_FT(3);
 #define PB_CENTRE(R) centre_stage<R>(s, p.n, lognb, p.drev)
     PB_FFT_RADIX_SWITCH(p.radix[last], PB_CENTRE)
 #undef PB_CENTRE
     __syncthreads();
+    PB_FT(4);
     for (int i = last - 1; i >= 1; --i) {
         L *= p.radix[i];
         stage_any<true, MAXR>(s, p.n, lognb, L, p.radix[i], p.tw);
         __syncthreads();
     }
+    PB_FT(5);
 #define PB_LAST(R) last_stage<R>(s, p.n, lognb, p.tw, io)
     PB_FFT_RADIX_SWITCH(p.radix[0], PB_LAST)
 #undef PB_LAST
+    PB_FT(6);
 }
 
 // s holds NB interleaved complex lines of length plan.line_n in natural order (for bluestein
