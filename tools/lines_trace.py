@@ -32,4 +32,5 @@ for k, kname in enumerate(("rows (gray_rows_kernel)", "columns (grad_cols_kernel
     t0 = t[k, :, 0].min()
     print(kname)
     for w, wname in enumerate(("workgroup 0", "grid / 4", "grid / 2", "last")):
-        print("   %-12s " % wname + "  ".join("%s %.1f" % (names[i], (t[k, w, i] - t0) / 100.0) for i in range(7)))
+        print("   %-12s " % wname + "  ".join("%s %.1f" % (names[i], (t[k, w, i] - t0) / 100.0) for i in range(7)) +
+              ("  [first stage's requests served %.1f]" % ((t[k, w, 7] - t0) / 100.0) if t[k, w, 7] > 0 else ""))
