@@ -128,7 +128,7 @@ struct pb_ctx {
     // pass over 768-sample tiles takes what three rank-1 stencil passes take
     float poly_gain = 0.7f;
     int poly_min_area = 768;
-    long poly_min_pairs128 = 150;        // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels): 720p x 3 (180 pairs: 0.385 -> 0.325 ms per call) and up; 700 x 500 x 3 (72 pairs) is slower with them (0.256 -> 0.279)
+    long poly_min_pairs128 = 1;          // env PB_POLY_MIN_PAIRS128: 128 x 128 windows only for images of at least this many window pairs (at 90 x 90 tiles, all channels).  150 in round 4 (a 700 x 500 image was slower with them: 0.256 -> 0.279 ms); 1 since the one-pass class removed the other launches (round 5, same box: 700 x 500 0.242 -> 0.211 ms per call, 256 x 256 0.222 -> 0.192, 1080p gray 0.431 -> 0.319, 16 x 700 x 500 1.14 -> 0.72): every size is in the class
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
     int zero_ring_aside = 1;             // env PB_ZERO_RING_ASIDE: 0 = the ring steps of a zero-boundary polynomial all behind its window pass on the caller's stream

@@ -319,7 +319,10 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         } else {
             // border window: columns mapped through the boundary model once per lane, rows on the scalar side (one per half)
             const int ixa = map_axis(wxA + x, a.W, a.in_kind, a.boundary, a.pad);
-            const int ixb = hasB ? map_axis(wxB + x, a.W, a.in_kind, a.boundary, a.pad) : -1;
+            // (no window B: window A's samples again -- finite, never stored --, as the LDS-DMA loaders of fp32 planes have it: what the
+            // imaginary half holds reaches the real half's ROUNDING, and an 8-bit or fp16 image must get bit for bit what its float
+            // copy gets -- tests/test_gpu_parity.py::test_uint8_edge)
+            const int ixb = map_axis((hasB ? wxB : wxA) + x, a.W, a.in_kind, a.boundary, a.pad);
             const unsigned colA = ixa >= 0 ? (unsigned)ixa * (unsigned)sizeof(TIn) : kNoAccess;
             const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
             const bool wrap = a.boundary == PB_WRAP;
