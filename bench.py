@@ -426,7 +426,7 @@ def main():
                                     stencil_multiply_adds_per_sample_it_replaces=round(sum(macs) / len(macs), 1),
                                     note="")
             roofline["body"]["note"] = ("launches_per_polynomial counts every launch issued; under PolySpec.always (wrap boundary, no edgetaper, "
-                                        "images of 150 window pairs and more) a polynomial issues the 128x128 and the 64x64 window launch and nothing "
+                                        "the estimation's own kernels) a polynomial issues the 128x128 and the 64x64 window launch and nothing "
                                         "else -- the one whose images the other one has finds no work; context.end_to_end_three_step_form is the same "
                                         "call with PB_POLY1=0, context.end_to_end_dense_stencil_body through the 2-D stencil body")
             # ---- what the forms that ran HAVE to move through HBM (the physical fraction) -------------------------------------

@@ -74,7 +74,7 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //                               pb_options.half_temporaries -- always take the workgroup form, the only one built for them)
 //   PB_POLY1=0..3               one-pass polynomial: 0 never, 1 4-sample halo class only, 2 + 64 x 64 windows with the
 //                               composite's halos, 3 (default) + 128 x 128 windows
-//   PB_POLY_GAIN, PB_POLY_MIN_AREA, PB_POLY_COST128, PB_POLY_MIN_PAIRS128   cost model of the forms (common.h: 0.7, 768, 8, 150)
+//   PB_POLY_GAIN, PB_POLY_MIN_AREA, PB_POLY_COST128, PB_POLY_MIN_PAIRS128   cost model of the forms (common.h: 0.7, 768, 8, 1)
 //   PB_ZERO_RING_ASIDE=0        ... its first two ring steps behind the window pass instead of beside it (side stream)
 //   PB_ZERO_RING=0              method='direct' keeps three Horner steps over the whole image
 //   PB_POLY_PADDED=0            the polynomial after an edgetaper keeps three Horner steps

@@ -54,7 +54,8 @@ def _run(eng, x, **kw):
 @pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 1080, 1920), np.float32), ((1, 3, 736, 1290), np.float16),
                                          ((1, 1, 1600, 2000), np.float32)])
 def test_short_chain_and_two_launches_change_nothing(engines, shape, dtype):
-    """images of 150 window pairs and more (the class PolySpec.always covers): the default call, the call whose parameter
+    """the class PolySpec.always covers (every size since PB_POLY_MIN_PAIRS128 = 1; these are the sizes of its first form,
+    150 window pairs and more): the default call, the call whose parameter
     kernel forms the whole record first, and the call that issues every launch are bit-identical -- output, records
     (stencil parts included: the record workgroup forms them beside the short chain) and selections"""
     B, C, H, W = shape
@@ -138,7 +139,7 @@ def test_edgetaper_copies_and_one_pass(engines, shape, dtype):
     assert np.abs(a.astype(np.float32) - want).max() < tol
     for i, w in zip(ia, winfos):
         assert np.array_equal(np.asarray(i["theta"], np.float32).reshape(-1), np.asarray(w["theta"], np.float32).reshape(-1))
-    if H >= 720:                                                       # (150 window pairs and more: the one-pass class)
+    if H >= 720:                                                       # (asserted for the class's original sizes)
         s = engines["default"].body_selection(B, 1)
         assert (s[:, 0] == 1).all() and (s[:, 3] != 0).all(), s
 
@@ -165,7 +166,7 @@ def test_zero_boundary_ring(engines, shape, dtype, extra):
     assert e.max() < (2e-5 if dtype == np.float32 else 1e-3), (e.max(), np.unravel_index(e.argmax(), e.shape))
     for i, w in zip(ia, winfos):
         assert np.array_equal(np.asarray(i["theta"], np.float32).reshape(-1), np.asarray(w["theta"], np.float32).reshape(-1))
-    if not extra.get("edgetaping") and C == 3:                              # (150 window pairs and more: the class that takes one pass)
+    if not extra.get("edgetaping") and C == 3:                              # (asserted for the class's original sizes)
         s0 = engines["default"].body_selection(B, 0)
         assert (s0[:, 0] == 1).all() and (s0[:, 3] != 0).all(), s0       # the interior took a one-pass form
 

@@ -1,4 +1,4 @@
-"""Random sweep inside the host-known one-pass class (images of 150 window pairs and more: csrc/api.hip poly_spec): random sizes
+"""Random sweep inside the host-known one-pass class (its original sizes, 150 window pairs and more: csrc/api.hip poly_spec): random sizes
 of 0.5 - 2.5 MP x 3 channels, every option, both boundary models, fp32 / fp16, against the oracle.
 python tools/sweep_random_large.py [first last]"""
 import sys, numpy as np, torch
