@@ -76,6 +76,7 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //                               composite's halos, 3 (default) + 128 x 128 windows
 //   PB_POLY_GAIN, PB_POLY_MIN_AREA, PB_POLY_COST128, PB_POLY_MIN_PAIRS128   cost model of the forms (common.h: 0.7, 768, 8, 1)
 //   PB_ZERO_RING_ASIDE=0        ... its first two ring steps behind the window pass instead of beside it (side stream)
+//   PB_ZERO_RING_MIN_PAIRS=<n>  ... the ring form only for images of at least n three-step window pairs (4096)
 //   PB_ZERO_RING=0              method='direct' keeps three Horner steps over the whole image
 //   PB_POLY_PADDED=0            the polynomial after an edgetaper keeps three Horner steps
 //   PB_POLY_ALWAYS=0            never PolySpec.always (issue every launch the records might need)
@@ -103,7 +104,7 @@ static void pb_read_knobs(pb_ctx *ctx) {
     geti("PB_ROWS_NT", ctx->rows_nt); getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
     geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);
     getf("PB_POLY_COST128", ctx->poly_cost128); getl("PB_POLY_MIN_PAIRS128", ctx->poly_min_pairs128);
-    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); geti("PB_ZERO_RING", ctx->zero_ring); geti("PB_ZERO_RING_ASIDE", ctx->zero_ring_aside); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
+    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); geti("PB_ZERO_RING", ctx->zero_ring); getl("PB_ZERO_RING_MIN_PAIRS", ctx->zero_ring_min_pairs); geti("PB_ZERO_RING_ASIDE", ctx->zero_ring_aside); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
     geti("PB_MAIN_STREAM_BODY", ctx->main_stream_body);
 }
 
@@ -344,7 +345,16 @@ void make_steps(const Geometry &g, const void *xsrc, int x_dtype, const float *x
 // gaussians: the records are (or will be) point-symmetric Gaussians the estimation itself builds on an odd ker_size grid
 PolySpec poly_spec(pb_ctx *ctx, const ConvPass *steps, float alpha, float beta, bool gaussians) {
     const int mode = pb_poly_spec_mode(ctx, steps);
-    if (!mode) return no_poly();
+    if (!mode) {
+        // (the zero boundary on an image too small for the ring form, the estimation's own Gaussians: every kernel on three
+        // window steps -- a fact of the call again, so the polynomial issues the wave body's three launches and nothing else)
+        if (steps[0].boundary == PB_ZERO && gaussians && ctx->poly_always && pb_poly_three_steps_ok(ctx, steps)) {
+            PolySpec ps = no_poly();
+            ps.always = 2;
+            return ps;
+        }
+        return no_poly();
+    }
     // (128 x 128 windows need an image of some size: a workgroup takes ~38 us for its pair whatever the launch, and a 700 x 500
     // image yields 72 of them for 256 CUs -- 0.35 against 0.32 ms per call.  The rule looks at ONE image, not at the batch, so
     // that what an image gets does not depend on the batch it travels in; the threshold sits just below 1080p x 3 channels

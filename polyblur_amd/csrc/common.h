@@ -45,8 +45,9 @@ struct ProfRec {
 // on 128 x 128 windows (conv_w128.hip, pb_fft_sel.poly == 2) where THAT is cheapest -- cost128 = what a 128 x 128 window pair
 // costs in units of a 64 x 64 one (four waves, longer transforms).
 // gain, min_area: the cost model of mode 2 (khat.h).
-// always == 2 (with on == 0; pb_build_khat_ring): the kernel's own spectrum, and every point-symmetric kernel takes the
-// three-step window form whatever its phase count or rank (the ring steps of a zero-boundary polynomial have no other launch).
+// always == 2 (with on == 0): the kernel's own spectrum, and EVERY kernel takes the three-step window form whatever its phase
+// count or rank -- the ring steps of a zero-boundary polynomial (pb_build_khat_ring), and the whole polynomial of a
+// zero-boundary image too small for the ring form (api.hip: poly_spec): three launches of the wave body and nothing else.
 // always: EVERY image of the record set takes a one-pass form (64 x 64 or 128 x 128 windows, whichever the cost model prices
 // lower) -- the three-step and stencil forms are out of the model.  Asked for where the host can tell from (boundary,
 // options, image size, ker_size) alone that every composite fits a 128 x 128 window and every kernel is a point-symmetric
@@ -55,8 +56,8 @@ struct ProfRec {
 struct PolySpec { int on; float a3, a2, a1, b; float gain; int min_area; float cost128; int always; };
 inline PolySpec no_poly() { return PolySpec{0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0.f, 0}; }
 inline bool same_spec(const PolySpec &x, const PolySpec &y) {
-    return x.on == y.on && (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b && (x.cost128 > 0.f) == (y.cost128 > 0.f) &&
-                                      x.always == y.always));
+    return x.on == y.on && x.always == y.always &&
+           (!x.on || (x.a3 == y.a3 && x.a2 == y.a2 && x.a1 == y.a1 && x.b == y.b && (x.cost128 > 0.f) == (y.cost128 > 0.f)));
 }
 
 // rf = window halo class of the workgroup form (conv_fft.hip): 4, 8 or 12 -- 0 when only the wave form can run the image
@@ -132,6 +133,7 @@ struct pb_ctx {
     float poly_cost128 = 8.0f;           // env PB_POLY_COST128; <= 0: never 128 x 128 windows.  Measured at 4K: a 128 x 128 pair costs 6 - 6.5 pairs of
                                          // 64 x 64 with host-built records, and a launch of its own (~10 us) in the pipeline
     int zero_ring_aside = 1;             // env PB_ZERO_RING_ASIDE: 0 = the ring steps of a zero-boundary polynomial all behind its window pass on the caller's stream
+    long zero_ring_min_pairs = 4096;     // env PB_ZERO_RING_MIN_PAIRS: ... only for images of at least this many three-step window pairs (40 x 40 tiles, all channels: two rounds of the chip)
     int zero_ring = 1;                   // env PB_ZERO_RING: 0 = a polynomial under the zero boundary (method='direct') keeps three Horner steps over the whole image
     int poly_padded = 1;                 // env PB_POLY_PADDED: 0 = a polynomial whose operand is a padded plane (after an edgetaper) keeps three Horner steps
     int est_lean = 1;                    // env PB_EST_LEAN: 0 = the parameter kernel always forms the whole record before the spectra
@@ -262,6 +264,7 @@ int pb_launch_conv_w128(pb_ctx *ctx, const ConvPass &p);                     // 
 bool pb_conv_w128_feasible(const ConvPass &p);                               // ... and whether its worst-case job list fits the grid
 bool pb_conv_wfft_feasible(const ConvPass &p, bool poly2, int min_area);     // conv_wfft.hip: likewise for the wave form
 bool pb_conv_w128_types(int in_dtype, int out_dtype);                                  // ... whether it is built for the pass's types
+bool pb_poly_three_steps_ok(pb_ctx *ctx, const ConvPass *steps);             // conv.hip: the three steps can all take the wave form (PolySpec.always == 2)
 int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps);                   // conv.hip: the PolySpec.on a polynomial with these steps may ask for
 // kernels larger than the 25 x 25 record (conv_big.hip): their taps on the ker_size grid, and one Horner step with them
 int pb_build_big_taps(pb_ctx *ctx, const pb_blur_info *dev_info, int B, int ksize, int shift, const float **taps);

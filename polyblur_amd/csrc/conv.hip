@@ -425,8 +425,18 @@ int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
     if (ctx->poly_mode == 0 || ctx->fft_min_phases < 0) return 0;
     // (the zero boundary, method='direct': one window pass for the interior plus three ring steps -- pb_launch_conv_poly --
     // where PolySpec.always holds; the caller drops the spec otherwise)
+    // (... and only for images whose three-step pass is several rounds of window pairs: a ring step is one or two rounds of
+    // ~20 us whatever its area, so on a 1080p image -- 2100 pairs, one round per step -- window pass + ring is SLOWER than three
+    // plain steps: 0.583 against 0.504 ms per call, 720p 0.467 against 0.392; at 4K, 8085 pairs, 1.02 against 1.16.  The rule
+    // looks at one image, never at the batch: what an image gets must not depend on the batch it travels in)
+    bool zero_ok = ctx->zero_ring != 0;
+    if (zero_ok && steps[0].boundary == PB_ZERO) {
+        const int Hp = steps[0].H + 2 * steps[0].pad, Wp = steps[0].W + 2 * steps[0].pad;
+        const long pairs3 = (long)(((Wp + 39) / 40 + 1) / 2) * ((Hp + 39) / 40) * steps[0].C;
+        zero_ok = pairs3 >= ctx->zero_ring_min_pairs;
+    }
     for (int s = 0; s < 3; ++s)
-        if ((steps[s].boundary != PB_WRAP && !(steps[s].boundary == PB_ZERO && ctx->zero_ring)) || steps[s].boundary != steps[0].boundary ||
+        if ((steps[s].boundary != PB_WRAP && !(steps[s].boundary == PB_ZERO && zero_ok)) || steps[s].boundary != steps[0].boundary ||
             steps[s].epilogue != EPI_HORNER || !fft_pass_ok(steps[s])) return 0;
     // (after an edgetaper the polynomial's operand is the padded, tapered plane: the window loaders read padded planes like
     // virtual ones -- every Horner step but the first always did -- PB_POLY_PADDED=0: three steps there, as in rounds 3 - 4)
@@ -444,6 +454,15 @@ int pb_poly_spec_mode(pb_ctx *ctx, const ConvPass *steps) {
     if (wave) return (ctx->poly_mode >= 3 && ctx->poly_cost128 > 0.f && pb_conv_w128_types(pc.in_dtype, pc.out_dtype) &&
                       pb_conv_w128_feasible(pc)) ? 3 : 2;
     return (fold || pb_conv_fft_types(pc)) ? 1 : 0;
+}
+
+// Whether the three Horner steps of a polynomial can all go to the wave form of the tile-spectrum body (PolySpec.always == 2)
+bool pb_poly_three_steps_ok(pb_ctx *ctx, const ConvPass *steps) {
+    if (ctx->poly_mode == 0 || ctx->fft_min_phases < 0 || !ctx->fft_wave) return false;
+    for (int s = 0; s < 3; ++s)
+        if (steps[s].epilogue != EPI_HORNER || !fft_pass_ok(steps[s]) || !pb_conv_wfft_types(steps[s]) || !pb_conv_wfft_feasible(steps[s], false, ctx->poly_min_area))
+            return false;
+    return true;
 }
 
 // The three Horner steps of one polynomial.  Whether the tile-spectrum body may be used is decided ONCE, from all three
@@ -484,6 +503,19 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
     // type, the first step's launch takes them along (ConvPass.poly = 2: no launch of their own, nothing to pay when no
     // image qualifies); otherwise a composite launch does them.  (The spectra the steps meet are those ctx->poly_want
     // asks for: pb_build_khat rebuilds any others.)
+    // PolySpec.always == 2 (records of the estimation): every image on three window steps, three launches of the wave body
+    if (fft && !ctx->poly_want.on && ctx->poly_want.always == 2 && !have) {
+        float *k = nullptr; pb_fft_sel *sel = nullptr;
+        const bool built = ctx->khat_by_estimate && ctx->khat_owner == steps[0].info && ctx->khat_B == B;
+        int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, !built);
+        for (int s = 0; s < 3 && !rc; ++s) {
+            ConvPass p = steps[s];
+            p.khat = k; p.fsel = sel; p.poly = 0;
+            rc = pb_launch_conv_wfft(ctx, p);
+            if (rc == PB_ERR_UNSUPPORTED) rc = pb_fail(ctx, PB_ERR_UNSUPPORTED, "three window steps: the wave form does not take this pass");
+        }
+        return rc;
+    }
     const bool poly_on = fft && ctx->poly_want.on;
     const bool fold = poly_on && steps[0].out_dtype == steps[2].out_dtype;
     auto first_step = [&](ConvPass &p) {

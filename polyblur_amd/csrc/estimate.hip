@@ -1912,7 +1912,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
         if (rc) return rc;
     }
     // (PolySpec.always under full support: the short chain to the spectra, the record beside it -- see the kernel)
-    const int lean = (khat && ctx->poly_want.always && opt->support == PB_SUPPORT_FULL && ctx->est_lean) ? 1 : 0;
+    const int lean = (khat && ctx->poly_want.always == 1 && opt->support == PB_SUPPORT_FULL && ctx->est_lean) ? 1 : 0;
     ProfScope prof(ctx, PB_PROF_PARAMS);
     hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? (lean ? KH_SLICES_LEAN + 1 : KH_SLICES) : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, est_tiles, ksize,

@@ -221,7 +221,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     PB_PT(20);
     // (PolySpec.always: the host vouches for point-symmetric taps -- the estimation's own Gaussians -- and has no other launch
     // to fall back on; taps that compare unequal there are NaNs, which the one-pass form turns into the same zeros)
-    const bool symm = (__syncthreads_and(sym) || ps.always == 1) && min_phases >= 0;
+    const bool symm = (__syncthreads_and(sym) || ps.always != 0) && min_phases >= 0;
     // The window halo of the tile-spectrum body, per axis.  The spectrum below holds EVERY tap of the record's box; the halo
     // only has to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error
     // of at most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero

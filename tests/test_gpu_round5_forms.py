@@ -39,7 +39,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "direct_three_steps": _engine(PB_ZERO_RING=0)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -157,7 +157,7 @@ def test_zero_boundary_ring(engines, shape, dtype, extra):
     x = x.astype(dtype)
     from polyblur_amd import _capi as capi
     kw = dict(KW, n_iter=2, boundary=capi.PB_ZERO, **extra)
-    a, ia = _run(engines["default"], x, **kw)
+    a, ia = _run(engines["direct_ring"], x, **kw)                  # (the ring form at every size: by default only from 4096 three-step window pairs per image)
     b, ib = _run(engines["direct_three_steps"], x, **kw)
     d = np.abs(a.astype(np.float32) - b.astype(np.float32))
     assert d.max() < (5e-6 if dtype == np.float32 else 1e-3), (d.max(), np.unravel_index(d.argmax(), d.shape))
@@ -167,7 +167,7 @@ def test_zero_boundary_ring(engines, shape, dtype, extra):
     for i, w in zip(ia, winfos):
         assert np.array_equal(np.asarray(i["theta"], np.float32).reshape(-1), np.asarray(w["theta"], np.float32).reshape(-1))
     if not extra.get("edgetaping") and C == 3:                              # (asserted for the class's original sizes)
-        s0 = engines["default"].body_selection(B, 0)
+        s0 = engines["direct_ring"].body_selection(B, 0)
         assert (s0[:, 0] == 1).all() and (s0[:, 3] != 0).all(), s0       # the interior took a one-pass form
 
 
@@ -177,7 +177,9 @@ def test_zero_boundary_ring_strong_blur(engines):
     from polyblur_amd.synthetic import synthetic_blurry_image
     x = np.stack([synthetic_blurry_image(3, 900, 1300, 5, blur=(3.5, 2.5, 48.0))[0]])
     kw = dict(KW, n_iter=2, boundary=capi.PB_ZERO)
-    a, _ = _run(engines["default"], x, **kw)
+    a, _ = _run(engines["direct_ring"], x, **kw)
     b, _ = _run(engines["direct_three_steps"], x, **kw)
     assert np.abs(a - b).max() < 5e-6
     assert np.abs(a - ref.polyblur_deblurring(x, n_iter=2, method="direct", **KW)).max() < 2e-5
+    c, _ = _run(engines["default"], x, **kw)                           # (below the default threshold: three plain steps)
+    assert np.array_equal(c, b)
