@@ -261,6 +261,9 @@ struct Geometry {
     int big_ksize = 0;
     // the records are point-symmetric Gaussians the estimation of THIS call builds on an odd ker_size grid (PolySpec.always)
     bool est_gaussians = false;
+    // ... and every one of them takes the window form of a single pass (PolySpec.always == 2): the edgetaper's three blends
+    // issue the wave body's launch and nothing else
+    bool taper_windows = false;
 };
 
 Geometry geometry(int B, int C, int H, int W, int pad = PB_KRAD) {
@@ -307,6 +310,9 @@ int run_edgetaper(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype
     set_in_virtual(p, g, src, src_dtype);
     set_x_virtual(p, g, src, src_dtype);
     set_out_padded(p, g, pa);
+    // (the spec the estimation built these records' spectra under: every kernel on the window form, one launch per blend)
+    struct SpecScope { pb_ctx *c; ~SpecScope() { c->poly_want = no_poly(); } } scope{ctx};
+    if (g.taper_windows) { ctx->poly_want = no_poly(); ctx->poly_want.always = 2; }
     int rc = pb_launch_conv(ctx, p);
     if (rc) return rc;
     set_in_padded(p, g, pa); set_x_padded(p, g, pa); set_out_padded(p, g, pb);
@@ -678,6 +684,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     Geometry g = geometry(B, C, H, W, ksize / 2);
     const bool poly_eligible = (opt->boundary == PB_WRAP || ctx->zero_ring) && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
     g.est_gaussians = (ksize & 1) && ksize <= PB_KSIZE && !opt->separable_approx;
+    g.taper_windows = opt->edgetaping && g.est_gaussians && ctx->poly_always && ctx->poly_mode != 0 && ctx->fft_min_phases >= 0 && ctx->fft_wave;
     const long n = (long)g.P * g.HW;
     const int n_iter = opt->n_iter;
     if (n_iter == 0) {
@@ -767,6 +774,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
             make_steps(g, cur, src_dtype, nullptr, info, opt->alpha, opt->beta, opt->boundary, nullptr, nullptr, dst, last_out, 1, steps);
             ctx->poly_want = poly_spec(ctx, steps, opt->alpha, opt->beta, (ksize & 1) != 0);
         }
+        else if (g.taper_windows) { ctx->poly_want = no_poly(); ctx->poly_want.always = 2; }      // (the blends come first: the kernels' own spectra, window form for all)
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
         ctx->poly_want = no_poly();
         if (rc) return rc;

@@ -392,7 +392,10 @@ int pb_launch_conv(pb_ctx *ctx, const ConvPass &p0) {
 #else
     (void)strip;
 #endif
-    const bool tile_needed = !have || (strip_done ? kf->any_tile : kf->any_other);
+    // (PolySpec.always == 2, records of the estimation: every image takes the window form -- no stencil launch to find that out)
+    const bool windows_only = !have && fft && !ctx->poly_want.on && ctx->poly_want.always == 2 && ctx->fft_wave && pb_conv_wfft_types(p) &&
+                              pb_conv_wfft_feasible(p, false, ctx->poly_min_area);
+    const bool tile_needed = windows_only ? false : (!have || (strip_done ? kf->any_tile : kf->any_other));
     if (tile_needed) {
         const int rc = launch_stencil(ctx, p);
         if (rc) return rc;
