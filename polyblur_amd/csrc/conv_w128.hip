@@ -179,8 +179,12 @@ __device__ __forceinline__ W128Jobs jobs128_of(const W128Geom &g, int hx, int hy
 
 // One window pair, by the four waves of a workgroup.  Z: the workgroup's LDS matrix; kp: the image's spectrum,
 // [wave][register][lane] (khat128_body).  hx a multiple of 4, hy even; a tile is 128 - 2 hx by 128 - 2 hy outputs.
-template <typename TIn, typename TOut>
+// ZERO: the pass's boundary model is PB_ZERO (method='direct') -- a compile-time fact of the instantiation: the circular
+// domain's kernel is instruction for instruction what it was before the zero boundary's loaders existed (with the model a
+// run-time branch inside the loaders the rank-1 inner loop took 0.1026 ms against 0.0988 on the same box).
+template <typename TIn, typename TOut, bool ZERO>
 __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, int pxi, int hx, int hy, float2 *Z, const float *kp) {
+    constexpr int kBoundary = ZERO ? PB_ZERO : PB_WRAP;
     const int Tx = W_N - 2 * hx, Ty = W_N - 2 * hy;
     const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
     const bool upper = h != 0;
@@ -220,7 +224,8 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             const int pc = lane & 15;
             const unsigned colb = (unsigned)(((pc < 8 ? wxA : wxB - 32) - lo + 32 * w + 4 * pc) * 4);
             const unsigned vo = (unsigned)((lane >> 4) * pitchb) + colb;
-            const bool virt = a.in_kind == SRC_VIRTUAL, wrapb = a.boundary == PB_WRAP;
+            const bool virt = a.in_kind == SRC_VIRTUAL;
+            constexpr bool wrapb = !ZERO;
             auto request = [&](int k, int buf) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {     // LDS rows 4 j .. 4 j + 3 of the chunk: lane half j >> 2, its rows 16 k + 4 (j & 3) ..
@@ -229,10 +234,15 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
                         dma16<0>(rin, zl + buf * 8192 + j * 1024, vo, (p0 - lo) * pitchb);
                     } else {
                         int pr = p0 + (lane >> 4);
-                        if (wrapb) pr = pr < 0 ? pr + Hp : (pr >= Hp ? pr - Hp : pr);   // the circular domain (PB_WRAP) ...
-                        const bool ok = pr >= 0 && pr < Hp;                             // (PB_ZERO: zeros outside the padded domain)
-                        const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;   // ... of the replicate-padded plane
-                        dma16<0>(rin, zl + buf * 8192 + j * 1024, ok ? (unsigned)(row * pitchb) + colb : kNoAccess, 0);
+                        if (wrapb) {                                                    // the circular domain (PB_WRAP) ...
+                            pr = pr < 0 ? pr + Hp : (pr >= Hp ? pr - Hp : pr);
+                            const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;   // ... of the replicate-padded plane
+                            dma16<0>(rin, zl + buf * 8192 + j * 1024, (unsigned)(row * pitchb) + colb, 0);
+                        } else {                                                        // (PB_ZERO: zeros outside the padded domain; a branch of its own, the circular path pays nothing for it)
+                            const bool ok = pr >= 0 && pr < Hp;
+                            const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;
+                            dma16<0>(rin, zl + buf * 8192 + j * 1024, ok ? (unsigned)(row * pitchb) + colb : kNoAccess, 0);
+                        }
                     }
                 }
             };
@@ -241,16 +251,22 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             // (l < 32) or B through the boundary model, one LDS row of 256 bytes per wave instruction, its row mapped on the
             // scalar side; the chunk then looks exactly like one that arrived in 16-byte pieces.
             const int gx = (lane < 32 || hasB ? (lane < 32 ? wxA : wxB) : wxA) + 32 * w + (lane & 31);   // (no window B: A's samples again -- finite, never stored)
-            const int gix = map_axis(gx, a.W, a.in_kind, a.boundary, a.pad);
+            const int gix = map_axis(gx, a.W, a.in_kind, kBoundary, a.pad);
             const unsigned gcol = gix >= 0 ? (unsigned)(gix * (int)sizeof(TIn)) : kNoAccess;
             auto gather = [&](int k, int buf) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {    // LDS row i of the chunk: window row 16 k + i (i < 16) or 64 + 16 k + i - 16
                     int pr = wy0 + 16 * k + (i < 16 ? i : 48 + i);
-                    if (wrapb) { while (pr < 0) pr += Hp; while (pr >= Hp) pr -= Hp; }
-                    const bool ok = pr >= 0 && pr < Hp;
-                    const int row = ok ? (virt ? min(max(pr - a.pad, 0), a.H - 1) : pr) : 0;
-                    dma4<0>(rin, zl + buf * 8192 + i * 256, ok ? gcol : kNoAccess, row * pitchb);
+                    if (wrapb) {
+                        while (pr < 0) pr += Hp;
+                        while (pr >= Hp) pr -= Hp;
+                        const int row = virt ? min(max(pr - a.pad, 0), a.H - 1) : pr;
+                        dma4<0>(rin, zl + buf * 8192 + i * 256, gcol, row * pitchb);
+                    } else {
+                        const bool ok = pr >= 0 && pr < Hp;
+                        const int row = ok ? (virt ? min(max(pr - a.pad, 0), a.H - 1) : pr) : 0;
+                        dma4<0>(rin, zl + buf * 8192 + i * 256, ok ? gcol : kNoAccess, row * pitchb);
+                    }
                 }
             };
             // Both lanes of a pair read BOTH halves' rows of the chunk (LDS rows i and 16 + i of a buffer: 256 bytes each, A then
@@ -318,14 +334,14 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             r2_fwd(v, upper, sg);
         } else {
             // border window: columns mapped through the boundary model once per lane, rows on the scalar side (one per half)
-            const int ixa = map_axis(wxA + x, a.W, a.in_kind, a.boundary, a.pad);
+            const int ixa = map_axis(wxA + x, a.W, a.in_kind, kBoundary, a.pad);
             // (no window B: window A's samples again -- finite, never stored --, as the LDS-DMA loaders of fp32 planes have it: what the
             // imaginary half holds reaches the real half's ROUNDING, and an 8-bit or fp16 image must get bit for bit what its float
             // copy gets -- tests/test_gpu_parity.py::test_uint8_edge)
-            const int ixb = map_axis((hasB ? wxB : wxA) + x, a.W, a.in_kind, a.boundary, a.pad);
+            const int ixb = map_axis((hasB ? wxB : wxA) + x, a.W, a.in_kind, kBoundary, a.pad);
             const unsigned colA = ixa >= 0 ? (unsigned)ixa * (unsigned)sizeof(TIn) : kNoAccess;
             const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
-            const bool wrap = a.boundary == PB_WRAP;
+            constexpr bool wrap = !ZERO;
             const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(wy0, Hp)) : wy0;
             auto rowmap = [&](int p, bool &ok) -> int {
                 if (wrap) { while (p < 0) p += Hp; while (p >= Hp) p -= Hp; }
@@ -443,7 +459,7 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
 // b % 8 (the XCD it is observed to run on) at position b / 8, every list owns the same contiguous eighth of every plane's
 // pairs, images in order; the jobs are the window pairs of the images whose record says "one pass on 128 x 128 windows"
 // (pb_fft_sel.poly == 2), each with its own halos.
-template <typename TIn, typename TOut>
+template <typename TIn, typename TOut, bool ZERO>
 __global__ __launch_bounds__(256, 2) void conv_w128_kernel(const ConvPass a, const W128Geom g) {
     extern __shared__ __attribute__((aligned(16))) float2 Zw[];
     const int lane = threadIdx.x & 63;
@@ -486,12 +502,15 @@ __global__ __launch_bounds__(256, 2) void conv_w128_kernel(const ConvPass a, con
     const int pair = q * j.per + (rem - pl * j.per);
     if (pair >= j.njobs) return;
     const int ty = __builtin_amdgcn_readfirstlane(div_rcp128(pair, j.inv_pairs_x)), pxi = pair - ty * j.pairs_x;
-    w128_pair<TIn, TOut>(a, img * C + pl, ty, pxi, hx, hy, Zw, a.khat + (long)img * PB_KHAT_STRIDE);
+    w128_pair<TIn, TOut, ZERO>(a, img * C + pl, ty, pxi, hx, hy, Zw, a.khat + (long)img * PB_KHAT_STRIDE);
 }
 
 template <typename TIn, typename TOut>
 int launch_w128_typed(pb_ctx *ctx, const ConvPass &p, const W128Geom &g, long groups) {
-    hipLaunchKernelGGL((conv_w128_kernel<TIn, TOut>), dim3((unsigned)groups), dim3(256), kW128Lds, ctx->stream, p, g);
+    if (p.boundary == PB_ZERO)
+        hipLaunchKernelGGL((conv_w128_kernel<TIn, TOut, true>), dim3((unsigned)groups), dim3(256), kW128Lds, ctx->stream, p, g);
+    else
+        hipLaunchKernelGGL((conv_w128_kernel<TIn, TOut, false>), dim3((unsigned)groups), dim3(256), kW128Lds, ctx->stream, p, g);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

@@ -181,11 +181,18 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                         for (int i = 0; i < 16; ++i) {     // LDS row i of the chunk = register 8 (i >> 1) + 2 k + (i & 1)
                             const int r = 8 * (i >> 1) + 2 * k + (i & 1);
                             int pr = base + r - (r >= wrap_r ? FT_N : 0);
-                            if (wrapb) { while (pr < 0) pr += Hp; while (pr >= Hp) pr -= Hp; }
-                            const bool ok = pr >= 0 && pr < Hp;
-                            const int so = ok ? (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb : 0;
-                            dma4<0>(rin, zl + buf * 8192 + i * 512, ok ? gcolA : kNoAccess, so);
-                            dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, ok ? gcolB : kNoAccess, so);
+                            if (wrapb) {                      // (a branch of its own for each boundary model: the circular path pays nothing for the other)
+                                while (pr < 0) pr += Hp;
+                                while (pr >= Hp) pr -= Hp;
+                                const int so = (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb;
+                                dma4<0>(rin, zl + buf * 8192 + i * 512, gcolA, so);
+                                dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, gcolB, so);
+                            } else {
+                                const bool ok = pr >= 0 && pr < Hp;
+                                const int so = ok ? (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb : 0;
+                                dma4<0>(rin, zl + buf * 8192 + i * 512, ok ? gcolA : kNoAccess, so);
+                                dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, ok ? gcolB : kNoAccess, so);
+                            }
                         }
                     };
                     gather(0, 0); gather(1, 1);
@@ -267,11 +274,18 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                 for (int i = 0; i < 16; ++i) {     // LDS row i of the chunk = register 8 (i >> 1) + 2 k + (i & 1)
                     const int r = 8 * (i >> 1) + 2 * k + (i & 1);
                     int pr = base + r - (r >= wrap_r ? FT_N : 0);
-                    if (wrapb) { while (pr < 0) pr += Hp; while (pr >= Hp) pr -= Hp; }
-                    const bool ok = pr >= 0 && pr < Hp;
-                    const int so = ok ? (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb : 0;
-                    dma4<0>(rin, zl + buf * 8192 + i * 512, ok ? gcolA : kNoAccess, so);
-                    dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, ok ? gcolB : kNoAccess, so);
+                    if (wrapb) {
+                        while (pr < 0) pr += Hp;
+                        while (pr >= Hp) pr -= Hp;
+                        const int so = (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb;
+                        dma4<0>(rin, zl + buf * 8192 + i * 512, gcolA, so);
+                        dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, gcolB, so);
+                    } else {
+                        const bool ok = pr >= 0 && pr < Hp;
+                        const int so = ok ? (virt_in ? min(max(pr - a.pad, 0), a.H - 1) : pr) * pitchb : 0;
+                        dma4<0>(rin, zl + buf * 8192 + i * 512, ok ? gcolA : kNoAccess, so);
+                        dma4<0>(rin, zl + buf * 8192 + i * 512 + 256, ok ? gcolB : kNoAccess, so);
+                    }
                 }
             };
             const unsigned la = lds_addr(zb) + (unsigned)lane * 4u;
