@@ -87,9 +87,13 @@ __device__ unsigned long long g_wf_trace[kTraceWaves * kTraceStamps];
 // MODE 1: interior pairs on 16-byte boundaries (pair_is_fast); MODE 2: the same structure for the border pairs of the
 // circular domain (pair_is_gen: fp32 windows gathered through the boundary model, tiles cut by the region's end, an x
 // operand that needs the replicate clamp); MODE 0: everything else, sample by sample.
-template <int MODE, typename TIn, typename TX, typename TOut>
+// ZERO: the pass's boundary model is PB_ZERO -- a compile-time fact of the instantiation, as in conv_w128.hip: with the model a
+// run-time branch inside the loaders every pass of the circular domain was 3 - 5 % slower (same box: three steps 0.2442 ->
+// 0.2525 ms, one pass on 64 x 64 windows 0.0774 -> 0.0815).
+template <int MODE, typename TIn, typename TX, typename TOut, bool ZERO>
 __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info *info, int plane, int ty, int pxi, int hx, int hy,
                                           char *zb, const float *kp, unsigned long long *tr) {
+    constexpr int kBoundary = ZERO ? PB_ZERO : PB_WRAP;
     constexpr bool FAST = MODE != 0, GEN = MODE == 2;
     const int Tx = FT_N - 2 * hx, Ty = FT_N - 2 * hy;
     PB_T(1);
@@ -170,9 +174,9 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
                     // that touch no register, then the same LDS reads.
                     // (the zero boundary: a column or a row outside the padded domain is an out-of-range offset -- the request
                     // returns zeros, the bounds check being on the lane's offset)
-                    const bool wrapb = a.boundary == PB_WRAP;
-                    const int mxa = map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad);
-                    const int mxb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad);   // (no window B: A's samples again -- finite, never stored)
+                    constexpr bool wrapb = !ZERO;
+                    const int mxa = map_axis(wxA + lane, a.W, a.in_kind, kBoundary, a.pad);
+                    const int mxb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, kBoundary, a.pad);   // (no window B: A's samples again -- finite, never stored)
                     const unsigned gcolA = mxa >= 0 ? (unsigned)mxa * 4u : kNoAccess, gcolB = mxb >= 0 ? (unsigned)mxb * 4u : kNoAccess;
                     const int base = wrapb ? __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp)) : oy0;
                     const bool virt_in = a.in_kind == SRC_VIRTUAL;
@@ -263,9 +267,9 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
             // register, then the loader's own LDS reads (sample by sample into the registers this took 128 loads per lane
             // and made the border pairs -- 8 % of the pairs at 4K, 15 % at 1080p -- the stragglers of every launch).
             lds_char *zl = lds_ptr(zb);
-            const bool wrapb = a.boundary == PB_WRAP;
-            const int mxa = map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad);
-            const int mxb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad);   // (no window B: A's samples again -- finite, never stored)
+            constexpr bool wrapb = !ZERO;
+            const int mxa = map_axis(wxA + lane, a.W, a.in_kind, kBoundary, a.pad);
+            const int mxb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, kBoundary, a.pad);   // (no window B: A's samples again -- finite, never stored)
             const unsigned gcolA = mxa >= 0 ? (unsigned)mxa * 4u : kNoAccess, gcolB = mxb >= 0 ? (unsigned)mxb * 4u : kNoAccess;
             const int base = wrapb ? __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp)) : oy0;
             const bool virt_in = a.in_kind == SRC_VIRTUAL;
@@ -321,14 +325,14 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
             }
         } else {
             // border window: columns mapped through the boundary model once per lane, rows on the scalar side
-            const int ixa = map_axis(wxA + lane, a.W, a.in_kind, a.boundary, a.pad);
+            const int ixa = map_axis(wxA + lane, a.W, a.in_kind, kBoundary, a.pad);
             // (no window B: window A's samples again -- finite, never stored --, as the LDS-DMA loaders of fp32 planes have it: what the
             // imaginary half holds reaches the real half's ROUNDING, and an 8-bit or fp16 image must get bit for bit what its float
             // copy gets -- tests/test_gpu_parity.py::test_uint8_edge)
-            const int ixb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, a.boundary, a.pad);
+            const int ixb = map_axis((hasB ? wxB : wxA) + lane, a.W, a.in_kind, kBoundary, a.pad);
             const unsigned colA = ixa >= 0 ? (unsigned)ixa * (unsigned)sizeof(TIn) : kNoAccess;
             const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
-            const bool wrap = a.boundary == PB_WRAP;
+            constexpr bool wrap = !ZERO;
             const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp)) : oy0;
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
@@ -694,7 +698,7 @@ __device__ __forceinline__ bool ring_live(const ConvPass &a, int ty, int pxi, in
 // the single launch takes exactly what the three launches take; three waves per SIMD instead of two -- 168 registers, the
 // spectrum streamed, a 16-row transpose tile: 119 us per 4K pass against 85, nothing can be requested far enough ahead.
 // NOTEBOOK.md has the records.)
-template <typename TIn, typename TX, typename TOut>
+template <typename TIn, typename TX, typename TOut, bool ZERO>
 __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, const WGeom g) {
     extern __shared__ __attribute__((aligned(16))) char zb[];
     const int lane = threadIdx.x & 63;
@@ -754,9 +758,9 @@ __global__ __launch_bounds__(64, 2) void conv_wfft_kernel(const ConvPass a, cons
     if (a.ring && !ring_live(a, ty, pxi, hx, hy)) return;
     const ConvPass af = fold_pass(a, fold);
     if (taper_is_copy(af, ty, pxi, hx, hy)) { copy_pair<TX, TOut>(af, plane, ty, pxi, hx, hy); return; }
-    if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<1, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
-    else if (pair_is_gen<TIn, TX, TOut>(af, pxi, hx)) wave_pair<2, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
-    else wave_pair<0, TIn, TX, TOut>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
+    if (pair_is_fast<TIn, TX, TOut>(af, ty, pxi, hx, hy)) wave_pair<1, TIn, TX, TOut, ZERO>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
+    else if (pair_is_gen<TIn, TX, TOut>(af, pxi, hx)) wave_pair<2, TIn, TX, TOut, ZERO>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
+    else wave_pair<0, TIn, TX, TOut, ZERO>(af, info, plane, ty, pxi, hx, hy, zb, kp, tr);
 }
 
 // The output extent of a pass and the largest job list its records may ask for: `poly2` = the records may carry one-pass
@@ -785,7 +789,10 @@ bool wfft_geometry(const ConvPass &p, bool poly2, float min_area, WGeom &g, long
 
 template <typename TIn, typename TX, typename TOut>
 int launch_wfft_typed(pb_ctx *ctx, const ConvPass &p, const WGeom &g, long groups) {
-    hipLaunchKernelGGL((conv_wfft_kernel<TIn, TX, TOut>), dim3((unsigned)groups), dim3(64), kWfLdsWave, ctx->stream, p, g);
+    if (p.boundary == PB_ZERO)
+        hipLaunchKernelGGL((conv_wfft_kernel<TIn, TX, TOut, true>), dim3((unsigned)groups), dim3(64), kWfLdsWave, ctx->stream, p, g);
+    else
+        hipLaunchKernelGGL((conv_wfft_kernel<TIn, TX, TOut, false>), dim3((unsigned)groups), dim3(64), kWfLdsWave, ctx->stream, p, g);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
