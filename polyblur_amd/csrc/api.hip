@@ -78,6 +78,7 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //   PB_ZERO_RING_ASIDE=0        ... its first two ring steps behind the window pass instead of beside it (side stream)
 //   PB_ZERO_RING_MIN_PAIRS=<n>  ... the ring form only for images of at least n three-step window pairs (4096)
 //   PB_ZERO_RING=0              method='direct' keeps three Horner steps over the whole image
+//   PB_TAPER_RING=0             the second and third blend of an edgetaper over the whole plane, not over the border ring
 //   PB_POLY_PADDED=0            the polynomial after an edgetaper keeps three Horner steps
 //   PB_POLY_ALWAYS=0            never PolySpec.always (issue every launch the records might need)
 //   PB_SIDE_STREAM=0, PB_SIDE_MIN_TILES=<n>, PB_MAIN_STREAM_BODY=0|1   the side stream of launches that may find no work
@@ -104,7 +105,7 @@ static void pb_read_knobs(pb_ctx *ctx) {
     geti("PB_ROWS_NT", ctx->rows_nt); getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
     geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);
     getf("PB_POLY_COST128", ctx->poly_cost128); getl("PB_POLY_MIN_PAIRS128", ctx->poly_min_pairs128);
-    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); geti("PB_ZERO_RING", ctx->zero_ring); getl("PB_ZERO_RING_MIN_PAIRS", ctx->zero_ring_min_pairs); geti("PB_ZERO_RING_ASIDE", ctx->zero_ring_aside); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
+    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); geti("PB_TAPER_RING", ctx->taper_ring); geti("PB_ZERO_RING", ctx->zero_ring); getl("PB_ZERO_RING_MIN_PAIRS", ctx->zero_ring_min_pairs); geti("PB_ZERO_RING_ASIDE", ctx->zero_ring_aside); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
     geti("PB_MAIN_STREAM_BODY", ctx->main_stream_body);
 }
 
@@ -315,10 +316,16 @@ int run_edgetaper(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype
     if (g.taper_windows) { ctx->poly_want = no_poly(); ctx->poly_want.always = 2; }
     int rc = pb_launch_conv(ctx, p);
     if (rc) return rc;
+    // (window form for every image: the second and the third blend only touch the ring of window pairs on which alpha < 1
+    // can reach them -- the rest of `pa` keeps the first blend's copy of the image, which is what three blends with alpha = 1
+    // leave there; `pb` is only ever read inside the second blend's ring)
+    const int ring2 = g.taper_windows && ctx->taper_ring ? 5 : 0, ring3 = g.taper_windows && ctx->taper_ring ? 4 : 0;
     set_in_padded(p, g, pa); set_x_padded(p, g, pa); set_out_padded(p, g, pb);
+    p.ring = ring2;
     rc = pb_launch_conv(ctx, p);
     if (rc) return rc;
     set_in_padded(p, g, pb); set_x_padded(p, g, pb); set_out_padded(p, g, pa);
+    p.ring = ring3;
     rc = pb_launch_conv(ctx, p);
     *result = pa;
     return rc;

@@ -135,6 +135,7 @@ struct pb_ctx {
     int zero_ring_aside = 1;             // env PB_ZERO_RING_ASIDE: 0 = the ring steps of a zero-boundary polynomial all behind its window pass on the caller's stream
     long zero_ring_min_pairs = 4096;     // env PB_ZERO_RING_MIN_PAIRS: ... only for images of at least this many three-step window pairs (40 x 40 tiles, all channels: two rounds of the chip)
     int zero_ring = 1;                   // env PB_ZERO_RING: 0 = a polynomial under the zero boundary (method='direct') keeps three Horner steps over the whole image
+    int taper_ring = 1;                  // env PB_TAPER_RING: 0 = every blend of an edgetaper covers the whole padded plane
     int poly_padded = 1;                 // env PB_POLY_PADDED: 0 = a polynomial whose operand is a padded plane (after an edgetaper) keeps three Horner steps
     int est_lean = 1;                    // env PB_EST_LEAN: 0 = the parameter kernel always forms the whole record before the spectra
     int dt_rows_reg = 1;                 // env PB_DT_ROWS_REG: 0 = the domain-transform row pass always through global memory (dt_rows_fused_kernel)
@@ -240,7 +241,8 @@ struct ConvPass {
                          // composite pass, written to out2 with scale 1, coef 0 and clamp2 (same output type as `out`)
     void *out2;  int out2_kind;  int out2_pitch;  long out2_plane;  int clamp2;
     int no_fft;          // this pass keeps the stencil bodies (pb_launch_conv_poly: some step of the polynomial does not suit the other)
-    int ring;            // 0: every tile.  1 / 2 / 3: Horner step 1 / 2 / 3 of the BORDER RING of a zero-boundary polynomial whose interior
+    int ring;            // 0: every tile.  4 / 5: the third / second blend of an edgetaper over the ring its weights differ from 1 on (api.hip:
+                         // run_edgetaper).  1 / 2 / 3: Horner step 1 / 2 / 3 of the BORDER RING of a zero-boundary polynomial whose interior
                          // one window pass has done (pb_launch_conv_poly): only the window pairs the frame of outputs within 24 samples of
                          // the padded border depends on (conv_wfft.hip: ring_live)
 };

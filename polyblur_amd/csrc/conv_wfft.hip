@@ -533,10 +533,14 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
     const unsigned xoffB = okB && usex ? (unsigned)min(max(pxB - xsh, 0), xmax) * (unsigned)sizeof(TX) : kNoAccess;
     const unsigned ooffA = okA ? (unsigned)(pxA - oo) * (unsigned)sizeof(TOut) : kNoAccess;
     const unsigned ooffB = okB ? (unsigned)(pxB - oo) * (unsigned)sizeof(TOut) : kNoAccess;
-    float txa = 0.f, txb = 0.f;
+    float txa = 0.f, txb = 0.f, tyl = 0.f;
     if (taper) {
         txa = taper_weight(info->acorr_x, min(max(pxA, 0), Wp - 1), Wp);
         txb = taper_weight(info->acorr_x, min(max(pxB, 0), Wp - 1), Wp);
+        // the rows' weights: lane y holds tile row y's, read back with a constant lane number below (one weight per row through
+        // the scalar unit was two dependent scalar loads in front of each of the tile's 64 rows: the blends' border pairs --
+        // all the pairs a blend has left -- took ~60 us at 4K)
+        tyl = taper_weight(info->acorr_y, min(oy0 + lane, Hp - 1), Hp);
     }
     // Border pairs, the taper blend, narrower types: the last transform's second stage finishes the registers 8 n1 + n2
     // group by group (n2 = 0 .. 7); each group's rows go through the epilogue and to memory at once, and the x operand
@@ -564,7 +568,7 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
             const bool rok = y < tyv;
             float ra, rb;
             if (taper) {
-                const float tyw = taper_weight(info->acorr_y, min(py, Hp - 1), Hp);
+                const float tyw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tyl), y));
                 const float ala = tyw * txa, alb = tyw * txb;
                 ra = ala * xa[n2][n1] + (1.f - ala) * v[y].x; rb = alb * xb[n2][n1] + (1.f - alb) * v[y].y;
             } else {
@@ -682,6 +686,13 @@ __device__ __forceinline__ bool ring_live(const ConvPass &a, int ty, int pxi, in
     const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
     const int y0 = rg.y_lo + ty * Ty, y1 = min(y0 + Ty, rg.y_hi), x0 = rg.x_lo + 2 * pxi * Tx, x1 = min(x0 + 2 * Tx, rg.x_hi);
     const int dy = min(y0, Hp - y1), dx = min(x0, Wp - x1);
+    if (a.ring >= 4) {
+        // the second (ring 5) and third (ring 4) blend of an edgetaper (edgetaper.py:26-33): alpha < 1 only within 24 samples of
+        // the padded border, so the third blend computes the pairs that come within 25 of it -- everything else of its output
+        // plane still holds the first blend's copy of the image -- and the second the pairs those read, 12 further
+        const int mt = a.ring - 4;
+        return dy < 25 + 12 * mt + mt * Ty || dx < 25 + 12 * mt + 2 * mt * Tx;
+    }
     const int m = 3 - a.ring;                                    // 0 for step 3, 1 for step 2, 2 for step 1
     return dy < 24 + 12 * m + m * Ty || dx < 24 + 12 * m + 2 * m * Tx;
 }

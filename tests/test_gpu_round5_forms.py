@@ -39,7 +39,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -133,6 +133,8 @@ def test_edgetaper_copies_and_one_pass(engines, shape, dtype):
     kw = dict(KW, n_iter=2, edgetaping=True)
     a, ia = _run(engines["default"], x, **kw)
     b, ib = _run(engines["taper_three_steps"], x, **kw)
+    c, _ = _run(engines["taper_full_blends"], x, **kw)              # (the second and third blend over the whole plane: the same bits)
+    assert np.array_equal(a, c)
     tol = 2e-5 if dtype == np.float32 else 1e-3
     assert np.abs(a.astype(np.float32) - b.astype(np.float32)).max() < (5e-6 if dtype == np.float32 else 1e-3)
     want, winfos = ref.polyblur_deblurring(x.astype(np.float32), return_info=True, **kw)
