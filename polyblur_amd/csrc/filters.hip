@@ -392,11 +392,21 @@ __global__ __launch_bounds__(NT) void dt_rows_reg_kernel(const TIN *in, float *F
     float *f = F + off;
     const int nch = (W + 63) >> 6;
     float x[NCH][C], v[NCH];
+    // (addresses clamped into the row, not loads under a lane mask: a masked fp16 load is followed by its conversion inside
+    //  the masked block and by a wait for it, which put the 96 loads of a 1080p row one after the other -- 1.55 ms on
+    //  64 x 1080p fp16 against 0.77 ms for the same row in fp32, profiles/r05_bench_cfg3_kernel_stats.csv)
+    TIN raw[NCH][C];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ic = min(64 * k + lane, W - 1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) raw[k][c] = x0[c * HW + ic];
+    }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int i = 64 * k + lane;
 #pragma unroll
-        for (int c = 0; c < C; ++c) x[k][c] = (k < nch && i < W) ? pb_ld(x0 + c * HW + i) : 0.f;
+        for (int c = 0; c < C; ++c) x[k][c] = (i < W) ? pb_ld(&raw[k][c]) : 0.f;
     }
     // ---- left -> right
     float carry[C], last[C];
