@@ -295,7 +295,9 @@ template <> __device__ __forceinline__ float pb_ld<__half>(const __half *p) { re
 // 8-bit pixels: img_as_float32 on load, img_as_ubyte on store (skimage 0.19.2 util/dtype.py _convert)
 __device__ __forceinline__ float pb_from_ubyte(unsigned u) {
     float r = (float)u * (1.0f / 255.0f);
-    asm volatile("" : "+v"(r));          // keeps the product from being contracted into a neighbouring FMA
+    asm("" : "+v"(r));                   // keeps the product from being contracted into a neighbouring FMA (not volatile:
+                                         // volatile statements keep their order, and with it the loads that feed them one
+                                         // behind the other -- 128 byte loads of a window column, each waited for)
     return r;
 }
 template <> __device__ __forceinline__ float pb_ld<unsigned char>(const unsigned char *p) { return pb_from_ubyte(*p); }

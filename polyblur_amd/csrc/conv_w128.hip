@@ -343,21 +343,30 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
             constexpr bool wrap = !ZERO;
             const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(wy0, Hp)) : wy0;
-            auto rowmap = [&](int p, bool &ok) -> int {
-                if (wrap) { while (p < 0) p += Hp; while (p >= Hp) p -= Hp; }
-                ok = wrap || (p >= 0 && p < Hp);
-                return ok ? (a.in_kind == SRC_VIRTUAL ? min(max(p - a.pad, 0), a.H - 1) : p) : 0;
-            };
+            // (planes at least a window tall: one conditional step brings a row into the circular domain -- straight-line code,
+            // the 128 loads in flight together; the loops of a shorter plane end a basic block per row, and every pair of loads
+            // is then waited for before the next is issued)
+            auto rows = [&](auto tall) {
+                auto rowmap = [&](int p, bool &ok) -> int {
+                    if (wrap) {
+                        if (decltype(tall)::value) p -= p >= Hp ? Hp : 0;           // (base in [0, Hp), 0 <= r < 128)
+                        else { while (p < 0) p += Hp; while (p >= Hp) p -= Hp; }
+                    }
+                    ok = wrap || (p >= 0 && p < Hp);
+                    return ok ? (a.in_kind == SRC_VIRTUAL ? min(max(p - a.pad, 0), a.H - 1) : p) : 0;
+                };
 #pragma unroll
-            for (int q = 0; q < 64; ++q) {
-                const int r = 8 * (q & 7) + (q >> 3);
-                bool ok0, ok1;
-                const int i0 = rowmap(base + r, ok0), i1 = rowmap(base + 64 + r, ok1);
-                const bool ok = upper ? ok1 : ok0;
-                const unsigned ro_ = (unsigned)((upper ? i1 : i0) * pitchb);
-                v[r] = (cf){BufIO<TIn>::ld(rin, ok && colA != kNoAccess ? colA + ro_ : kNoAccess, 0),
-                            BufIO<TIn>::ld(rin, ok && colB != kNoAccess ? colB + ro_ : kNoAccess, 0)};
-            }
+                for (int q = 0; q < 64; ++q) {
+                    const int r = 8 * (q & 7) + (q >> 3);
+                    bool ok0, ok1;
+                    const int i0 = rowmap(base + r, ok0), i1 = rowmap(base + 64 + r, ok1);
+                    const bool ok = upper ? ok1 : ok0;
+                    const unsigned ro_ = (unsigned)((upper ? i1 : i0) * pitchb);
+                    v[r] = (cf){BufIO<TIn>::ld(rin, ok && colA != kNoAccess ? colA + ro_ : kNoAccess, 0),
+                                BufIO<TIn>::ld(rin, ok && colB != kNoAccess ? colB + ro_ : kNoAccess, 0)};
+                }
+            };
+            if (Hp >= W_N) rows(std::true_type()); else rows(std::false_type());
             r2_fwd(v, upper, sg);
         }
     }

@@ -334,16 +334,25 @@ __device__ __forceinline__ void wave_pair(const ConvPass &a, const pb_blur_info 
             const unsigned colB = ixb >= 0 ? (unsigned)ixb * (unsigned)sizeof(TIn) : kNoAccess;
             constexpr bool wrap = !ZERO;
             const int base = wrap ? __builtin_amdgcn_readfirstlane(wrap_idx(oy0, Hp)) : oy0;
+            // (planes at least a window tall: one conditional step brings a row into the circular domain -- straight-line code,
+            // the 128 loads in flight together; the loops of a shorter plane end a basic block per row, and every pair of loads
+            // is then waited for before the next is issued)
+            auto rows = [&](auto tall) {
 #pragma unroll
-            for (int q = 0; q < 64; ++q) {
-                const int y = 8 * (q & 7) + (q >> 3);
-                int p = base + y - (y >= wrap_r ? FT_N : 0);
-                if (wrap) { while (p < 0) p += Hp; while (p >= Hp) p -= Hp; }
-                const bool ok = wrap || (p >= 0 && p < Hp);
-                const int iy = ok ? (a.in_kind == SRC_VIRTUAL ? min(max(p - a.pad, 0), a.H - 1) : p) : 0;
-                const int so = iy * pitchb;
-                v[y] = (cf){BufIO<TIn>::ld(rin, ok ? colA : kNoAccess, so), BufIO<TIn>::ld(rin, ok ? colB : kNoAccess, so)};
-            }
+                for (int q = 0; q < 64; ++q) {
+                    const int y = 8 * (q & 7) + (q >> 3);
+                    int p = base + y - (y >= wrap_r ? FT_N : 0);
+                    if (wrap) {
+                        if (decltype(tall)::value) { p += p < 0 ? Hp : 0; p -= p >= Hp ? Hp : 0; }
+                        else { while (p < 0) p += Hp; while (p >= Hp) p -= Hp; }
+                    }
+                    const bool ok = wrap || (p >= 0 && p < Hp);
+                    const int iy = ok ? (a.in_kind == SRC_VIRTUAL ? min(max(p - a.pad, 0), a.H - 1) : p) : 0;
+                    const int so = iy * pitchb;
+                    v[y] = (cf){BufIO<TIn>::ld(rin, ok ? colA : kNoAccess, so), BufIO<TIn>::ld(rin, ok ? colB : kNoAccess, so)};
+                }
+            };
+            if (Hp >= FT_N) rows(std::true_type()); else rows(std::false_type());
         }
     }
     PB_T(2);
