@@ -144,6 +144,7 @@ struct pb_ctx {
     int main_stream_body = -1;           // env PB_MAIN_STREAM_BODY: which launch stays on the caller's stream when the others go to the side stream (0 = wave body, 1 = 128 x 128; -1 = by spec)
     int est_gray_rows = 1;               // env PB_EST_GRAY_ROWS: 1 = gray + range + row transform in one launch where measured faster (fp32 planes, lines of up to 4096 samples), 2 = for any line held in LDS, 0 = never
     int fft_ext_radix = 1;               // env PB_FFT_EXT_RADIX: 0 = greedy plans only (radices up to 16)
+    int fft_first = -1;                  // env PB_FFT_FIRST: the radix of the column transform's first / last stage where the plan holds it; 0 = the plan's own order; -1 = chosen by trips (launch_cols)
     // tuning / comparison knobs of single kernels, read once in pb_create (the table of every knob: api.hip, pb_read_knobs)
     long wave_min_jobs = 0;              // env PB_WAVE_MIN_JOBS: three-step passes of fewer window pairs than this go to the workgroup form of the tile-spectrum body
     int fft_lognb = -1;                  // env PB_FFT_LOGNB: log2 of the complex lines per column workgroup (-1: by LDS size)
@@ -179,7 +180,7 @@ struct ProfScope {
     }
 };
 void *pb_scratch(pb_ctx *ctx, const char *name, size_t bytes);   // nullptr on failure (error set)
-const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices = false);   // ext_radices: the caller's kernel holds radices 18 / 20 / 24
+const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices = false, int first = 0);   // ext_radices: the caller's kernel holds radices 18 / 20 / 24; first: the radix (one of the plan's) of the stages that talk to global memory, 0 = the plan's own order
 const float *pb_get_interp_weights(pb_ctx *ctx, int n_angles, int n_interp);
 
 #define PB_HIP(call)                                                                          \

@@ -148,8 +148,9 @@ extern "C" int pb_fft_length_supported(int n) {
     return core * (long)sizeof(float2) <= 160 * 1024 ? 1 : 2;
 }
 
-const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices) {
-    const int key = ext_radices ? -n : n;                 // (two plans per length: the kernel variants without the radices above 16 take the greedy one)
+const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices, int first) {
+    // (two plans per length: the kernel variants without the radices above 16 take the greedy one; and one per first radix asked for)
+    const int key = (ext_radices ? -1 : 1) * (n + (first << 17));
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) return &it->second;
     FftPlan pl;
@@ -164,6 +165,10 @@ const FftPlan *pb_get_plan(pb_ctx *ctx, int n, bool ext_radices) {
         while (core < 2 * n - 1) core *= 2;
         pl.bluestein_m = core;
         factorize(core, radix, rest);
+    }
+    if (first > 0 && !pl.bluestein_m) {
+        auto it = std::find(radix.begin(), radix.end(), first);
+        if (it != radix.end()) std::rotate(radix.begin(), it, it + 1);
     }
     if ((int)radix.size() > 24) { pb_fail(ctx, PB_ERR_UNSUPPORTED, "fft length %d: too many stages", n); return nullptr; }
     pl.nstage = (int)radix.size();
@@ -1677,6 +1682,26 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     const int lognb = pick_lognb(ctx, pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt);
     const size_t lds = fft_lds_bytes(pl, 1 << lognb);
     const bool through_memory = fft_lds_bytes(pl, 1) > kMaxLds;
+    // Which of the plan's radices the first and the last stage take -- the two that talk to global memory.  A stage of radix r
+    // is (H / r) << lognb butterflies over the workgroup's threads, trip after trip, and every trip of these two stages is a
+    // round trip to memory plus r loads and a radix-r butterfly per thread: 2160 = 16 x 15 x 9 in tiles of 16 columns is 1080
+    // butterflies of radix 16 for 1024 threads -- a second trip for 56 of them -- or 1920 of radix 9, two full trips of a
+    // smaller butterfly (4K: 48.5 -> 43.3 us per launch; 15 first: 45.2).  Taken where the model says 15 % or more.
+    if (!through_memory && !pl->bluestein_m && pl->nstage >= 2) {
+        const int threads = ext ? 1024 : (nt == 512 && (mode == 0 || n_angles == 6)) ? 1024 : (mode == 1 && n_angles == 6) ? 512 : NT;
+        auto cost = [&](int r) { const long items = (long)(H / r) << lognb; return (double)((items + threads - 1) / threads) * (8 + r); };
+        int first = pl->radix[0];
+        if (ctx->fft_first > 0) first = ctx->fft_first;
+        else if (ctx->fft_first < 0) {
+            double best = 0.85 * cost(first);
+            for (int i = 1; i < pl->nstage; ++i)
+                if (pl->radix[i] <= 16 && cost(pl->radix[i]) < best) { best = cost(pl->radix[i]); first = pl->radix[i]; }
+        }
+        if (first != pl->radix[0]) {
+            pl = pb_get_plan(ctx, H, ext_variant, first);
+            if (!pl) return PB_ERR_NOMEM;
+        }
+    }
     if (through_memory && !pb_fft_length_supported(H))
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image height %d: lines of up to %d samples are supported", H, kMaxLineLength);
     const int tc = 2 << lognb;
