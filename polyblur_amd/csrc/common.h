@@ -144,6 +144,7 @@ struct pb_ctx {
     int main_stream_body = -1;           // env PB_MAIN_STREAM_BODY: which launch stays on the caller's stream when the others go to the side stream (0 = wave body, 1 = 128 x 128; -1 = by spec)
     int est_gray_rows = 1;               // env PB_EST_GRAY_ROWS: 1 = gray + range + row transform in one launch where measured faster (fp32 planes, lines of up to 4096 samples), 2 = for any line held in LDS, 0 = never
     int fft_ext_radix = 1;               // env PB_FFT_EXT_RADIX: 0 = greedy plans only (radices up to 16)
+    int fft_first_rows = -1;             // env PB_FFT_FIRST_ROWS: the same for the row transforms (rows_plan)
     int fft_first = -1;                  // env PB_FFT_FIRST: the radix of the column transform's first / last stage where the plan holds it; 0 = the plan's own order; -1 = chosen by trips (launch_cols)
     // tuning / comparison knobs of single kernels, read once in pb_create (the table of every knob: api.hip, pb_read_knobs)
     long wave_min_jobs = 0;              // env PB_WAVE_MIN_JOBS: three-step passes of fewer window pairs than this go to the workgroup form of the tile-spectrum body

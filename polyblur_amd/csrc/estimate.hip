@@ -1582,12 +1582,45 @@ __global__ __launch_bounds__(NT) void dir_maxima_kernel(const float *__restrict_
 
 #endif
 
+// How many threads the row kernels run a line pair with (launch_rows and launch_gray_rows; the comments there).
+static int rows_threads(pb_ctx *ctx, const FftPlan *pl, size_t lds, long blocks) {
+    const int force_nt = ctx->rows_nt;
+    const bool one_round = blocks <= 256L * 5;
+    if (!plan_ext(pl) && lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) return 128;
+    if (plan_ext(pl) || force_nt == 512 || (force_nt == 0 && lds > 40 * 1024)) return 512;
+    return 256;
+}
+
+// The row transforms' plan with the radix of the first / last stage -- the two that talk to global memory -- chosen: of the
+// plan's radices (2 .. 16) the smallest whose n / r butterflies are one trip for 256 threads.  Fewer loads and a smaller
+// butterfly between a thread's loads and its LDS writes, every thread busy: 1920 = 16 x 15 x 8 is 120 butterflies of
+// radix 16 or 240 of radix 8.  Measured per launch (one image, 256 threads): 1080p 24.2 -> 21.0 us (8 first), 1280-sample
+// rows 23.0 -> 19.5 (5), 700-sample rows 16.3 -> 15.1 (7), 1024 21.0 -> 16.0 (4), 720 22.6 -> 15.9 (3), 512 18.6 -> 12.4 (2:
+// 256 threads loading instead of 32); batches on 128 threads: 16 x 720-sample rows 126 -> 93 us, 8 x 1024 57 -> 50,
+// 32 x 1080p, where radix 8 is a second trip, 304 -> 307 (15 first: 289).  A function of the line length ALONE: the order of the stages decides the roundings, and an image
+// gets the same bits alone and in a batch (tests/test_gpu_fullsize.py).  launch_cols has the column transform's rule.
+static int first_radix_for(const FftPlan *pl, int n, int max_items, int always_from, int min_r) {
+    if (pl->bluestein_m || pl->nstage < 2) return 0;
+    int first = pl->radix[0];
+    for (int i = 1; i < pl->nstage; ++i) {
+        const int r = pl->radix[i];
+        if (r <= 16 && r < first && (r >= always_from || (r >= min_r && n / r <= max_items))) first = r;
+    }
+    return first == pl->radix[0] ? 0 : first;
+}
+static const FftPlan *rows_plan(pb_ctx *ctx, int n) {
+    const FftPlan *pl = pb_get_plan(ctx, n, true);       // (the 512-thread variant holds the radices above 16)
+    if (!pl || ctx->fft_first_rows == 0 || fft_lds_bytes(pl, 1) > kMaxLds) return pl;
+    const int first = ctx->fft_first_rows > 0 ? ctx->fft_first_rows : first_radix_for(pl, n, 256, 17, 2);
+    return first > 0 && first != pl->radix[0] ? pb_get_plan(ctx, n, true, first) : pl;
+}
+
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
                 const unsigned *mm, int planes_per_image) {
-    const FftPlan *pl = pb_get_plan(ctx, W, true);       // (the 512-thread variant holds the radices above 16)
+    const long blocks = (long)P * ((H + 1) / 2);
+    const FftPlan *pl = rows_plan(ctx, W);
     if (!pl) return PB_ERR_NOMEM;
     const size_t lds = fft_lds_bytes(pl, 1);
-    const long blocks = (long)P * ((H + 1) / 2);
     const pbfft::DevPlan dp = dev_plan(pl);
     if (lds > kMaxLds) {                            // the line buffer in global memory, one slot per workgroup
         if (!pb_fft_length_supported(W)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image width %d: lines of up to %d samples are supported", W, kMaxLineLength);
@@ -1613,11 +1646,10 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     // chains, and 256 threads -- one butterfly per thread and stage, held to 96 registers so that five such workgroups
     // still fit a CU -- shorten every chain: 41.0 -> 33.4 us at 4K, 17.4 -> 15.8 us at 700 x 500.  Larger grids are
     // throughput-bound and keep 128 threads (8 x 1080p: 63.7 us against 70.0 with 256).
-    const int force_nt = ctx->rows_nt;
-    const bool one_round = blocks <= 256L * 5;
+    const int nth = rows_threads(ctx, pl, lds, blocks);
     if (!fused) PB_ROWS(256, false);
-    else if (!plan_ext(pl) && lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_ROWS(128, true);
-    else if (plan_ext(pl) || force_nt == 512 || (force_nt == 0 && lds > 40 * 1024)) PB_ROWS(512, true);
+    else if (nth == 128) PB_ROWS(128, true);
+    else if (nth == 512) PB_ROWS(512, true);
     else PB_ROWS(256, true);
 #undef PB_ROWS
     PB_LAUNCH_CHECK();
@@ -1630,7 +1662,7 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
                      int *partials) {
     const int on = ctx->est_gray_rows;
     if (!on) return PB_ERR_UNSUPPORTED;
-    const FftPlan *pl = pb_get_plan(ctx, W, true);
+    const FftPlan *pl = rows_plan(ctx, W);
     if (!pl) return PB_ERR_NOMEM;
     const size_t lds = fft_lds_bytes(pl, 1);
     if (lds > kMaxLds || pl->bluestein_m || pl->nstage < 2) return PB_ERR_UNSUPPORTED;
@@ -1655,12 +1687,11 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     } while (0)
 #define PB_GROWS_C(T, NTH) do { if (C == 3) PB_GROWS(T, 3, NTH); else PB_GROWS(T, 0, NTH); } while (0)
 #define PB_GROWS_T(NTH) PB_GROWS_C(float, NTH)
-    const int force_nt = ctx->rows_nt;
-    const bool one_round = blocks <= 256L * 5;                      // (as launch_rows)
-    // (lines above 40 KB of LDS -- 8K rows -- leave room for two or three workgroups per CU: 512 threads each keep the
-    // CU's SIMDs supplied, PB_ROWS_NT=256 to compare)
-    if (!plan_ext(pl) && lds <= 32 * 1024 && (force_nt == 128 || (force_nt != 256 && !one_round))) PB_GROWS_T(128);
-    else if (plan_ext(pl) || force_nt == 512 || (force_nt == 0 && lds > 40 * 1024)) PB_GROWS_T(512);
+    // (as launch_rows; lines above 40 KB of LDS -- 8K rows -- leave room for two or three workgroups per CU: 512 threads each
+    // keep the CU's SIMDs supplied, PB_ROWS_NT=256 to compare)
+    const int nth = rows_threads(ctx, pl, lds, blocks);
+    if (nth == 128) PB_GROWS_T(128);
+    else if (nth == 512) PB_GROWS_T(512);
     else PB_GROWS_T(256);
 #undef PB_GROWS_T
 #undef PB_GROWS_C
@@ -1682,22 +1713,20 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     const int lognb = pick_lognb(ctx, pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt);
     const size_t lds = fft_lds_bytes(pl, 1 << lognb);
     const bool through_memory = fft_lds_bytes(pl, 1) > kMaxLds;
-    // Which of the plan's radices the first and the last stage take -- the two that talk to global memory.  A stage of radix r
-    // is (H / r) << lognb butterflies over the workgroup's threads, trip after trip, and every trip of these two stages is a
-    // round trip to memory plus r loads and a radix-r butterfly per thread: 2160 = 16 x 15 x 9 in tiles of 16 columns is 1080
-    // butterflies of radix 16 for 1024 threads -- a second trip for 56 of them -- or 1920 of radix 9, two full trips of a
-    // smaller butterfly (4K: 48.5 -> 43.3 us per launch; 15 first: 45.2).  Taken where the model says 15 % or more.
-    if (!through_memory && !pl->bluestein_m && pl->nstage >= 2) {
-        const int threads = ext ? 1024 : (nt == 512 && (mode == 0 || n_angles == 6)) ? 1024 : (mode == 1 && n_angles == 6) ? 512 : NT;
-        auto cost = [&](int r) { const long items = (long)(H / r) << lognb; return (double)((items + threads - 1) / threads) * (8 + r); };
-        int first = pl->radix[0];
-        if (ctx->fft_first > 0) first = ctx->fft_first;
-        else if (ctx->fft_first < 0) {
-            double best = 0.85 * cost(first);
-            for (int i = 1; i < pl->nstage; ++i)
-                if (pl->radix[i] <= 16 && cost(pl->radix[i]) < best) { best = cost(pl->radix[i]); first = pl->radix[i]; }
-        }
-        if (first != pl->radix[0]) {
+    // Which of the plan's radices the first and the last stage take -- the two that talk to global memory, the last one with
+    // the epilogue's operands (gx, the gray sample) prefetched for every output of its butterfly and the directional maxima
+    // folded behind it.  The SMALLEST: fewer values per thread between the loads and the butterfly, fewer operands held for
+    // the epilogue (the 1024-thread variants have 128 registers per thread), and trips over the workgroup's threads that
+    // are full -- 2160 = 16 x 15 x 9 in tiles of 16 columns is 1080 butterflies of radix 16 for 1024 threads, a second
+    // trip for 56 of them, or 1920 of radix 9.  Measured per launch, greedy order -> smallest first: 4K 48.5 -> 43.3 us
+    // (9; 15 first: 45.2), 1080p 40.7 -> 32.0 (6; 12 first: 36.5), 1440p 50.5 -> 45.3 (6), 1920 x 1200 41.1 -> 35.2 (5),
+    // 1920 x 1280 40.0 -> 35.9 (5), 720p 28.3 -> 26.9 (3), 500 x 700 31.1 -> 28.4 (7), 2048^2 33.7 -> 33.1 (8);
+    // 32 x 1080p 394 -> 323 us.  Radices below 5 only for lines of up to 256 of their butterflies (every trip is a round
+    // trip to memory): 512 x 512 24.6 -> 20.8 us with 2 first, 3000-sample columns -- twelve trips of radix 2 -- no different.
+    // A function of the line length alone, as rows_plan's.
+    if (!through_memory && ctx->fft_first != 0) {
+        const int first = ctx->fft_first > 0 ? ctx->fft_first : first_radix_for(pl, H, 256, 5, 2);
+        if (first > 0 && first != pl->radix[0]) {
             pl = pb_get_plan(ctx, H, ext_variant, first);
             if (!pl) return PB_ERR_NOMEM;
         }
