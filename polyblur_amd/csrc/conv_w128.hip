@@ -163,6 +163,22 @@ __device__ __forceinline__ void transpose_r2c_r2(cf (&v)[64], float2 *Z, int w, 
     __syncthreads();
 }
 
+#if defined(PB_EXPERIMENTAL) && defined(PB_W128_TRACE)
+// Lab build only (tools/build_variant.sh w128trace "-DPB_EXPERIMENTAL -DPB_W128_TRACE" conv_w128.hip): shader-clock stamps of the
+// phases of wave 0 of the first workgroups, read back with pb_debug_w128_trace (tools/w128_trace.py).
+constexpr int kTraceGroups = 8192, kTraceStamps = 12;
+__device__ unsigned long long g_w128_trace[kTraceGroups * kTraceStamps];
+#define PB_WT(i) do { if (tr) { __builtin_amdgcn_sched_barrier(0); tr[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PB_WRT(i) do { if (tr) tr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PB_WT_ARG , unsigned long long *tr
+#define PB_WT_PASS , tr
+#else
+#define PB_WT(i)
+#define PB_WRT(i)
+#define PB_WT_ARG
+#define PB_WT_PASS
+#endif
+
 struct W128Geom { int ow, oh; };
 struct W128Jobs { int pairs_x, njobs, per; float inv_pairs_x; };
 __device__ __forceinline__ int div_rcp128(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }   // exact for 0 <= n < 2^21
@@ -183,7 +199,7 @@ __device__ __forceinline__ W128Jobs jobs128_of(const W128Geom &g, int hx, int hy
 // domain's kernel is instruction for instruction what it was before the zero boundary's loaders existed (with the model a
 // run-time branch inside the loaders the rank-1 inner loop took 0.1026 ms against 0.0988 on the same box).
 template <typename TIn, typename TOut, bool ZERO>
-__device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, int pxi, int hx, int hy, float2 *Z, const float *kp) {
+__device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, int pxi, int hx, int hy, float2 *Z, const float *kp PB_WT_ARG) {
     constexpr int kBoundary = ZERO ? PB_ZERO : PB_WRAP;
     const int Tx = W_N - 2 * hx, Ty = W_N - 2 * hy;
     const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), c = lane & 31, h = lane >> 5;
@@ -198,6 +214,7 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
     TOut *opl = static_cast<TOut *>(a.out) + (long)plane * a.out_plane;
     const int Hp = a.H + 2 * a.pad, Wp = a.W + 2 * a.pad;
     cf v[64];
+    PB_WT(1);
 
     // ---- the window: lane = (column, half), register r = row 64 h + r ----
     {
@@ -370,8 +387,11 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             r2_fwd(v, upper, sg);
         }
     }
+    PB_WT(2);
     fft64_fwd(v);                                                   // columns (their radix-2 step: above)
+    PB_WT(3);
     transpose_c2r_r2(v, Z, w, lane, upper, sg);                      // ... and the rows' radix-2 step
+    PB_WT(4);
     {
         // rows: (radix-2 across the halves -- columns x and x + 64 -- inside the transposes,) 64-point transform, x spectrum,
         // and back.  The spectrum's 64 values per lane travel in a ring of four groups of eight, as in conv_wfft.hip.
@@ -391,10 +411,13 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
         centre_stage<4>(v, kh[0]); centre_stage<5>(v, kh[1]); centre_stage<6>(v, kh[2]); centre_stage<7>(v, kh[3]);
         fft64_inv_stage1(v);
     }
+    PB_WT(5);
     transpose_r2c_r2(v, Z, w, lane, upper);                         // ... with the rows' inverse radix-2 step
+    PB_WT(6);
     fft64_inv_stage2(v);                                            // columns
     fft64_inv_stage1(v);
     r2_twiddle_inv(v, upper);                                       // (the halves' exchange: in the epilogue)
+    PB_WT(7);
 
     // ---- epilogue: lane = (column, half); after the exchange register r = window row 64 h + r; the polynomial carries its
     // own b x ----
@@ -462,6 +485,8 @@ __device__ __forceinline__ void w128_pair(const ConvPass &a, int plane, int ty, 
             }
         }
     }
+    PB_WT(8);
+    PB_WRT(10);
 }
 
 // One workgroup of four waves per window pair; the GRID is the job list, as in conv_wfft.hip: workgroup b belongs to list
@@ -472,6 +497,11 @@ template <typename TIn, typename TOut, bool ZERO>
 __global__ __launch_bounds__(256, 2) void conv_w128_kernel(const ConvPass a, const W128Geom g) {
     extern __shared__ __attribute__((aligned(16))) float2 Zw[];
     const int lane = threadIdx.x & 63;
+#if defined(PB_EXPERIMENTAL) && defined(PB_W128_TRACE)
+    unsigned long long *tr = (blockIdx.x < kTraceGroups && threadIdx.x < 64) ? g_w128_trace + (long)blockIdx.x * kTraceStamps : nullptr;
+    PB_WT(0);
+    PB_WRT(9);
+#endif
     const int C = a.C, B = a.P / C;
     const int q = (int)(blockIdx.x & 7u);
     int rem = (int)(blockIdx.x >> 3);
@@ -511,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_w128_kernel(const ConvPass a, con
     const int pair = q * j.per + (rem - pl * j.per);
     if (pair >= j.njobs) return;
     const int ty = __builtin_amdgcn_readfirstlane(div_rcp128(pair, j.inv_pairs_x)), pxi = pair - ty * j.pairs_x;
-    w128_pair<TIn, TOut, ZERO>(a, img * C + pl, ty, pxi, hx, hy, Zw, a.khat + (long)img * PB_KHAT_STRIDE);
+    w128_pair<TIn, TOut, ZERO>(a, img * C + pl, ty, pxi, hx, hy, Zw, a.khat + (long)img * PB_KHAT_STRIDE PB_WT_PASS);
 }
 
 template <typename TIn, typename TOut>
@@ -525,6 +555,15 @@ int launch_w128_typed(pb_ctx *ctx, const ConvPass &p, const W128Geom &g, long gr
 }
 
 }  // namespace
+
+#if defined(PB_EXPERIMENTAL) && defined(PB_W128_TRACE)
+extern "C" int pb_debug_w128_trace(unsigned long long *host) {
+    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w128_trace), sizeof(g_w128_trace));
+    static unsigned long long zeros[kTraceGroups * kTraceStamps];
+    if (!rc) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_w128_trace), zeros, sizeof(zeros));
+    return rc;
+}
+#endif
 
 bool pb_conv_w128_types(int in_dtype, int out_dtype) { return in_dtype >= 0 && in_dtype <= 2 && out_dtype >= 0 && out_dtype <= 2; }
 
