@@ -86,6 +86,7 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //   PB_EST_LEAN=0               the parameter kernel forms the whole record before the spectra (no short chain)
 //   PB_DT_ROWS_REG=0            the domain-transform row pass through global memory instead of registers
 //   PB_FFT_EXT_RADIX=0          greedy transform plans only (radices up to 16)
+//   PB_FFT_FIRST / _ROWS=0|r    the column / row transform's first and last stage: the greedy plan's order, or radix r (default: by line length)
 //   PB_FFT_LOGNB, PB_COLS_WIDE, PB_ROWS_NT, PB_WAVE_MIN_JOBS   shapes of the transform / wave-body launches
 //   PB_XT=2                     the x-t approximation through two launches of the general body
 //   PB_STRIP, PB_STRIP_SEG, PB_EST_OVERLAP   measured experiments, --experimental builds only

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NT) void dt_rows_fused_kernel(const TJ *J, const TI
 // right-to-left pass runs on lane-reversed values (lane l <-> sample base + 63 - l), exactly as that kernel lays them out --
 // bit-identical results (tests/test_gpu_parity.py::test_dt_rows_register_form).
 template <typename TIN, int C, int NCH>
-__global__ __launch_bounds__(NT) void dt_rows_reg_kernel(const TIN *in, float *F, int H, int W, float ratio, float log_a, long rows_total) {
+__global__ __launch_bounds__(NT, NCH == 32 ? 3 : 1) void dt_rows_reg_kernel(const TIN *in, float *F, int H, int W, float ratio, float log_a, long rows_total) {   // (32 chunks: three waves per SIMD -- 168 registers)
     const int lane = threadIdx.x & 63;
     const long row_id = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);   // over B*H: one wave = one row, all channels
     if (row_id >= rows_total) return;
@@ -394,13 +394,16 @@ __global__ __launch_bounds__(NT) void dt_rows_reg_kernel(const TIN *in, float *F
     float x[NCH][C], v[NCH];
     // (addresses clamped into the row, not loads under a lane mask: a masked fp16 load is followed by its conversion inside
     //  the masked block and by a wait for it, which put the 96 loads of a 1080p row one after the other -- 1.55 ms on
-    //  64 x 1080p fp16 against 0.77 ms for the same row in fp32, profiles/r05_bench_cfg3_kernel_stats.csv)
+    //  64 x 1080p fp16 against 0.77 ms for the same row in fp32.
+    //  Only the row's last chunk is ragged: every other chunk's address is a uniform base plus the lane -- one offset
+    //  register for all of them; a clamp per chunk cost 35 registers and the third wave per SIMD.)
     TIN raw[NCH][C];
+    const int klast = nch - 1, lane_last = min(lane, W - 1 - 64 * klast);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        const int ic = min(64 * k + lane, W - 1);
+        const TIN *xk = x0 + 64 * min(k, klast) + (k < klast ? lane : lane_last);      // (chunks past the row: the last chunk again)
 #pragma unroll
-        for (int c = 0; c < C; ++c) raw[k][c] = x0[c * HW + ic];
+        for (int c = 0; c < C; ++c) raw[k][c] = xk[c * HW];
     }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
