@@ -185,3 +185,43 @@ def test_zero_boundary_ring_strong_blur(engines):
     assert np.abs(a - ref.polyblur_deblurring(x, n_iter=2, method="direct", **KW)).max() < 2e-5
     c, _ = _run(engines["default"], x, **kw)                           # (below the default threshold: three plain steps)
     assert np.array_equal(c, b)
+
+
+# ---- which of a plan's radices the line transforms' first / last stage take (csrc/estimate.hip: rows_plan, launch_cols) ----
+STAGE_ORDER_SHAPES = [(1, 1, 512, 512), (1, 1, 720, 1280), (1, 1, 1080, 1920), (1, 1, 700, 500), (1, 1, 1200, 1280),
+                      (1, 1, 1024, 2048), (1, 1, 2160, 1440), (3, 1, 600, 360)]
+
+
+@pytest.fixture(scope="module")
+def greedy_engine():
+    return _engine(PB_FFT_FIRST=0, PB_FFT_FIRST_ROWS=0)
+
+
+@pytest.mark.parametrize("shape", STAGE_ORDER_SHAPES)
+def test_stage_order_of_the_line_transforms(engines, greedy_engine, shape):
+    """the smallest radix first (2 at 512, 3 at 720, 5 at 1280 / 1200, 6 at 1080 / 1440, 7 at 700, 8 at 1920 / 2048, 9 at 2160,
+    15 at 3840-class lines) is the same transform as the greedy order's -- filters.py:159-186 -- to rounding: both against the
+    oracle, and against each other"""
+    rng = np.random.default_rng(23)
+    x = rng.random(shape, dtype=np.float32)
+    rx, ry = ref.spectral_gradients(x)
+    scale = max(1.0, float(np.abs(rx).max()), float(np.abs(ry).max()))
+    gx, gy = engines["default"].fourier_gradients(x)
+    hx, hy = greedy_engine.fourier_gradients(x)
+    for a, b in ((gx, rx), (gy, ry), (hx, rx), (hy, ry), (gx, hx), (gy, hy)):
+        assert np.abs(a - b).max() < 4e-6 * scale, float(np.abs(a - b).max())
+
+
+def test_stage_order_does_not_depend_on_the_batch(engines):
+    """the order of the stages decides the roundings, so it is a function of the line length alone: an image's records and
+    output are the same bits alone (256-thread row workgroups, 512-thread column workgroups) and in a batch (128 / 1024)"""
+    B, C, H, W = 12, 3, 360, 640
+    x, _ = synthetic_blurry_batch(B, C, H, W, seed0=5)
+    eng = engines["default"]
+    full, infos = _run(eng, x, n_iter=2, **KW)
+    for i in (0, 7, 11):
+        one, oinfos = _run(eng, x[i:i + 1], n_iter=2, **KW)
+        assert np.array_equal(full[i:i + 1], one), i
+        for k in range(2):
+            for f in ("mags", "theta", "sigma", "rho"):
+                assert np.array_equal(np.asarray(infos[k][f])[i], np.asarray(oinfos[k][f])[0]), (i, k, f)
