@@ -1591,14 +1591,10 @@ static int rows_threads(pb_ctx *ctx, const FftPlan *pl, size_t lds, long blocks)
     return 256;
 }
 
-// The row transforms' plan with the radix of the first / last stage -- the two that talk to global memory -- chosen: of the
-// plan's radices (2 .. 16) the smallest whose n / r butterflies are one trip for 256 threads.  Fewer loads and a smaller
-// butterfly between a thread's loads and its LDS writes, every thread busy: 1920 = 16 x 15 x 8 is 120 butterflies of
-// radix 16 or 240 of radix 8.  Measured per launch (one image, 256 threads): 1080p 24.2 -> 21.0 us (8 first), 1280-sample
-// rows 23.0 -> 19.5 (5), 700-sample rows 16.3 -> 15.1 (7), 1024 21.0 -> 16.0 (4), 720 22.6 -> 15.9 (3), 512 18.6 -> 12.4 (2:
-// 256 threads loading instead of 32); batches on 128 threads: 16 x 720-sample rows 126 -> 93 us, 8 x 1024 57 -> 50,
-// 32 x 1080p, where radix 8 is a second trip, 304 -> 307 (15 first: 289).  A function of the line length ALONE: the order of the stages decides the roundings, and an image
-// gets the same bits alone and in a batch (tests/test_gpu_fullsize.py).  launch_cols has the column transform's rule.
+// Which of a plan's radices its first and last stage should take -- the two that talk to global memory: the smallest one
+// (up to 16) that is at least `always_from`, or at least `min_r` with n / r <= max_items butterflies per line; 0 = the
+// plan's own first radix.  A function of the plan and the line length ALONE: the order of the stages decides the roundings,
+// and an image gets the same bits alone and in a batch (tests/test_gpu_fullsize.py, test_gpu_round5_forms.py).
 static int first_radix_for(const FftPlan *pl, int n, int max_items, int always_from, int min_r) {
     if (pl->bluestein_m || pl->nstage < 2) return 0;
     int first = pl->radix[0];
@@ -1608,6 +1604,14 @@ static int first_radix_for(const FftPlan *pl, int n, int max_items, int always_f
     }
     return first == pl->radix[0] ? 0 : first;
 }
+
+// The row transforms' plan: of its radices (2 .. 16) the smallest whose n / r butterflies are one trip for 256 threads goes
+// first.  Fewer loads and a smaller butterfly between a thread's loads and its LDS writes, every thread busy: 1920 = 16 x
+// 15 x 8 is 120 butterflies of radix 16 or 240 of radix 8.  Measured per launch (one image, 256 threads): 1080p 24.2 ->
+// 21.0 us (8 first), 1280-sample rows 23.0 -> 19.5 (5), 700-sample rows 16.3 -> 15.1 (7), 1024 21.0 -> 16.0 (4), 720 22.6
+// -> 15.9 (3), 512 18.6 -> 12.4 (2: 256 threads loading instead of 32); batches on 128 threads: 16 x 720-sample rows 126 ->
+// 93 us, 8 x 1024 57 -> 50, 32 x 1080p -- where radix 8 is a second trip -- 304 -> 307 (15 first: 289).  launch_cols has
+// the column transform's rule.
 static const FftPlan *rows_plan(pb_ctx *ctx, int n) {
     const FftPlan *pl = pb_get_plan(ctx, n, true);       // (the 512-thread variant holds the radices above 16)
     if (!pl || ctx->fft_first_rows == 0 || fft_lds_bytes(pl, 1) > kMaxLds) return pl;
