@@ -546,6 +546,128 @@ __global__ __launch_bounds__(NT) void dt_cols_fused_kernel(const TJ *__restrict_
     }
 }
 
+// ---- the column pass in strips (round 5) -----------------------------------------------------------------------------------
+// dt_cols_fused_kernel moves 6 words per sample: the down sweep reads F and J and writes F, the up sweep reads both again
+// and writes F again.  The up sweep at row r needs the down sweep's value of row r and the up sweep's of row r + 1, so the
+// down sweep has to reach the bottom first -- but not to WRITE anything on the way except what lets its values be formed
+// again: one carry per strip of S rows (dt_cols_down_kernel: 2 words per sample read, 1 / S written).  dt_cols_up_kernel
+// then takes the strips bottom-up: the strip's rows of F and J into registers, the down sweep's values of the strip formed
+// again from the carry above it -- the same operations on the same operands in the same order: the same bits --, the up
+// sweep over them, one store per sample: 3 words.  5 words instead of 6, and one exponential per sample and column instead
+// of two (the up sweep's weight of row r + 1 is the down sweep's, domain_transform.py:62-85: |J[r+1] - J[r]| either way).
+// Bit-identical to dt_cols_fused_kernel (tests/test_gpu_round5_forms.py).
+template <int C> __device__ __forceinline__ float dt_weight(const float (&jr)[C], const float (&jp)[C], float ratio, float log_a) {
+    float dy = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) dy += fabsf(jr[c] - jp[c]);
+    return expf((1.f + ratio * dy) * log_a);
+}
+constexpr int DT_STRIP = 16;
+template <typename TJ, int C>
+__global__ __launch_bounds__(NT) void dt_cols_down_kernel(const TJ *__restrict__ J, const float *__restrict__ F, float *__restrict__ carry,
+                                                          int H, int W, float ratio, float log_a, long cols_total) {
+    const long id = (long)blockIdx.x * NT + threadIdx.x;   // over B*W: one thread = one column, all channels
+    if (id >= cols_total) return;
+    const long b = id / W;
+    const int col = (int)(id - b * W);
+    const long HW = (long)H * W;
+    const float *f = F + b * C * HW + col;
+    const TJ *j = J + b * C * HW + col;
+    float prev[C], pj[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { prev[c] = f[c * HW]; pj[c] = pb_ld(j + c * HW); }
+    // carry[s][c][id] = the down sweep's value of the last row of strip s (rows S s .. S s + S - 1), for every strip but the last
+    for (int r0 = 1; r0 < H; r0 += DT_UF) {
+        float xs[DT_UF][C], js[DT_UF][C];
+#pragma unroll
+        for (int u = 0; u < DT_UF; ++u) {
+            const int r = min(r0 + u, H - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { xs[u][c] = f[c * HW + (long)r * W]; js[u][c] = pb_ld(j + c * HW + (long)r * W); }
+        }
+#pragma unroll
+        for (int u = 0; u < DT_UF; ++u) {
+            const int r = r0 + u;
+            if (r < H) {
+                const float v = dt_weight<C>(js[u], pj, ratio, log_a);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    pj[c] = js[u][c];
+                    prev[c] = xs[u][c] + v * (prev[c] - xs[u][c]);
+                }
+                if ((r & (DT_STRIP - 1)) == DT_STRIP - 1 && r + 1 < H) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) carry[((long)(r / DT_STRIP) * C + c) * cols_total + id] = prev[c];
+                }
+            }
+        }
+    }
+}
+template <typename TJ, int C>
+__global__ __launch_bounds__(NT) void dt_cols_up_kernel(const TJ *__restrict__ J, float *__restrict__ F, const float *__restrict__ carry,
+                                                        int H, int W, float ratio, float log_a, long cols_total) {
+    const long id = (long)blockIdx.x * NT + threadIdx.x;
+    if (id >= cols_total) return;
+    const long b = id / W;
+    const int col = (int)(id - b * W);
+    const long HW = (long)H * W;
+    float *f = F + b * C * HW + col;
+    const TJ *j = J + b * C * HW + col;
+    const int nstrips = (H + DT_STRIP - 1) / DT_STRIP;
+    float fnext[C], vnext = 0.f;                            // the up sweep's value of the row below the strip, and that row's weight
+#pragma unroll
+    for (int c = 0; c < C; ++c) fnext[c] = 0.f;
+    for (int s = nstrips - 1; s >= 0; --s) {
+        const int a = s * DT_STRIP;
+        float xs[DT_STRIP][C], js[DT_STRIP][C], pj[C], prev[C], v[DT_STRIP];
+        // (rows past the plane's end: the last row again -- loaded, never used)
+#pragma unroll
+        for (int u = 0; u < DT_STRIP; ++u) {
+            const int r = min(a + u, H - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { xs[u][c] = f[c * HW + (long)r * W]; js[u][c] = pb_ld(j + c * HW + (long)r * W); }
+        }
+        if (s > 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { prev[c] = carry[((long)(s - 1) * C + c) * cols_total + id]; pj[c] = pb_ld(j + c * HW + (long)(a - 1) * W); }
+        }
+        // the down sweep's values of the strip, formed again (row 0 keeps its value: domain_transform.py:62-72)
+#pragma unroll
+        for (int u = 0; u < DT_STRIP; ++u) {
+            const int r = a + u;
+            if (r == 0) {
+                v[u] = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { prev[c] = xs[u][c]; pj[c] = js[u][c]; }
+            } else if (r < H) {
+                v[u] = dt_weight<C>(js[u], pj, ratio, log_a);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    pj[c] = js[u][c];
+                    prev[c] = xs[u][c] + v[u] * (prev[c] - xs[u][c]);
+                    xs[u][c] = prev[c];
+                }
+            } else {
+                v[u] = 0.f;
+            }
+        }
+        // the up sweep over the strip (the last row of the plane keeps the down sweep's value)
+#pragma unroll
+        for (int u = DT_STRIP - 1; u >= 0; --u) {
+            const int r = a + u;
+            if (r < H) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (r < H - 1) fnext[c] = xs[u][c] + vnext * (fnext[c] - xs[u][c]);
+                    else fnext[c] = xs[u][c];
+                    f[c * HW + (long)r * W] = fnext[c];
+                }
+                vnext = v[u];
+            }
+        }
+    }
+}
+
 template <typename T> __global__ void to_float_kernel(const T *__restrict__ in, float *__restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = pb_ld(in + i);
 }
@@ -648,7 +770,17 @@ static int dt_filter_fused(pb_ctx *ctx, const T *in, const T *J, float *out, int
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, T, C>), rgrid, dim3(NT), 0, ctx->stream, J, in, out, H, W, ratio, log_a, rows_total);
         else
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, float, C>), rgrid, dim3(NT), 0, ctx->stream, J, out, out, H, W, ratio, log_a, rows_total);
-        hipLaunchKernelGGL((dt_cols_fused_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, H, W, ratio, log_a, cols_total);
+        float *carry = nullptr;
+        if (ctx->dt_cols_strip && H >= 4 * DT_STRIP) {
+            carry = static_cast<float *>(pb_scratch(ctx, "dt.carry", sizeof(float) * (size_t)((H + DT_STRIP - 1) / DT_STRIP) * C * (size_t)cols_total));
+            if (!carry) return PB_ERR_NOMEM;
+        }
+        if (carry) {
+            hipLaunchKernelGGL((dt_cols_down_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, carry, H, W, ratio, log_a, cols_total);
+            hipLaunchKernelGGL((dt_cols_up_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, carry, H, W, ratio, log_a, cols_total);
+        } else {
+            hipLaunchKernelGGL((dt_cols_fused_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, H, W, ratio, log_a, cols_total);
+        }
         PB_LAUNCH_CHECK();
     }
     return PB_OK;

@@ -39,7 +39,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "dt_cols_sweeps": _engine(PB_DT_COLS_STRIP=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -225,3 +225,20 @@ def test_stage_order_does_not_depend_on_the_batch(engines):
         for k in range(2):
             for f in ("mags", "theta", "sigma", "rho"):
                 assert np.array_equal(np.asarray(infos[k][f])[i], np.asarray(oinfos[k][f])[0]), (i, k, f)
+
+
+@pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 203, 333), np.float16), ((1, 1, 1081, 700), np.float32),
+                                         ((3, 3, 64, 97), np.float32), ((1, 3, 65, 40), np.float16), ((1, 1, 1600, 2100), np.float32)])
+def test_dt_columns_in_strips(engines, shape, dtype):
+    """the column pass of the domain transform (domain_transform.py:56-85) with the down sweep's values formed again strip by
+    strip from one carry per 16 rows (csrc/filters.hip: dt_cols_down_kernel / dt_cols_up_kernel) against the two sweeps
+    through global memory: the same bits -- heights that are and are not multiples of the strip, one and three channels,
+    one and three iterations of the filter -- and the oracle"""
+    rng = np.random.default_rng(29)
+    x = rng.random(shape, dtype=np.float32).astype(dtype)
+    a = engines["default"].dt_recursive_filter(x, 2.0, 0.8, 1)
+    assert np.array_equal(a, engines["dt_cols_sweeps"].dt_recursive_filter(x, 2.0, 0.8, 1))
+    tol = 5e-6 if dtype == np.float32 else 1e-3
+    assert np.abs(a.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
+    a3 = engines["default"].dt_recursive_filter(x, 6.0, 0.4, 3)
+    assert np.array_equal(a3, engines["dt_cols_sweeps"].dt_recursive_filter(x, 6.0, 0.4, 3))
