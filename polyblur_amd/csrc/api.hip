@@ -85,6 +85,7 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //   PB_EST_GRAY_ROWS=0|1|2      gray + range + row transform in one launch: never | fp32 lines up to 4096 | any line in LDS
 //   PB_EST_LEAN=0               the parameter kernel forms the whole record before the spectra (no short chain)
 //   PB_DT_ROWS_REG=0            the domain-transform row pass through global memory instead of registers
+//   PB_DT_COLS_STRIP=0          the domain-transform column pass as two sweeps through global memory instead of strips
 //   PB_FFT_EXT_RADIX=0          greedy transform plans only (radices up to 16)
 //   PB_FFT_FIRST / _ROWS=0|r    the column / row transform's first and last stage: the greedy plan's order, or radix r (default: by line length)
 //   PB_FFT_LOGNB, PB_COLS_WIDE, PB_ROWS_NT, PB_WAVE_MIN_JOBS   shapes of the transform / wave-body launches
