@@ -355,8 +355,9 @@ int pb_comm_gather(pb_comm *comm, const void *shard, void *root_batch, int dtype
  * from every peer --, every rank deblurs chunk t - 1 meanwhile (ONE pb_polyblur_batch call of k images: a lone 1080p image
  * costs twice what it costs inside a batch), and the results land in root_out on the root.  Called by every rank with the
  * same B, C, H, W, dtype, options, root and chunk; root_batch / root_out are read / written on the root only (NULL
- * elsewhere).  Returns with the context's stream behind every transfer.  k: pb_comm_set_chunk (0 = pb_comm_default_chunk
- * = about sqrt(largest peer shard / 2): 4 for 32 images per GPU, 1 for one).
+ * elsewhere).  Returns with the context's stream behind every transfer.  k: pb_comm_set_chunk -- 0 (the default) = image by
+ * image (k = 1: the chunked exchange stays opt-in until it has run on two GPUs), k >= 1 = that many images per step,
+ * PB_COMM_CHUNK_AUTO = pb_comm_default_chunk = about sqrt(largest peer shard / 2): 4 for 32 images per GPU, 1 for one.
  *   On an error between two steps (a failed pb_polyblur_batch, a HIP error) every remaining step is still posted -- moving
  * buffers whose content no longer matters -- so that no peer is left waiting for a matching send / recv; the first error
  * is returned once the exchange stream has been joined.
@@ -368,6 +369,7 @@ int pb_comm_gather(pb_comm *comm, const void *shard, void *root_batch, int dtype
  * index } -- at most 2 (world - 1) of them, the order both sides enumerate them in; host-only, no GPU needed.   */
 int pb_comm_deblur_from_root(pb_comm *comm, const void *root_batch, void *root_out, int dtype, int B, int C, int H, int W,
                              const pb_options *opt, int root);
+#define PB_COMM_CHUNK_AUTO (-1)
 int pb_comm_set_chunk(pb_comm *comm, int chunk);
 int pb_comm_default_chunk(int B, int world, int root);
 int pb_comm_plan_steps(int B, int world, int root);

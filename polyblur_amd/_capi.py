@@ -24,6 +24,7 @@ PB_PREFILTER_NONE, PB_PREFILTER_BILATERAL, PB_PREFILTER_DOMAIN_TRANSFORM, PB_PRE
 PB_SUPPORT_FULL, PB_SUPPORT_ADAPTIVE = 0, 1
 PB_DENSE_STENCIL, PB_DENSE_AUTO = 0, 1
 PB_DENSE_MIN_PHASES = 16
+PB_COMM_CHUNK_AUTO = -1      # pb_comm_set_chunk: pb_comm_default_chunk's rule (0 = image by image, the default)
 
 STATUS = {0: "PB_OK", -1: "PB_ERR_BADARG", -2: "PB_ERR_UNSUPPORTED", -3: "PB_ERR_HIP", -4: "PB_ERR_NOMEM"}
 

@@ -72,7 +72,7 @@ struct pb_comm {
     // pb_comm_deblur_from_root: the exchange runs on a stream of its own beside the context's (compute) stream
     hipStream_t xs = nullptr;
     hipEvent_t ev_ready = nullptr, ev_all = nullptr, ev_arrived[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
-    int chunk = 0;       // images per exchange step of pb_comm_deblur_from_root (pb_comm_set_chunk); 0 = pb_comm_default_chunk
+    int chunk = 0;       // images per exchange step of pb_comm_deblur_from_root (pb_comm_set_chunk); 0 = image by image, PB_COMM_CHUNK_AUTO = pb_comm_default_chunk
 };
 
 namespace {
@@ -202,7 +202,8 @@ static int exchange(pb_comm *c, const void *root_batch_in, void *root_batch_out,
 // operations in the same order (no tags: RCCL ignores them) -- pb_comm_plan_chunked is that order, the one
 // polyblur_amd/distributed.py:exchange_plan states in Python (the two are compared for every (B, world, root, rank, step, k) on
 // the CPU).  k = 1 is the image-by-image exchange of rounds 2 - 4; a lone 1080p call costs twice what an image costs inside
-// a batch, hence pb_comm_default_chunk ~ sqrt(shard / 2).  UNMEASURED on more than one GPU (one-GPU lease).
+// a batch, hence pb_comm_default_chunk ~ sqrt(shard / 2) -- opt-in (pb_comm_set_chunk(c, PB_COMM_CHUNK_AUTO) or k > 1): the default
+// stays k = 1 until the chunked exchange has run on two GPUs.  UNMEASURED on more than one GPU (one-GPU lease).
 int pb_comm_default_chunk(int B, int world, int root) {
     if (B < 0 || world < 1 || root < 0 || root >= world) return PB_ERR_BADARG;
     int mx = 0;
@@ -257,7 +258,7 @@ int pb_comm_plan(int B, int world, int root, int rank, int step, int *ops, int *
 }
 
 int pb_comm_set_chunk(pb_comm *c, int chunk) {
-    if (!c || chunk < 0) return PB_ERR_BADARG;
+    if (!c || chunk < PB_COMM_CHUNK_AUTO) return PB_ERR_BADARG;
     c->chunk = chunk;
     return PB_OK;
 }
@@ -279,7 +280,8 @@ int pb_comm_deblur_from_root(pb_comm *c, const void *root_batch, void *root_out,
     if (!r) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "pb_comm: librccl.so could not be loaded");
     int rc = make_exchange_stream(c);
     if (rc) return rc;
-    const int k = c->chunk > 0 ? c->chunk : pb_comm_default_chunk(B, c->world, root);
+    // image by image unless the caller opted in: the chunked exchange has not run on two GPUs yet
+    const int k = c->chunk > 0 ? c->chunk : (c->chunk == PB_COMM_CHUNK_AUTO ? pb_comm_default_chunk(B, c->world, root) : 1);
     const int nsteps = pb_comm_plan_steps_chunked(B, c->world, root, k);
     std::vector<int> ops(8 * (size_t)c->world);
     // every buffer the steps will name exists BEFORE anything is posted: a rank that bailed out between two steps would leave

@@ -17,12 +17,21 @@ step t is ONE grouped point-to-point exchange (``batch_isend_irecv`` = ncclGroup
 which the root sends chunk t of every peer's shard and receives result chunk t-2 from every peer, so
 the root's seven xGMI links carry traffic concurrently and each peer has chunk t arriving and result
 t-2 leaving while it deblurs chunk t-1 -- as ONE batch of k images -- on its compute stream.  k = 1
-is the image-by-image exchange of rounds 2-4; a lone 1080p call costs 0.33-0.38 ms against 0.17 ms
-per image inside a batch (profiles/), so ``default_chunk`` picks k ~ sqrt(shard / 2): 4 for the 32
-images per GPU of BASELINE config 4 (10 steps of ~0.9 ms instead of 34 of 0.33), 1 for config 5's
-single 8K image.  Nothing relies on message tags (RCCL ignores them): both sides enumerate the
-exchanges of a step in the same order.  Results land directly in the output batch (no staging
-buffers on the root).  Unmeasured on N > 1 GPUs (one-GPU lease): gloo runs and one-rank nccl runs only.
+is the image-by-image exchange of rounds 2-4 and **the default** (``chunk=None``): the chunked exchange
+has never run on more than one GPU (one-GPU lease: gloo runs and one-rank nccl runs only), so it is
+opt-in until a two-GPU run of tests/test_gpu_rccl.py has passed -- ``chunk=k`` (the same k on every
+rank), ``chunk="auto"`` (``default_chunk``: k ~ sqrt(shard / 2), the rule for "a lone call costs twice
+what an image costs inside a batch": 4 for the 32 images per GPU of BASELINE config 4, 1 for config 5's
+single 8K image) or ``chunk="measure"`` (``measured_chunk``: the same minimisation with the per-image
+times of THIS engine on THIS image size, taken from two timed calls on the root and broadcast).
+Nothing relies on message tags (RCCL ignores them): both sides enumerate the exchanges of a step in
+the same order.  Results land directly in the output batch (no staging buffers on the root).
+
+Errors: a ``compute`` that raises on one rank must not leave the others waiting for a matching send /
+recv.  Every rank therefore posts EVERY remaining step after its first failure (buffers whose content
+no longer matters), then all ranks agree on a status word (one 4-byte all-reduce, control plane) and
+every rank raises -- the failing one its own exception, the others ``RuntimeError`` naming the rank.
+pb_comm_deblur_from_root drains the same way in C.
 
 The compute function is a parameter so that the sharding logic can be exercised on CPU (gloo)
 without a GPU; in production it is polyblur_amd.polyblur_deblurring.
@@ -55,6 +64,16 @@ def default_chunk(batch: int, world: int, root: int = 0) -> int:
     return k
 
 
+def measured_chunk(shard: int, t_alone: float, t_in_batch: float) -> int:
+    """Images per exchange step from MEASURED call times: a step of k images costs ~ t_alone + (k - 1) t_in_batch and a shard
+    of n images takes n / k + 2 steps, so the total is least at k = sqrt(n (t_alone - t_in_batch) / (2 t_in_batch)) (which is
+    default_chunk's sqrt(n / 2) when a lone call costs twice an image inside a batch).  At least 1, at most the shard."""
+    if shard <= 1 or not (t_alone > 0.0 and t_in_batch > 0.0) or t_alone <= t_in_batch:
+        return 1
+    k = int(round((shard * (t_alone - t_in_batch) / (2.0 * t_in_batch)) ** 0.5))
+    return max(1, min(int(shard), k))
+
+
 def exchange_plan(batch: int, world: int, root: int, rank: int, step: int, chunk: int = 1):
     """The point-to-point operations of `rank` in exchange step `step`, as (kind, peer, first image, count) -- for chunk == 1
     (kind, peer, image index) -- in the order both sides enumerate them: the root's list for a step, filtered to one peer, is
@@ -85,11 +104,13 @@ def exchange_steps(batch: int, world: int, root: int, chunk: int = 1) -> int:
 
 
 def deblur_from_root(images, shape: Sequence[int], dtype, compute: Optional[Callable] = None, device=None,
-                     root: int = 0, group=None, chunk: Optional[int] = None, **kwargs):
+                     root: int = 0, group=None, chunk=None, check: bool = True, **kwargs):
     """Scatter a (B,C,H,W) batch that lives on `root`, deblur every shard where it lands, gather
     the result on `root` (other ranks return None).  `images` is ignored on non-root ranks;
-    `shape` / `dtype` must be given on all ranks; `chunk` = images per exchange step (None: default_chunk; the same
-    value on every rank)."""
+    `shape` / `dtype` must be given on all ranks; `chunk` = images per exchange step, the same value on every rank:
+    None or 1 = image by image (the default), an int k >= 1, "auto" (default_chunk) or "measure" (measured_chunk from two
+    timed calls on the root).  `check`: agree on a status word afterwards so that a failure on one rank raises on all."""
+    import time
     import torch
     import torch.distributed as dist
     if compute is None:
@@ -97,10 +118,54 @@ def deblur_from_root(images, shape: Sequence[int], dtype, compute: Optional[Call
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     B = int(shape[0])
     lo, hi = shard_bounds(B, world, rank)
-    k = default_chunk(B, world, root) if chunk is None else int(chunk)
+    if isinstance(chunk, bool) or not (chunk is None or chunk in ("auto", "measure") or isinstance(chunk, int)):
+        raise ValueError("chunk must be None, an int >= 1, 'auto' or 'measure'")
+    if isinstance(chunk, int) and chunk < 1:
+        raise ValueError("chunk must be >= 1 (got %d)" % chunk)           # (the same on every rank: nobody has posted anything yet)
     if device is None:
         device = images.device if (rank == root and images is not None) else torch.device("cpu")
+    first_exc = None                                                       # this rank's first failure; every step is still posted
+    root_ok = rank != root or (images is not None and tuple(images.shape) == tuple(shape))
+    if not root_ok:
+        first_exc = ValueError("root must pass the full batch with the announced shape")
+    peer_max = max([n for r, n in enumerate(shard_sizes(B, world)) if r != root] or [0])
+    if chunk is None:
+        k = 1
+    elif chunk == "auto":
+        k = default_chunk(B, world, root)
+    elif chunk == "measure":
+        # the engine's own times on this image size: one image alone, and per image inside a batch of (up to) four
+        kt = torch.ones(1, dtype=torch.int32, device=device)
+        if rank == root and root_ok and world > 1 and peer_max > 1:
+            try:
+                def clock(n):
+                    compute(images[:n], **kwargs)                          # (first call: plans, scratch)
+                    if images.is_cuda:
+                        torch.cuda.synchronize(images.device)
+                    t0 = time.perf_counter()
+                    compute(images[:n], **kwargs)
+                    if images.is_cuda:
+                        torch.cuda.synchronize(images.device)
+                    return time.perf_counter() - t0
+                nb = min(4, B)
+                t1, tn = clock(1), clock(nb)
+                kt[0] = measured_chunk(peer_max, t1, (tn - t1) / (nb - 1) if nb > 1 else t1)
+            except Exception as e:                                         # noqa: BLE001 -- reported after the exchange
+                first_exc = e
+        if world > 1:
+            dist.broadcast(kt, root, group)
+        k = max(1, int(kt.item()))
+    else:
+        k = int(chunk)
     nsteps = exchange_steps(B, world, root, k)
+    chunk_shape = (k,) + tuple(int(v) for v in shape[1:])
+    dummy = None
+
+    def dead(cnt):                                                         # a buffer for the steps after a failure
+        nonlocal dummy
+        if dummy is None:
+            dummy = torch.zeros(chunk_shape, dtype=dtype, device=device)
+        return dummy[:cnt]
 
     def plan(t):
         return [(op[0], op[1], op[2], op[3] if len(op) > 3 else 1) for op in exchange_plan(B, world, root, rank, t, k)]
@@ -111,42 +176,68 @@ def deblur_from_root(images, shape: Sequence[int], dtype, compute: Optional[Call
         p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, tensor_of(kind, a, n), peer, group) for kind, peer, a, n in ops]
         return dist.batch_isend_irecv(p2p)
 
+    def guarded(fn):                                                       # compute nothing after the first failure
+        nonlocal first_exc
+        if first_exc is not None:
+            return None
+        try:
+            return fn()
+        except Exception as e:                                             # noqa: BLE001 -- kept, raised after the drain
+            first_exc = e
+            return None
+
+    out_full = None
     if rank == root:
-        if images is None or tuple(images.shape) != tuple(shape):
-            raise ValueError("root must pass the full batch with the announced shape")
-        images = images.contiguous()
-        out_full = torch.empty_like(images)
+        if root_ok:
+            images = images.contiguous()
+            out_full = torch.empty_like(images)
         pending = []
         own = list(range(lo, hi))
         per_step = -(-len(own) // nsteps) if nsteps else len(own)
-        for t in range(nsteps):
-            pending += post(plan(t), lambda kind, a, n: images[a:a + n] if kind == "send" else out_full[a:a + n])
-            mine = own[t * per_step:(t + 1) * per_step]            # the root's own shard, spread over the steps, a batch per step
-            if mine:
+
+        def root_tensor(kind, a, n):
+            if not root_ok:
+                return dead(n)
+            return images[a:a + n] if kind == "send" else out_full[a:a + n]
+
+        def own_batch(mine):
+            def run():
                 out_full[mine[0]:mine[-1] + 1] = compute(images[mine[0]:mine[-1] + 1], **kwargs)
-        rest = own[nsteps * per_step:]
-        if rest:
-            out_full[rest[0]:rest[-1] + 1] = compute(images[rest[0]:rest[-1] + 1], **kwargs)
+            if mine:
+                guarded(run)
+
+        for t in range(nsteps):
+            pending += post(plan(t), root_tensor)
+            own_batch(own[t * per_step:(t + 1) * per_step])                # the root's own shard, spread over the steps, a batch per step
+        own_batch(own[nsteps * per_step:])
         for w in pending:
             w.wait()
-        return out_full
-
-    n = hi - lo
-    nchunks = -(-n // k) if n else 0
-    chunk_shape = (k,) + tuple(int(v) for v in shape[1:])
-    bufs = [torch.empty(chunk_shape, dtype=dtype, device=device) for _ in range(min(nchunks, 3))]   # ring: arriving / in work / spare
-    res = {}
-    works = {}
-    for t in range(nsteps):
-        works[t] = post(plan(t), lambda kind, a, cnt: bufs[((a - lo) // k) % 3][:cnt] if kind == "recv" else res[(a - lo) // k])
-        i = t - 1                                                   # chunk i arrived in step t-1: deblur it now, as one batch
-        if 0 <= i < nchunks:
-            for w in works.pop(t - 1):
+    else:
+        n = hi - lo
+        nchunks = -(-n // k) if n else 0
+        bufs = [torch.empty(chunk_shape, dtype=dtype, device=device) for _ in range(min(nchunks, 3))]   # ring: arriving / in work / spare
+        res = {}
+        works = {}
+        for t in range(nsteps):
+            works[t] = post(plan(t), lambda kind, a, cnt: bufs[((a - lo) // k) % 3][:cnt] if kind == "recv" else res[(a - lo) // k])
+            i = t - 1                                                   # chunk i arrived in step t-1: deblur it now, as one batch
+            if 0 <= i < nchunks:
+                for w in works.pop(t - 1):
+                    w.wait()
+                cnt = min(k, n - i * k)
+                r_i = guarded(lambda: compute(bufs[i % 3][:cnt], **kwargs).contiguous())
+                res[i] = r_i if r_i is not None else dead(cnt)          # (after a failure: the step's send still has a buffer)
+                res.pop(i - 3, None)                                    # its send (step i+1) was waited for in step i+2
+        for ws in works.values():
+            for w in ws:
                 w.wait()
-            cnt = min(k, n - i * k)
-            res[i] = compute(bufs[i % 3][:cnt], **kwargs).contiguous()
-            res.pop(i - 3, None)                                    # its send (step i+1) was waited for in step i+2
-    for ws in works.values():
-        for w in ws:
-            w.wait()
-    return None
+    if check and world > 1:
+        # one status word: the lowest failing rank + 1, 0 if none (control plane; the data path has no collective)
+        st = torch.tensor([-(rank + 1) if first_exc is not None else -(world + 1)], dtype=torch.int32, device=device)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group)
+        bad = -int(st.item()) - 1
+        if first_exc is None and bad < world:
+            raise RuntimeError("deblur_from_root: rank %d failed; the batch on rank %d is incomplete" % (bad, root))
+    if first_exc is not None:
+        raise first_exc
+    return out_full if rank == root else None

@@ -37,7 +37,9 @@ def test_bench_under_torchrun_one_rank():
     a, b = _line(plain.stdout), _line(ranked.stdout)
     assert a["rccl_ranks"] == 1 and a["n_gpus"] == 1
     assert b["rccl_ranks"] == 1 and b["n_gpus"] == 1 and b["scaling"] == "weak"
-    # the same workload on the same GPU: the RCCL-bracketed timing must tell the same story (boxes jitter by a few per cent; the first of two 13-ms measurements in a fresh process by up to 20)
+    # the same workload on the same GPU: the RCCL-bracketed run must tell the same story.  Compared on the median device time per
+    # step (one event between steps), which the first-run jitter of a 13-ms timed region does not reach: 15 %
+    assert abs(b["value_at_median_step"] / a["value_at_median_step"] - 1.0) < 0.15, (a["value_at_median_step"], b["value_at_median_step"])
     assert abs(b["value"] / a["value"] - 1.0) < 0.3, (a["value"], b["value"])
 
 
@@ -154,7 +156,7 @@ for B, root, chunk in %(cases)r:
     # (2) the C ABI over its own communicator
     out = torch.zeros((B, 3, H, W), device=dev) if rank == root else None
     o = eng.make_options(**kw)
-    eng._check(eng.lib.pb_comm_set_chunk(comm, 0 if chunk is None else chunk))
+    eng._check(eng.lib.pb_comm_set_chunk(comm, 0 if chunk is None else (capi.PB_COMM_CHUNK_AUTO if chunk == "auto" else chunk)))
     eng._check(eng.lib.pb_comm_deblur_from_root(comm, C.c_void_p(x.data_ptr()) if rank == root else None,
                                                 C.c_void_p(out.data_ptr()) if rank == root else None, capi.PB_F32, B, 3, H, W, C.byref(o), root))
     eng.synchronize()
@@ -187,7 +189,7 @@ def _gpu_count():
 def test_two_ranks_from_root_python_and_c_abi(tmp_path):
     """uneven shards (5 over 2), B < world (1 over 2), root != 0, image by image and in chunks: deblur_from_root and
     pb_comm_deblur_from_root under torch.distributed.run with 2 ranks over RCCL, bit-equal to the unsharded calls"""
-    cases = [(5, 0, 1), (5, 1, 2), (1, 0, None), (1, 1, 1), (9, 0, None), (8, 1, 3)]
+    cases = [(5, 0, 1), (5, 1, 2), (1, 0, None), (1, 1, 1), (9, 0, None), (8, 1, 3), (17, 0, "auto")]
     script = tmp_path / "two_ranks.py"
     script.write_text(_TWO_RANK % dict(repo=REPO, cases=cases))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
