@@ -31,7 +31,9 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                    whether the per-iteration theta sequences are identical; the run FAILS above tolerance
   cpu_baseline  -- the NumPy oracle (a port of the reference's CPU path) timed on this box's host cores on
                    bounded samples (rank 0, N == 1 only): 1 thread and all cores, 700x500 / 1080p / 4K
-  stages_ms_per_step, context -- labelled side numbers, never the headline value.
+  stages_ms_per_step, context -- labelled side numbers, never the headline value; at N = 1 on the default config `context`
+                   also carries the other BASELINE configs (cfg3, cfg4_share, cfg5_share: 1 warm-up + 3 timed steps each,
+                   image 0 against the oracle for cfg3 / cfg4; a parity failure there fails the run too).
 """
 import argparse
 import json
@@ -130,6 +132,47 @@ def cpu_baseline_samples(x_np, kw, want_4k_result):
     return samples, res4k
 
 
+def forms_per_iteration(eng, B, n_iter):
+    """How each iteration's polynomial was evaluated (pb_body_selection: the device's choice, iteration by iteration)."""
+    per_it = []
+    for k in range(n_iter):
+        sel = eng.body_selection(B, k)
+        one = sel[(sel[:, 0] == 1) & (sel[:, 3] != 0)]
+        three = sel[(sel[:, 0] == 1) & (sel[:, 3] == 0)]
+        halos = lambda t: sorted({(int(r[4]), int(r[5])) for r in t})[:4]
+        per_it.append(dict(one_pass_images=int(len(one)), one_pass_on_128x128_windows=int((one[:, 3] == 2).sum()),
+                           one_pass_halos_xy=halos(one), three_step_images=int(len(three)),
+                           three_step_halos_xy=halos(three), stencil_images=int((sel[:, 0] == 0).sum())))
+    return per_it
+
+
+def moved_bytes(per_it, opts, s, H, W):
+    """Bytes the forms that ran HAVE to move through HBM: (polynomial launches, whole call).  A one-pass polynomial reads x
+    and writes y: 2 words per sample; a three-step one SURVEY 8d's 8.  End to end one more read of the image per iteration
+    (the estimation).  Word sizes are the stored types: the caller's at either end of the call, fp32 between iterations (and
+    around the options); the options' own stages are not counted."""
+    n_it, opts_on = len(per_it), bool(opts)
+    moved_poly = moved_e2e = 0.0
+    for k, pi in enumerate(per_it):
+        rd = s if (k == 0 and not opts.get("prefiltering")) else 4
+        wr = s if (k == n_it - 1 and not opts_on) else 4
+        one_n, other_n = pi.get("one_pass_images", 0), pi.get("three_step_images", 0) + pi.get("stencil_images", 0)
+        per_img = 3 * H * W
+        moved_poly += per_img * (one_n * (rd + wr) + other_n * (3 * rd + 16 + wr))      # three steps: x read 3 times, t1 / t2 (fp32) written and read, y
+        moved_e2e += per_img * (one_n + other_n) * (s if k == 0 else 4)                 # the estimation's read of the image
+    return moved_poly, moved_e2e + moved_poly
+
+
+def survey_words(opts):
+    """9 words per sample and iteration, + 3 halo masking, + 5 domain-transform prefilter (+ 2 bilateral)."""
+    words = 9.0
+    if opts.get("remove_halo"):
+        words += 3.0
+    if opts.get("prefiltering"):
+        words += 5.0 if opts.get("prefilter") == "domain_transform" else 2.0
+    return words
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -192,8 +235,14 @@ def main():
         x = torch.from_numpy(x_np).to(dev).to(tdt).contiguous() if rank == 0 else None
         full_shape = (B * world, 3, H, W)
 
+        n_calls = [0]
+
+        def counted(t, **k2):                                  # (this rank's pb_polyblur_batch calls: the roofline's launches are its own)
+            n_calls[0] += 1
+            return polyblur_deblurring(t, **k2)
+
         def step(support="full"):
-            return deblur_from_root(x, full_shape, tdt, device=dev, support=support, **kw)
+            return deblur_from_root(x, full_shape, tdt, compute=counted, device=dev, support=support, **kw)
     else:
         x_np = make_batch(B, H, W, DEFAULT_SEED + 1000 * rank)[0]
         x = torch.from_numpy(x_np).to(dev).to(tdt).contiguous()
@@ -226,9 +275,12 @@ def main():
     mp_per_step = B * H * W * world / 1e6
     value = mp_per_step / (ms_per_step / 1e3)
     # the same K steps once more with an event pair around every launch: per-kernel-class device times
+    if from_root:
+        n_calls[0] = 0
     eng.profile_begin()
     dt_prof, _ = timed(args.steps, step)
     prof = eng.profile_end()
+    calls_profiled = n_calls[0] if from_root else args.steps
     ms_per_step_prof = 1e3 * dt_prof / args.steps
     # ... and once more with one event between the steps ("median of >= 10 timed runs"): device time per step
     step_ms = []
@@ -243,6 +295,7 @@ def main():
         step_ms = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
 
     side = {}
+    side_failed = []                         # context configs whose parity check failed (the run then fails too)
     if world > 1 and not from_root and not args.no_context:
         # the same total batch starting and ending on rank 0 (scatter + compute + gather)
         xr = torch.cat([x] * world) if rank == 0 else None
@@ -300,8 +353,7 @@ def main():
         # (the one-pass polynomial on 128 x 128 windows, conv_w128_kernel, carries the same event tag: one class)
         dom_kernel = "conv_wfft_kernel + conv_w128_kernel" if os.environ.get("PB_FFT_BODY", "wave") != "wg" and not cfg["opts"].get("half_temporaries") else "conv_fft_kernel"
     # one polynomial application = (2s + 3s + 3s) bytes per sample, spread over its launches
-    from polyblur_amd.distributed import default_chunk
-    calls_per_step = -(-B // default_chunk(B * world, world, 0)) if (from_root and world > 1) else 1   # from_root deblurs chunk by chunk as they arrive
+    calls_per_step = max(calls_profiled / args.steps, 1e-9)       # from_root deblurs chunk by chunk as they arrive: counted, not assumed
     launches_per_poly = max(conv_n / (args.steps * cfg["n_iter"] * calls_per_step), 1e-9)
     alg_bytes_per_launch = 8.0 * s * (samples / calls_per_step) / launches_per_poly
     conv_avg_ms = conv_ms / max(conv_n, 1)
@@ -370,11 +422,7 @@ def main():
         roofline["frac_of_copy"] = round(achieved / b21, 4) if b21 else None
     # whole-step figure of SURVEY 8d: 9 words per sample per iteration (8 for the polynomial + 1 read for the estimate),
     # plus the options' adders: halo masking 3, domain-transform prefilter 4 + 1 for the residual add-back, bilateral 2
-    words = 9.0
-    if cfg["opts"].get("remove_halo"):
-        words += 3.0
-    if cfg["opts"].get("prefiltering"):
-        words += 5.0 if cfg["opts"].get("prefilter") == "domain_transform" else 2.0
+    words = survey_words(cfg["opts"])
     e2e_gbs = words * s * samples * cfg["n_iter"] * world / (ms_per_step * 1e-3) / 1e9
     roofline["end_to_end"] = dict(algorithmic_bytes_per_step=int(words * s * samples * cfg["n_iter"]), achieved=round(e2e_gbs, 1),
                                   unit="GB/s", frac=round(e2e_gbs / (HBM_PEAK_GBS * world), 4),
@@ -404,16 +452,8 @@ def main():
         spectrum = [bool(not sp and int(sum(nph)) >= capi.PB_DENSE_MIN_PHASES)
                     for i in infos for sp, nph in zip(i["separable"], i["nphase"])]
         # how each iteration's polynomial was evaluated (pb_body_selection: the device's choice, iteration by iteration)
-        per_it = []
         try:
-            for k in range(cfg["n_iter"]):
-                sel = eng.body_selection(B, k)
-                one = sel[(sel[:, 0] == 1) & (sel[:, 3] != 0)]
-                three = sel[(sel[:, 0] == 1) & (sel[:, 3] == 0)]
-                halos = lambda t: sorted({(int(r[4]), int(r[5])) for r in t})[:4]
-                per_it.append(dict(one_pass_images=int(len(one)), one_pass_on_128x128_windows=int((one[:, 3] == 2).sum()),
-                                   one_pass_halos_xy=halos(one), three_step_images=int(len(three)),
-                                   three_step_halos_xy=halos(three), stencil_images=int((sel[:, 0] == 0).sum())))
+            per_it = forms_per_iteration(eng, B, cfg["n_iter"])
         except Exception as e:                                   # (a label, not a measurement)
             per_it = [dict(error="%s: %s" % (type(e).__name__, str(e)[:120]))]
         if any(spectrum) or any(p.get("one_pass_images") for p in per_it):
@@ -433,24 +473,16 @@ def main():
             # a one-pass polynomial reads x and writes y: 2 words per sample; a three-step one SURVEY 8d's 8.  End to end one
             # more read of the image per iteration (the estimation): 3 words where every polynomial is one pass.  Word sizes are
             # the stored types: the caller's type at either end of the call, fp32 between iterations (and around the options).
-            n_it, opts_on = cfg["n_iter"], bool(cfg["opts"])
-            moved_poly = moved_e2e = 0.0
-            for k, pi in enumerate(per_it):
-                rd = s if (k == 0 and not cfg["opts"].get("prefiltering")) else 4
-                wr = s if (k == n_it - 1 and not opts_on) else 4
-                one_n, other_n = pi.get("one_pass_images", 0), pi.get("three_step_images", 0) + pi.get("stencil_images", 0)
-                per_img = 3 * H * W
-                moved_poly += per_img * (one_n * (rd + wr) + other_n * (3 * rd + 16 + wr))      # three steps: x read 3 times, t1 / t2 (fp32) written and read, y
-                moved_e2e += per_img * (one_n + other_n) * (s if k == 0 else 4)                                          # the estimation's read of the image
-            moved_e2e += moved_poly
+            n_it = cfg["n_iter"]
+            moved_poly, moved_e2e = moved_bytes(per_it, cfg["opts"], s, H, W)
             conv_ms_step = conv_ms / args.steps
             roofline["hbm_min"] = dict(
                 polynomial=dict(bytes_per_step=int(moved_poly), achieved=round(moved_poly / (conv_ms_step * 1e-3) / 1e9, 1), unit="GB/s",
                                 frac=round(moved_poly / (conv_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 note="bytes the reblurring launches have to move (read x, write y per one-pass polynomial) / their summed duration per step"),
                 end_to_end=dict(bytes_per_step=int(moved_e2e), achieved=round(moved_e2e * world / (ms_per_step * 1e-3) / 1e9, 1), unit="GB/s",
-                                frac=round(moved_e2e / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                note="+ one read of the image per iteration for the estimation (gray and its x derivative, one fp32 plane each, "
+                                frac=round(moved_e2e * world / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                note="whole job against n_gpus x 8 TB/s; + one read of the image per iteration for the estimation (gray and its x derivative, one fp32 plane each, "
                                      "are written and read once more: on-chip candidates, not counted); options' stages not counted"))
             ceiling = (roofline.get("copy_ceiling_GBps") or {}).get("read2_write1")
             if ceiling and achieved > ceiling:
@@ -577,10 +609,10 @@ def main():
             o_sep = polyblur_deblurring(x, **sep_kw)
         dt_sep, o_sep = timed(args.steps, lambda: polyblur_deblurring(x, **sep_kw))
         ms_sep = 1e3 * dt_sep / args.steps
-        dev = (o_sep.float() - polyblur_deblurring(x, **dict(kw, method="direct")).float()).abs()
+        dsep = (o_sep.float() - polyblur_deblurring(x, **dict(kw, method="direct")).float()).abs()
         side["end_to_end_direct_separable_approximation"] = dict(
             ms_per_step=round(ms_sep, 4), mp_per_s=round(B * H * W / 1e6 / (ms_sep * 1e-3), 1),
-            max_abs_vs_exact_direct=float(dev.max()), mean_abs_vs_exact_direct=float(dev.mean()),
+            max_abs_vs_exact_direct=float(dsep.max()), mean_abs_vs_exact_direct=float(dsep.mean()),
             note="approximate by design; not the headline")
         # the method's own use case, labelled: the same scene under a MILD blur (sigma 0.7 / rho 0.45 at 30 degrees) -- the
         # later iterations estimate kernels within a 4-sample halo, whose whole polynomial is one window pass
@@ -600,6 +632,71 @@ def main():
             del xm
         except Exception as e:                                   # a labelled extra must not cost the run its line
             side["end_to_end_mild_blur"] = dict(error="%s: %s" % (type(e).__name__, str(e)[:200]))
+        # ---- the other BASELINE configs, driver-observed: per-GPU shares on this GPU, 1 warm-up + 3 timed steps each,
+        # image 0 of the timed batch against the oracle (cfg5: no oracle image -- the 8K NumPy call takes minutes; its parity
+        # at full size is tests/test_gpu_fullsize.py's) ---------------------------------------------------------------------
+        if args.config == "cfg2" and (B, H, W) == (1, 2160, 3840):
+            x1080 = None
+            for name in ("cfg3", "cfg4", "cfg5"):
+                c2 = CONFIGS[name]
+                key = name if name == "cfg3" else name + "_share"
+                try:
+                    b2, h2, w2 = c2["batch"], c2["height"], c2["width"]
+                    t_dt = torch.float32 if c2["dtype"] == "f32" else torch.float16
+                    s2 = 4 if c2["dtype"] == "f32" else 2
+                    if name == "cfg5":
+                        xs_np = np.tile(x_np[:1], (1, 1, 2, 2))            # the headline's 4K image 2 x 2: an 8K image without 40 s of generator
+                        src = "the headline's 4K image tiled 2 x 2"
+                    else:
+                        if x1080 is None:
+                            x1080 = make_batch(4, h2, w2, DEFAULT_SEED + 77)[0]
+                        xs_np = np.concatenate([x1080] * (b2 // 4))
+                        src = "4 distinct synthetic 1080p images, repeated"
+                    xs = torch.from_numpy(xs_np).to(dev).to(t_dt).contiguous()
+                    del xs_np
+                    kw2 = dict(KW, n_iter=c2["n_iter"], **c2["opts"])
+                    o2, inf2 = polyblur_deblurring(xs, return_info=True, **kw2)            # the warm-up step; also the parity output
+                    dt2, _ = timed(3, lambda: polyblur_deblurring(xs, **kw2))
+                    ms2 = 1e3 * dt2 / 3
+                    n2 = b2 * 3 * h2 * w2
+                    words2 = survey_words(c2["opts"])
+                    e2e2 = words2 * s2 * n2 * c2["n_iter"] / (ms2 * 1e-3) / 1e9
+                    ent = dict(ms_per_step=round(ms2, 4), steps=3, warmup=1, mp_per_s=round(b2 * h2 * w2 / 1e6 / (ms2 * 1e-3), 1),
+                               workload="batch=%d %dx%dx3 %s, n_iter=%d%s" % (b2, w2, h2, "fp32" if s2 == 4 else "fp16", c2["n_iter"],
+                                                                              "".join(", %s=%s" % kv for kv in sorted(c2["opts"].items()))),
+                               data=src, end_to_end=dict(achieved=round(e2e2, 1), unit="GB/s", frac=round(e2e2 / HBM_PEAK_GBS, 4),
+                                                         words_per_sample_per_iteration=words2, basis="SURVEY 8d algorithmic bytes"))
+                    if name != "cfg3":
+                        ent["note"] = "the per-GPU share of the 8-GPU config, resident on one GPU"
+                    try:
+                        pit = forms_per_iteration(eng, b2, c2["n_iter"])
+                        mp2, me2 = moved_bytes(pit, c2["opts"], s2, h2, w2)
+                        ent["hbm_min"] = dict(bytes_per_step=int(me2), achieved=round(me2 / (ms2 * 1e-3) / 1e9, 1), unit="GB/s",
+                                              frac=round(me2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              one_pass_images_per_iteration=[q["one_pass_images"] for q in pit],
+                                              on_128x128_windows_per_iteration=[q["one_pass_on_128x128_windows"] for q in pit],
+                                              note="bytes the forms that ran have to move end to end (options' own stages not counted)")
+                    except Exception as e:                               # noqa: BLE001 -- a label
+                        ent["hbm_min"] = dict(error="%s: %s" % (type(e).__name__, str(e)[:120]))
+                    if name != "cfg5" and not args.no_parity:
+                        from oracle import polyblur_ref as ref          # checker only
+                        xin = xs[:1].float().cpu().numpy()
+                        want2, winf2 = ref.polyblur_deblurring(xin, method="fft", return_info=True, **kw2)
+                        err2 = float(np.abs(o2[:1].float().cpu().numpy() - want2).max())
+                        th_a = [float(i["theta"][0]) for i in inf2]
+                        th_b = [float(i["theta"][0]) for i in winf2]
+                        tol2 = 2e-5 if s2 == 4 else 1e-3
+                        ent["parity"] = dict(max_abs=err2, tolerance=tol2, theta_sequence_equal=th_a == th_b, image="image 0 of the batch vs the oracle")
+                        if not (err2 <= tol2 and th_a == th_b):
+                            side_failed.append(key)
+                    elif name == "cfg5":
+                        ent["parity"] = dict(skipped="no oracle image in the bench run (the 8K NumPy call takes minutes); tests/test_gpu_fullsize.py "
+                                                     "compares this config with the oracle at full size", finite=bool(torch.isfinite(o2.float()).all()))
+                    side[key] = ent
+                    del xs, o2
+                    torch.cuda.empty_cache()
+                except Exception as e:                                   # noqa: BLE001 -- a labelled extra must not cost the run its line
+                    side[key] = dict(error="%s: %s" % (type(e).__name__, str(e)[:200]))
         # host buffers in and out (PCIe-inclusive; never the headline value)
         xn = x_np.astype(np.float32 if s == 4 else np.float16)
         polyblur_deblurring(torch.from_numpy(xn), **kw)
@@ -634,6 +731,8 @@ def main():
         parity = dict(max_abs=err, tolerance=tol, theta_sequence_equal=th_hip == th_ref, image="%dx%d, image 0 of the batch" % (W, H),
                       oracle="oracle/polyblur_ref.py (NumPy fp32, pinned to the reference by tests/golden)")
         failed = not (err <= tol and th_hip == th_ref)
+    if side_failed:
+        failed = True
 
     desc = "batch=%d %dx%dx3 %s per GPU, n_iter=%d, method=fft (circular), full 25-tap support" % (
         B, W, H, "fp32" if s == 4 else "fp16", cfg["n_iter"])
@@ -658,7 +757,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if failed:
-        print("PARITY FAILURE: %r" % (parity,), file=sys.stderr)
+        print("PARITY FAILURE: %r %r" % (parity, side_failed), file=sys.stderr)
         return 1
     return 0
 

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libpolyblur_hip.so"
-SOURCES = ["api.hip", "comm.hip", "conv.hip", "conv_fft.hip", "conv_big.hip", "conv_wfft.hip", "conv_w128.hip", "estimate.hip", "filters.hip", "nc.hip"]
+SOURCES = ["api.hip", "comm.hip", "conv.hip", "conv_fft.hip", "conv_big.hip", "conv_wfft.hip", "conv_w128.hip", "estimate.hip", "lines_fixed.hip", "filters.hip", "nc.hip"]
 # measured experiments that are not part of the product (NOTEBOOK.md): python -m polyblur_amd.build --experimental
 EXPERIMENTAL_SOURCES = ["conv_strip.hip", "conv_xt.hip"]
 ARCH = "gfx950"

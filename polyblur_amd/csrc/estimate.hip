@@ -49,6 +49,7 @@ extern "C" int pb_debug_params_trace(unsigned long long *host) {
 }
 #endif
 #include "khat.h"
+#include "lines_fixed.h"
 
 namespace {
 
@@ -758,7 +759,7 @@ template <int MODE, int NA> struct ColsIO {
         // m_k = max |cos(t_k) gx - sin(t_k) gy|  (blur_estimation.py:129-133)
 #pragma unroll
         for (int k = 0; k < (NA ? NA : PB_MAX_ANGLES); ++k)
-            if (NA || k < na) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
+            if (NA || k < na) best[k] = fmaxf(best[k], pbfft::dir_abs(ang.cs[k], ang.sn[k], dx, dy));
     }
     __device__ __forceinline__ void store(int p, int j, float2 v, const Pre &pre) {
         const int c = c0 + 2 * j;
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(NTH) void grad_cols_kernel(const float *__restrict_
                     const float dy = h ? -vv.y : vv.x;
 #pragma unroll
                     for (int k = 0; k < PB_MAX_ANGLES; ++k)
-                        if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
+                        if (k <= n_angles) best[k] = fmaxf(best[k], pbfft::dir_abs(ang.cs[k], ang.sn[k], dx, dy));
                 }
             }
         }
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(LONG_NT) void grad_cols_long_kernel(const float *__
                     const float dy = h ? -vv.y : vv.x;
 #pragma unroll
                     for (int k = 0; k < PB_MAX_ANGLES; ++k)
-                        if (k <= n_angles) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
+                        if (k <= n_angles) best[k] = fmaxf(best[k], pbfft::dir_abs(ang.cs[k], ang.sn[k], dx, dy));
                 }
             }
             __syncthreads();
@@ -1564,7 +1565,7 @@ __global__ __launch_bounds__(NT) void dir_maxima_kernel(const float *__restrict_
         if (discard_sat && g > thr) return;
 #pragma unroll
         for (int k = 0; k < (NA ? NA : PB_MAX_ANGLES); ++k)
-            if (NA || k < na) best[k] = fmaxf(best[k], fabsf(ang.cs[k] * dx - ang.sn[k] * dy));
+            if (NA || k < na) best[k] = fmaxf(best[k], pbfft::dir_abs(ang.cs[k], ang.sn[k], dx, dy));
     };
     if ((HW & 3) == 0) {
         const long n4 = HW >> 2;
@@ -1763,6 +1764,13 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
         return PB_OK;
     }
     ProfScope prof(ctx, PB_PROF_GRAD_COLS);
+    // the line lengths whose plan is compiled in (lines_fixed.hip: 2160, 1080, 4320, on every tile width pick_lognb gives them):
+    // the same arithmetic in a kernel that holds one plan -- bit-identical maxima (PB_COLS_FIXED=0: the run-time-plan kernel,
+    // the tests' reference)
+    if (mode == 1 && !normalize && ctx->cols_fixed) {
+        const int rcf = pb_launch_cols_fixed(ctx, planes, gx, P, H, W, lognb, mags, n_angles, discard_sat, pl);
+        if (rcf != PB_ERR_UNSUPPORTED) return rcf;
+    }
 #define PB_COLS(MODE, NA)                                                                                        \
     do {                                                                                                         \
         int rc = allow_lds(ctx, grad_cols_kernel<MODE, NA, NT>, lds);                                            \

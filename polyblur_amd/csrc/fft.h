@@ -111,9 +111,18 @@ template <> __device__ __forceinline__ void dft_small<4>(cf (&v)[4]) {
 }
 // 3 and 5 points in the Rader/Winograd form (sums and differences of the mirrored pairs first): 6 and 19 packed
 // operations -- radices 3, 5, 6, 9, 10, 12, 15 are built on them
+// (Every multiply-add below is an EXPLICIT fused one: left to -ffp-contract the compiler chooses which product of a sum
+// of two products is fused, and the choice depends on the code around the butterfly -- the same source gave results one unit
+// in the last place apart in two kernels.  Written out, a line gets the same bits from every kernel that transforms it.)
+__device__ __forceinline__ cf cfma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cf cmul_only(cf a, cf b) {           // a product that stays a product (never fused into its consumer)
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <> __device__ __forceinline__ void dft_small<3>(cf (&v)[3]) {
     const cf t = v[1] + v[2], d = v[1] - v[2];
-    const cf m = v[0] - 0.5f * t;
+    const cf m = cfma((cf){-0.5f, -0.5f}, t, v[0]);
     const float s = 0.86602540378443864676f;
     v[0] = v[0] + t;
     v[1] = cfma_mi(m, (cf){s, s}, d);                        // m - i s d
@@ -123,11 +132,11 @@ template <> __device__ __forceinline__ void dft_small<5>(cf (&v)[5]) {
     const cf t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
     const cf t5 = t1 + t2;
     const float c = 0.55901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-    const cf m1 = v[0] - 0.25f * t5;
-    const cf m2 = c * (t1 - t2);
-    const cf a1 = m1 + m2, a2 = m1 - m2;
-    const cf b1 = s1 * t3 + s2 * t4;
-    const cf b2 = s2 * t3 - s1 * t4;
+    const cf m1 = cfma((cf){-0.25f, -0.25f}, t5, v[0]);
+    const cf d12 = t1 - t2;
+    const cf a1 = cfma((cf){c, c}, d12, m1), a2 = cfma((cf){-c, -c}, d12, m1);
+    const cf b1 = cfma((cf){s1, s1}, t3, cmul_only((cf){s2, s2}, t4));
+    const cf b2 = cfma((cf){s2, s2}, t3, -cmul_only((cf){s1, s1}, t4));
     v[0] = v[0] + t5;
     v[1] = cadd_mi(a1, b1);                                  // a1 - i b1
     v[4] = csub_mi(a1, b1);
@@ -151,6 +160,10 @@ template <> __device__ __forceinline__ void dft_small<7>(cf (&v)[7]) {        //
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = o[k];
 }
+
+// |cos(t) gx - sin(t) gy| of the directional maxima (blur_estimation.py:129-133) with its roundings written out (as above: the
+// second product rounded, the first fused into the difference), so that every kernel that folds a sample gets the same bits
+__device__ __forceinline__ float dir_abs(float cs, float sn, float dx, float dy) { return fabsf(fmaf(cs, dx, -__fmul_rn(sn, dy))); }
 
 // ---- composite radices, evaluated in registers as A x B Cooley-Tukey with constant twiddles -------------
 // X[k1 + A k2] = sum_{n2} W_N^{n2 k1} ( sum_{n1} x[n1 B + n2] W_A^{n1 k1} ) W_B^{n2 k2},  N = A B

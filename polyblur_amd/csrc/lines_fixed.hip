@@ -1,0 +1,272 @@
+// Column transform + directional maxima of the estimation (blur_estimation.py:112-134, filters.py:159-186) for the line
+// lengths whose plan is known when the library is compiled: 2160 = 9 x 16 x 15 (4K), 1080 = 6 x 15 x 12 (1080p), 4320 =
+// 15 x 16 x 18 (8K) -- the orders estimate.hip:launch_cols gives those lengths.
+//
+// What grad_cols_kernel<1, 7, 1024> computes, operation for operation (the butterflies, the twiddle products and the fold of
+// the maxima are the SAME inline functions of fft.h, so every record is bit-identical to the run-time-plan kernel's --
+// tests/test_gpu_estimation_paths.py), but as a kernel that holds ONE plan:
+//   * no switch over fifteen radices per stage: the run-time-plan kernel is 60 k lines of ISA whose register allocation is
+//     that of its widest butterfly (10 vector + 176 scalar registers spilled under the 128-register cap of a 1024-thread
+//     workgroup); this one is the five stages it runs, every trip count and index division a constant;
+//   * the gray tile travels global -> LDS by LDS-DMA (16 bytes per lane, 16 rows of a 16-column tile per wave instruction,
+//     no staging register), every request of the tile issued at entry; the first stage is then an ordinary in-place LDS stage;
+//   * the twiddle table of the line (n complex values) sits in LDS beside the tile where the two fit 160 KB (2160- and
+//     1080-point lines), fetched by LDS-DMA with the tile: a stage's four twiddle bases are LDS reads, not four dependent
+//     gathers from L2 in front of every butterfly;
+//   * the epilogue's gx operands of BOTH trips of the last stage are requested before the first trip's butterfly.
+#include "common.h"
+#include "fft.h"
+#include "lines_fixed.h"
+
+namespace {
+
+using pbfft::cf;
+
+typedef __amdgpu_buffer_rsrc_t brsrc;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <typename T> __device__ __forceinline__ brsrc rsrc_of(const T *p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(p), 0, (int)bytes, 0x00020000);
+}
+// 16 bytes per lane straight into LDS: lane i's bytes land at dst + 16 i (dst wave-uniform); an offset beyond the
+// descriptor writes zeros
+__device__ __forceinline__ void dma16(brsrc r, void *dst, unsigned voffset, int soffset) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)dst, 16, (int)voffset, soffset, 0, 0);
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// pbfft::stage<R, DIT> with every size a constant: in place on the NB = 1 << LOGNB interleaved lines of s
+template <int R, bool DIT, int N, int L, int LOGNB, int NTH>
+__device__ __forceinline__ void fstage(float2 *s, const float2 *tw) {
+    constexpr int M = L / R, TW_STEP = N / L, NB = 1 << LOGNB, WORK = (N / R) << LOGNB, STRIDE = M << LOGNB;
+#pragma unroll 1
+    for (int w = threadIdx.x; w < WORK; w += NTH) {
+        const int j = w & (NB - 1), t = w >> LOGNB;
+        const int blk = t / M, np = t - blk * M;
+        cf *base = reinterpret_cast<cf *>(s) + ((blk * L + np) << LOGNB) + j;
+        cf v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = base[q * STRIDE];
+        if (DIT) {
+            if (M > 1) {
+                cf wq[R];
+                pbfft::twiddle_powers<R>(wq, tw, np * TW_STEP);
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+            }
+            pbfft::dft_small<R>(v);
+        } else {
+            pbfft::dft_small<R>(v);
+            if (M > 1) {
+                cf wq[R];
+                pbfft::twiddle_powers<R>(wq, tw, np * TW_STEP);
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) base[q * STRIDE] = v[q];
+    }
+}
+
+// pbfft::centre_stage<R>: innermost DIF stage, derivative multiplier, innermost DIT stage, in registers
+template <int R, int N, int LOGNB, int NTH>
+__device__ __forceinline__ void fcentre(float2 *s, const float *__restrict__ drev) {
+    constexpr int NB = 1 << LOGNB, WORK = (N / R) << LOGNB;
+#pragma unroll 1
+    for (int w = threadIdx.x; w < WORK; w += NTH) {
+        const int j = w & (NB - 1), t = w >> LOGNB;
+        cf *base = reinterpret_cast<cf *>(s) + ((t * R) << LOGNB) + j;
+        cf v[R];
+        float d[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { v[q] = base[q << LOGNB]; d[q] = drev[t * R + q]; }
+        pbfft::dft_small<R>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = (cf){-d[q] * v[q].y, -d[q] * v[q].x};                // conj(i d z)
+        pbfft::dft_small<R>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) base[q << LOGNB] = v[q];
+    }
+}
+
+struct AngleTable7 { float cs[7], sn[7]; };
+
+// m_k = max |cos(t_k) gx - sin(t_k) gy|  (blur_estimation.py:129-133): ColsIO<1, 7>::fold
+__device__ __forceinline__ void fold7(float (&best)[7], const AngleTable7 &ang, float dx, float dy) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) best[k] = fmaxf(best[k], pbfft::dir_abs(ang.cs[k], ang.sn[k], dx, dy));
+}
+
+// R0 x R1 x R2 = the line length; a workgroup = 2 << LOGNB adjacent columns of all rows of one plane.
+// TWLDS: the line's twiddle table in LDS behind the tile.  SAT: gradients under the saturation mask (gray > thr) are zero.
+template <int R0, int R1, int R2, int LOGNB, int NTH, bool TWLDS, bool SAT>
+__global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict__ gray, const float *__restrict__ gx, int W,
+                                                         unsigned *__restrict__ mags, int total_tiles,
+                                                         const float2 *__restrict__ tw_g, const float *__restrict__ drev,
+                                                         AngleTable7 ang, float thr) {
+    constexpr int N = R0 * R1 * R2, NB = 1 << LOGNB, TC = 2 * NB;
+    constexpr int TILE_BYTES = N * NB * 8, ROW_BYTES = TC * 4;                 // one tile row: 64 bytes (LOGNB = 3) or 32
+    constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES, LANES_PER_ROW = ROW_BYTES / 16;
+    constexpr int TILE_DMAS = (TILE_BYTES + 1023) / 1024, TW_DMAS = (N * 8 + 1023) / 1024;
+    extern __shared__ __attribute__((aligned(16))) float2 sfft[];
+    // (LDS: [ twiddle table, rounded up to whole 1-KB requests ][ tile, rounded up likewise ])
+    float2 *twl = sfft;
+    float2 *s = TWLDS ? sfft + TW_DMAS * 128 : sfft;
+    const int tiles = W / TC;
+    // adjacent column tiles share 128-byte lines: each XCD (= blockIdx % 8) takes a contiguous run of tiles (as grad_cols_kernel)
+    const int chunk = gridDim.x >> 3;
+    const int tile_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (tile_id >= total_tiles) return;
+    const int plane = tile_id / tiles;
+    const int c0 = (tile_id - plane * tiles) * TC;
+    const int tiles_pad = (tiles + 3) & ~3;
+    unsigned *mags_tile = mags + (long)plane * PB_MAX_ANGLES * tiles_pad + (tile_id - plane * tiles);
+    const long plane_off = (long)plane * N * W;
+    const float *src = gray + plane_off;
+    const float *gxp = gx + plane_off;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // ---- every request of the tile (and of the twiddle table) at entry: global -> LDS, no register in between -------------
+    {
+        const brsrc rg = rsrc_of(src, (long)N * W * 4);
+        const int pitchb = W * 4;
+        const unsigned vo = (unsigned)((lane / LANES_PER_ROW) * pitchb + c0 * 4 + (lane % LANES_PER_ROW) * 16);
+        char *sb = reinterpret_cast<char *>(s);
+#pragma unroll 1
+        for (int i = wave; i < TILE_DMAS; i += NTH / 64) {
+            // rows ROWS_PER_DMA i ...: the lanes of a last request that runs past the line read beyond the descriptor (zeros,
+            // into the tile's rounded-up tail, which nobody reads)
+            const int row0 = i * ROWS_PER_DMA;
+            if (row0 + ROWS_PER_DMA <= N) dma16(rg, sb + i * 1024, vo, row0 * pitchb);
+            else dma16(rg, sb + i * 1024, row0 + (int)(lane / LANES_PER_ROW) < N ? vo + (unsigned)(row0 * pitchb) : 0xfffffff0u, 0);
+        }
+        if (TWLDS) {
+            const brsrc rt = rsrc_of(tw_g, (long)N * 8);
+            char *tb = reinterpret_cast<char *>(twl);
+#pragma unroll 1
+            for (int i = wave; i < TW_DMAS; i += NTH / 64) dma16(rt, tb + i * 1024, (unsigned)(lane * 16), i * 1024);
+        }
+        wait_vm0();
+    }
+    __syncthreads();
+    const float2 *tw = TWLDS ? twl : tw_g;
+    // ---- the five stages --------------------------------------------------------------------------------------------------
+    fstage<R0, false, N, N, LOGNB, NTH>(s, tw);
+    __syncthreads();
+    fstage<R1, false, N, N / R0, LOGNB, NTH>(s, tw);
+    __syncthreads();
+    fcentre<R2, N, LOGNB, NTH>(s, drev);
+    __syncthreads();
+    fstage<R1, true, N, R1 * R2, LOGNB, NTH>(s, tw);
+    __syncthreads();
+    // ---- last stage + maxima (pbfft::last_stage<R0> with ColsIO<1, 7>) ------------------------------------------------------
+    float best[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) best[k] = 0.f;
+    {
+        constexpr int M = N / R0, STRIDE = M << LOGNB;
+#pragma unroll 1
+        for (int w = threadIdx.x; w < STRIDE; w += NTH) {
+            const int j = w & (NB - 1), np = w >> LOGNB;
+            const long idx0 = (long)np * W + c0 + 2 * j;
+            float2 dx[R0], g[SAT ? R0 : 1];
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                dx[q] = *reinterpret_cast<const float2 *>(gxp + idx0 + (long)q * M * W);
+                if (SAT) g[q] = *reinterpret_cast<const float2 *>(src + idx0 + (long)q * M * W);
+            }
+            cf v[R0];
+            const cf *base = reinterpret_cast<const cf *>(s) + w;
+#pragma unroll
+            for (int q = 0; q < R0; ++q) v[q] = base[q * STRIDE];
+            cf wq[R0];
+            pbfft::twiddle_powers<R0>(wq, tw, np);
+#pragma unroll
+            for (int q = 1; q < R0; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+            pbfft::dft_small<R0>(v);
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                // gradients are zeroed under the saturation mask (blur_estimation.py:117-118): they cannot raise a maximum
+                if (!(SAT && g[SAT ? q : 0].x > thr)) fold7(best, ang, dx[q].x, v[q].x);
+                if (!(SAT && g[SAT ? q : 0].y > thr)) fold7(best, ang, dx[q].y, -v[q].y);
+            }
+        }
+    }
+    __syncthreads();
+    // workgroup maximum of every direction -> one partial per column tile (estimate.hip: reduce_maxima)
+    float *red = reinterpret_cast<float *>(sfft);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        float m = best[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wave * PB_MAX_ANGLES + k] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        float m = red[threadIdx.x];
+        for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w * PB_MAX_ANGLES + threadIdx.x]);
+        mags_tile[(long)threadIdx.x * tiles_pad] = __float_as_uint(m);   // m >= 0
+    }
+}
+
+template <int R0, int R1, int R2, int LOGNB, int NTH, bool TWLDS>
+int launch_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int W, unsigned *mags, bool sat, const FftPlan *pl,
+                 const AngleTable7 &ang) {
+    constexpr int N = R0 * R1 * R2, NB = 1 << LOGNB;
+    constexpr size_t lds = (size_t)((N * NB * 8 + 1023) / 1024) * 1024 + (TWLDS ? (size_t)((N * 8 + 1023) / 1024) * 1024 : 0);
+    static_assert(lds <= 160 * 1024, "tile + twiddle table beyond LDS");
+    const long blocks = (long)P * (W / (2 * NB));
+    if (blocks > 0x7fffffffL) return PB_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);
+#define PB_LAUNCH_FIXED(SAT)                                                                                                     \
+    do {                                                                                                                         \
+        auto k = cols_fixed_kernel<R0, R1, R2, LOGNB, NTH, TWLDS, SAT>;                                                          \
+        PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), lds, ctx->stream, gray, gx, W, mags, (int)blocks, pl->tw, pl->drev, ang, 0.99f); \
+    } while (0)
+    if (sat) PB_LAUNCH_FIXED(true);
+    else PB_LAUNCH_FIXED(false);
+#undef PB_LAUNCH_FIXED
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+}  // namespace
+
+// PB_ERR_UNSUPPORTED: not one of the compiled plans / tile widths (the caller then takes grad_cols_kernel).
+// Which kernel transforms a line must not depend on the batch it arrives in (an image gets the same bits alone and in a
+// batch): every tile width estimate.hip:pick_lognb can give one of these line lengths is compiled -- the wide tile of a grid
+// that fills the chip (1024 threads, one workgroup per CU) and the narrow one of a lone image (512 threads, two per CU) -- and
+// what decides between this file and grad_cols_kernel is the image's own shape and the options alone.
+int pb_launch_cols_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int H, int W, int lognb, unsigned *mags,
+                         int n_angles, int discard_sat, const FftPlan *pl) {
+    if (n_angles != 6 || !pl || pl->bluestein_m || pl->nstage != 3 || pl->n != H || lognb < 1 || (W % (2 << lognb)) != 0)
+        return PB_ERR_UNSUPPORTED;
+    AngleTable7 ang;
+    for (int k = 0; k < 7; ++k) {
+        const float t = 3.14159265358979323846f * (float)k / (float)n_angles;       // (as launch_cols)
+        ang.cs[k] = std::cos(t);
+        ang.sn[k] = std::sin(t);
+    }
+    const int r0 = pl->radix[0], r1 = pl->radix[1], r2 = pl->radix[2];
+    const bool sat = discard_sat != 0;
+#define PB_FIXED(R0, R1, R2, LOGNB, NTH, TWLDS) return launch_fixed<R0, R1, R2, LOGNB, NTH, TWLDS>(ctx, gray, gx, P, W, mags, sat, pl, ang)
+    if (H == 2160 && r0 == 9 && r1 == 16 && r2 == 15) {
+        if (lognb == 3) PB_FIXED(9, 16, 15, 3, 1024, true);
+        if (lognb == 2) PB_FIXED(9, 16, 15, 2, 512, false);        // (69 KB of tile: two workgroups per CU, no room for the table)
+    }
+    if (H == 1080 && r0 == 6 && r1 == 15 && r2 == 12) {
+        if (lognb == 4) PB_FIXED(6, 15, 12, 4, 1024, true);
+        if (lognb == 3) PB_FIXED(6, 15, 12, 3, 512, true);         // (69 + 9 KB: two per CU with the table)
+    }
+    if (H == 4320 && r0 == 15 && r1 == 16 && r2 == 18) {
+        if (lognb == 2) PB_FIXED(15, 16, 18, 2, 1024, false);
+        if (lognb == 1) PB_FIXED(15, 16, 18, 1, 512, false);
+    }
+#undef PB_FIXED
+    return PB_ERR_UNSUPPORTED;
+}

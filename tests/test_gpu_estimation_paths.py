@@ -75,3 +75,32 @@ def test_extended_radix_plans_against_greedy_and_oracle(engines, shape):
     _, r = ref.estimate_gaussian_blur(img, c=0.362, b=0.468, return_info=True)
     assert np.max(np.abs(np.asarray(b["mags"])[:, :7] - r["mags"])) < 5e-6
     assert np.max(np.abs(np.asarray(b["sigma"]) - r["sigma"])) < 2e-5 and np.max(np.abs(np.asarray(b["rho"]) - r["rho"])) < 2e-5
+
+
+@pytest.fixture(scope="module")
+def runtime_plan_engine():
+    return _engine(PB_COLS_FIXED=0)
+
+
+@pytest.mark.parametrize("shape,sat", [((1, 3, 2160, 3840), False), ((1, 3, 2160, 3840), True), ((4, 3, 1080, 1920), False),
+                                       ((5, 1, 1080, 1920), True), ((1, 3, 4320, 7680), False), ((1, 1, 4320, 512), True),
+                                       ((1, 3, 2160, 2000), False), ((1, 3, 2160, 3848), False)])
+def test_fixed_plan_columns_are_bit_identical(engines, runtime_plan_engine, shape, sat):
+    """csrc/lines_fixed.hip (the column transform of 2160- / 1080- / 4320-point lines as a kernel that holds one plan, its
+    tile fetched by LDS-DMA, its twiddle table in LDS) against grad_cols_kernel with the run-time plan (PB_COLS_FIXED=0):
+    the same butterflies in the same order -- every field of the record bit-identical, with and without the saturation
+    mask; and both within the goldens' tolerance of the oracle (blur_estimation.py:112-134, filters.py:159-186)."""
+    B, C, H, W = shape
+    nd = min(B, 2)
+    img, _ = synthetic_blurry_batch(nd, C, H, W, seed0=41)
+    img = np.concatenate([img] * ((B + nd - 1) // nd))[:B]
+    if sat:
+        img = np.clip(img * 1.35, 0.0, 1.0).astype(np.float32)              # a good part of the image under the mask
+    o = opts(c=0.362, b=0.468, discard_saturation=sat)
+    a = runtime_plan_engine.estimate_blur(img, o)
+    b = engines["default"].estimate_blur(img, o)
+    for f in FIELDS:
+        assert np.array_equal(np.asarray(a[f]), np.asarray(b[f])), f
+    if H * W <= 2160 * 3840:
+        _, r = ref.estimate_gaussian_blur(img[:1], c=0.362, b=0.468, discard_saturation=sat, return_info=True)
+        assert np.max(np.abs(np.asarray(b["mags"])[:1, :7] - r["mags"])) < 5e-6
