@@ -150,6 +150,7 @@ struct pb_ctx {
     // tuning / comparison knobs of single kernels, read once in pb_create (the table of every knob: api.hip, pb_read_knobs)
     long wave_min_jobs = 0;              // env PB_WAVE_MIN_JOBS: three-step passes of fewer window pairs than this go to the workgroup form of the tile-spectrum body
     int fft_lognb = -1;                  // env PB_FFT_LOGNB: log2 of the complex lines per column workgroup (-1: by LDS size)
+    int rows_fixed = 1;                  // env PB_ROWS_FIXED: the same for the row transforms (gray_rows_kernel / grad_rows_kernel)
     int cols_fixed = 1;                  // env PB_COLS_FIXED: 0 = the column transform always by the run-time-plan kernel (grad_cols_kernel), also where lines_fixed.hip holds the plan
     int cols_wide = 1;                   // env PB_COLS_WIDE: 0 = never the double-width column tile
     int rows_nt = 0;                     // env PB_ROWS_NT: threads per row workgroup (128 / 256 / 512; 0 = by line length and grid size)

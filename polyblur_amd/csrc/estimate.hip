@@ -1652,6 +1652,12 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     // still fit a CU -- shorten every chain: 41.0 -> 33.4 us at 4K, 17.4 -> 15.8 us at 700 x 500.  Larger grids are
     // throughput-bound and keep 128 threads (8 x 1080p: 63.7 us against 70.0 with 256).
     const int nth = rows_threads(ctx, pl, lds, blocks);
+    // (line lengths whose plan is compiled in -- lines_fixed.hip: 3840, 1920, 7680 --: the same butterflies in a one-plan kernel
+    // on a padded LDS line; PB_ROWS_FIXED=0: this file's kernel, the tests' reference)
+    if (fused && !normalize && ctx->rows_fixed) {
+        const int rcf = pb_launch_rows_fixed(ctx, planes, 0, nullptr, gx, nullptr, P, H, W, nth, pl);
+        if (rcf != PB_ERR_UNSUPPORTED) return rcf;
+    }
     if (!fused) PB_ROWS(256, false);
     else if (nth == 128) PB_ROWS(128, true);
     else if (nth == 512) PB_ROWS(512, true);
@@ -1695,6 +1701,13 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     // (as launch_rows; lines above 40 KB of LDS -- 8K rows -- leave room for two or three workgroups per CU: 512 threads each
     // keep the CU's SIMDs supplied, PB_ROWS_NT=256 to compare)
     const int nth = rows_threads(ctx, pl, lds, blocks);
+    if (ctx->rows_fixed && (C == 3 || C == 1)) {                       // (as launch_rows)
+        const int rcf = pb_launch_rows_fixed(ctx, static_cast<const float *>(in), C, gray, gx, pt, B, H, W, nth, pl);
+        if (rcf != PB_ERR_UNSUPPORTED) {
+            if (rcf == PB_OK) { *part = pt; *partials = pairs; }
+            return rcf;
+        }
+    }
     if (nth == 128) PB_GROWS_T(128);
     else if (nth == 512) PB_GROWS_T(512);
     else PB_GROWS_T(256);

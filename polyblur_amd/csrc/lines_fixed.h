@@ -5,3 +5,6 @@
 
 int pb_launch_cols_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int H, int W, int lognb, unsigned *mags,
                          int n_angles, int discard_sat, const FftPlan *pl);
+
+int pb_launch_rows_fixed(pb_ctx *ctx, const float *in, int C, float *gray, float *gx, float2 *part, long images, int H, int W, int nth,
+                         const FftPlan *pl);

@@ -213,6 +213,191 @@ __global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Row transform (one workgroup = one PAIR of rows as one complex line): gray_rows_kernel / grad_rows_kernel<.., true> of
+// estimate.hip for the line lengths 3840 = 15 x 16 x 16, 1920 = 8 x 16 x 15 and 7680 = 16 x 20 x 24 (estimate.hip:rows_plan's
+// orders), the same butterflies in the same order.  Beside what a one-plan kernel saves (above), the line sits in LDS with
+// one pad element behind every 32 (PHI): the run-time-plan kernel's innermost stage reads s[16 t + q] from lane t -- a stride
+// of 128 bytes, every second lane on the same banks (61 % of its LDS cycles were bank conflicts, VERDICT r5 #1d) -- and its
+// middle stages meet four blocks of 16 lanes on the same banks; padded, every stage of the 3840-point plan is at the two
+// passes a 64-lane 8-byte access takes anyway.  31.7 KB per 3840-point line: still five workgroups per CU.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int PHI(int p) { return p + (p >> 5); }
+
+template <int R, bool DIT, int N, int L, int NTH>
+__device__ __forceinline__ void rstage(cf *s, const float2 *__restrict__ tw) {
+    constexpr int M = L / R, TW_STEP = N / L, WORK = N / R;
+#pragma unroll 1
+    for (int t = threadIdx.x; t < WORK; t += NTH) {
+        const int blk = t / M, np = t - blk * M;
+        const int p0 = blk * L + np;
+        cf v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = s[PHI(p0 + q * M)];
+        if (DIT) {
+            if (M > 1) {
+                cf wq[R];
+                pbfft::twiddle_powers<R>(wq, tw, np * TW_STEP);
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+            }
+            pbfft::dft_small<R>(v);
+        } else {
+            pbfft::dft_small<R>(v);
+            if (M > 1) {
+                cf wq[R];
+                pbfft::twiddle_powers<R>(wq, tw, np * TW_STEP);
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) s[PHI(p0 + q * M)] = v[q];
+    }
+}
+
+template <int R, int N, int NTH>
+__device__ __forceinline__ void rcentre(cf *s, const float *__restrict__ drev) {
+#pragma unroll 1
+    for (int t = threadIdx.x; t < N / R; t += NTH) {
+        cf v[R];
+        float d[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { v[q] = s[PHI(t * R + q)]; d[q] = drev[t * R + q]; }
+        pbfft::dft_small<R>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = (cf){-d[q] * v[q].y, -d[q] * v[q].x};                // conj(i d z)
+        pbfft::dft_small<R>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) s[PHI(t * R + q)] = v[q];
+    }
+}
+
+// how a row pair's samples arrive: the image's channels, forming the gray samples exactly as gray_minmax_kernel does
+// (blur_estimation.py:36; estimate.hip:GrayRowsIO) and keeping them for the column pass, with the pair's (min, max) ...
+template <int CC> struct GrayIn {
+    const float *row0;         // channel 0, first row of the pair
+    long cstride;
+    float *g0;                 // gray, first row of the pair
+    int W;
+    bool has1;
+    float lo, hi;
+    __device__ __forceinline__ float2 load(int p) {
+        float a = row0[p], b = has1 ? row0[W + p] : 0.f;
+        if (CC == 3) {
+            const float a1 = row0[cstride + p], a2 = row0[2 * cstride + p];
+            const float b1 = has1 ? row0[cstride + W + p] : 0.f, b2 = has1 ? row0[2 * cstride + W + p] : 0.f;
+            a = a + a1 + a2; b = b + b1 + b2;
+            a = a / 3.0f; b = b / 3.0f;
+        }
+        g0[p] = a;
+        lo = fminf(lo, a); hi = fmaxf(hi, a);
+        if (has1) { g0[W + p] = b; lo = fminf(lo, b); hi = fmaxf(hi, b); }
+        return make_float2(a, b);
+    }
+};
+// ... or the rows of a float plane as they are (estimate.hip:RowsIO without normalisation)
+struct PlainIn {
+    const float *row0;
+    int W;
+    bool has1;
+    __device__ __forceinline__ float2 load(int p) const { return make_float2(row0[p], has1 ? row0[W + p] : 0.f); }
+};
+
+template <int R0, int R1, int R2, int NTH, class IN>
+__device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, float *o0, int W, bool has1, const float2 *__restrict__ tw,
+                                                const float *__restrict__ drev) {
+    constexpr int N = R0 * R1 * R2, M = N / R0;
+    // first stage: pbfft::first_stage<R0>
+#pragma unroll 1
+    for (int np = threadIdx.x; np < M; np += NTH) {
+        cf v[R0];
+#pragma unroll
+        for (int q = 0; q < R0; ++q) v[q] = pbfft::to_cf(in.load(np + q * M));
+        pbfft::dft_small<R0>(v);
+        cf wq[R0];
+        pbfft::twiddle_powers<R0>(wq, tw, np);
+#pragma unroll
+        for (int q = 1; q < R0; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) s[PHI(np + q * M)] = v[q];
+    }
+    __syncthreads();
+    rstage<R1, false, N, N / R0, NTH>(s, tw);
+    __syncthreads();
+    rcentre<R2, N, NTH>(s, drev);
+    __syncthreads();
+    rstage<R1, true, N, R1 * R2, NTH>(s, tw);
+    __syncthreads();
+    // last stage: pbfft::last_stage<R0> with RowsIO::store
+#pragma unroll 1
+    for (int np = threadIdx.x; np < M; np += NTH) {
+        cf v[R0];
+#pragma unroll
+        for (int q = 0; q < R0; ++q) v[q] = s[PHI(np + q * M)];
+        cf wq[R0];
+        pbfft::twiddle_powers<R0>(wq, tw, np);
+#pragma unroll
+        for (int q = 1; q < R0; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+        pbfft::dft_small<R0>(v);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            o0[np + q * M] = v[q].x;
+            if (has1) o0[W + np + q * M] = -v[q].y;
+        }
+    }
+}
+
+constexpr int rows_lds_bytes(int n) { return (n + (n >> 5) + 1) * 8; }
+// (the second launch bound = waves per SIMD the register allocation must leave room for: five 256-thread workgroups per CU
+// -- what 31.7 KB of LDS allow a 3840-point line -- are five waves per SIMD)
+constexpr int rows_waves(int n, int nth) { return nth == 512 ? 4 : (n > 2048 && nth == 128 ? 3 : 5); }
+
+template <int R0, int R1, int R2, int NTH, int CC>
+__global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void gray_rows_fixed_kernel(const float *__restrict__ in, float *__restrict__ gray,
+                                                                                     float *__restrict__ gx, float2 *__restrict__ part, int H,
+                                                                                     const float2 *__restrict__ tw, const float *__restrict__ drev) {
+    constexpr int W = R0 * R1 * R2;
+    extern __shared__ __attribute__((aligned(16))) float2 sfft[];
+    const int pairs = (H + 1) / 2;
+    const int b = blockIdx.x / pairs, pr = blockIdx.x - b * pairs;
+    const int r0 = 2 * pr;
+    const long HW = (long)H * W;
+    GrayIn<CC> io;
+    io.row0 = in + (long)b * CC * HW + (long)r0 * W;
+    io.cstride = HW;
+    io.g0 = gray + (long)b * HW + (long)r0 * W;
+    io.W = W; io.has1 = r0 + 1 < H;
+    io.lo = INFINITY; io.hi = -INFINITY;
+    rows_fixed_body<R0, R1, R2, NTH>(reinterpret_cast<cf *>(sfft), io, gx + (long)b * HW + (long)r0 * W, W, io.has1, tw, drev);
+    float lo = io.lo, hi = io.hi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    __syncthreads();                                               // (the transform's last reads of sfft)
+    float *red = reinterpret_cast<float *>(sfft);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = lo; red[2 * (threadIdx.x >> 6) + 1] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NTH / 64; ++w) { lo = fminf(lo, red[2 * w]); hi = fmaxf(hi, red[2 * w + 1]); }
+        part[(long)b * pairs + pr] = make_float2(lo, hi);          // one partial per row pair, folded by the parameter kernel
+    }
+}
+
+template <int R0, int R1, int R2, int NTH>
+__global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void grad_rows_fixed_kernel(const float *__restrict__ planes, float *__restrict__ gx, int H,
+                                                                                     const float2 *__restrict__ tw, const float *__restrict__ drev) {
+    constexpr int W = R0 * R1 * R2;
+    extern __shared__ __attribute__((aligned(16))) float2 sfft[];
+    const int pairs = (H + 1) / 2;
+    const int plane = blockIdx.x / pairs;
+    const int r0 = 2 * (blockIdx.x - plane * pairs);
+    PlainIn io{planes + ((long)plane * H + r0) * W, W, r0 + 1 < H};
+    rows_fixed_body<R0, R1, R2, NTH>(reinterpret_cast<cf *>(sfft), io, gx + ((long)plane * H + r0) * W, W, io.has1, tw, drev);
+}
+
 template <int R0, int R1, int R2, int LOGNB, int NTH, bool TWLDS>
 int launch_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int W, unsigned *mags, bool sat, const FftPlan *pl,
                  const AngleTable7 &ang) {
@@ -268,5 +453,46 @@ int pb_launch_cols_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P,
         if (lognb == 1) PB_FIXED(15, 16, 18, 1, 512, false);
     }
 #undef PB_FIXED
+    return PB_ERR_UNSUPPORTED;
+}
+
+// The row transform of W-sample lines with the plan compiled in; C == 0: a float plane as it is (in = P planes of H x W),
+// else gray + range partials + transform from the image's C channels (in = B images; part: B x pairs partials).
+// nth: the thread count estimate.hip:rows_threads gives the launch.  PB_ERR_UNSUPPORTED: not compiled -- the caller runs its own.
+int pb_launch_rows_fixed(pb_ctx *ctx, const float *in, int C, float *gray, float *gx, float2 *part, long images, int H, int W, int nth,
+                         const FftPlan *pl) {
+    if (!pl || pl->bluestein_m || pl->nstage != 3 || pl->n != W || (C != 0 && C != 1 && C != 3)) return PB_ERR_UNSUPPORTED;
+    const long blocks = images * ((H + 1) / 2);
+    if (blocks > 0x7fffffffL || blocks < 1) return PB_ERR_UNSUPPORTED;
+    const int r0 = pl->radix[0], r1 = pl->radix[1], r2 = pl->radix[2];
+#define PB_ROWS_FIXED(R0, R1, R2, NTH)                                                                                              \
+    do {                                                                                                                            \
+        constexpr size_t lds = rows_lds_bytes(R0 * R1 * R2);                                                                        \
+        if (C == 0) {                                                                                                               \
+            auto k = grad_rows_fixed_kernel<R0, R1, R2, NTH>;                                                                       \
+            if (lds > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gx, H, pl->tw, pl->drev);                \
+        } else if (C == 3) {                                                                                                        \
+            auto k = gray_rows_fixed_kernel<R0, R1, R2, NTH, 3>;                                                                    \
+            if (lds > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gray, gx, part, H, pl->tw, pl->drev);    \
+        } else {                                                                                                                    \
+            auto k = gray_rows_fixed_kernel<R0, R1, R2, NTH, 1>;                                                                    \
+            if (lds > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gray, gx, part, H, pl->tw, pl->drev);    \
+        }                                                                                                                           \
+        PB_LAUNCH_CHECK();                                                                                                          \
+        return PB_OK;                                                                                                               \
+    } while (0)
+    if (W == 3840 && r0 == 15 && r1 == 16 && r2 == 16) {
+        if (nth == 256) PB_ROWS_FIXED(15, 16, 16, 256);
+        if (nth == 128) PB_ROWS_FIXED(15, 16, 16, 128);
+    }
+    if (W == 1920 && r0 == 8 && r1 == 16 && r2 == 15) {
+        if (nth == 256) PB_ROWS_FIXED(8, 16, 15, 256);
+        if (nth == 128) PB_ROWS_FIXED(8, 16, 15, 128);
+    }
+    if (W == 7680 && r0 == 16 && r1 == 20 && r2 == 24 && nth == 512) PB_ROWS_FIXED(16, 20, 24, 512);
+#undef PB_ROWS_FIXED
     return PB_ERR_UNSUPPORTED;
 }

@@ -104,3 +104,33 @@ def test_fixed_plan_columns_are_bit_identical(engines, runtime_plan_engine, shap
     if H * W <= 2160 * 3840:
         _, r = ref.estimate_gaussian_blur(img[:1], c=0.362, b=0.468, discard_saturation=sat, return_info=True)
         assert np.max(np.abs(np.asarray(b["mags"])[:1, :7] - r["mags"])) < 5e-6
+
+
+@pytest.fixture(scope="module")
+def runtime_plan_rows_engine():
+    return _engine(PB_ROWS_FIXED=0)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 2160, 3840), (1, 1, 33, 3840), (20, 3, 200, 3840), (1, 3, 1080, 1920), (4, 3, 1080, 1920),
+                                   (3, 1, 75, 1920), (1, 3, 36, 7680)])
+def test_fixed_plan_rows_are_bit_identical(engines, runtime_plan_rows_engine, shape):
+    """csrc/lines_fixed.hip's row transforms (3840- / 1920- / 7680-point lines: one plan per kernel, the line padded in LDS)
+    against gray_rows_kernel / grad_rows_kernel with the run-time plan (PB_ROWS_FIXED=0): one image and batches (256 and 128
+    threads per row pair), one and three channels, an odd height (an unpaired last row) -- every field of the record and
+    both gradient planes bit-identical (filters.py:159-186)."""
+    B, C, H, W = shape
+    nd = min(B, 2)
+    img, _ = synthetic_blurry_batch(nd, C, H, W, seed0=43)
+    img = np.concatenate([img] * ((B + nd - 1) // nd))[:B]
+    o = opts(c=0.362, b=0.468)
+    a = runtime_plan_rows_engine.estimate_blur(img, o)
+    b = engines["default"].estimate_blur(img, o)
+    for f in FIELDS:
+        assert np.array_equal(np.asarray(a[f]), np.asarray(b[f])), f
+    planes = img.reshape(B * C, H, W)[: min(B * C, 4)]
+    gxa, gya = runtime_plan_rows_engine.fourier_gradients(planes)
+    gxb, gyb = engines["default"].fourier_gradients(planes)
+    assert np.array_equal(gxa, gxb) and np.array_equal(gya, gyb)
+    if H * W <= 1080 * 1920:
+        rx, ry = ref.spectral_gradients(planes[None])
+        assert np.max(np.abs(gxb - rx[0])) < 2e-5 and np.max(np.abs(gyb - ry[0])) < 2e-5
