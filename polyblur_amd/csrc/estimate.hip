@@ -1512,7 +1512,7 @@ template <typename K> int allow_lds(pb_ctx *ctx, K kernel, size_t bytes) {
 // the same waves per CU, but half as many 128-byte lines requested per useful byte of the column segments
 // (measured, 4K: 73.7 -> 68.5 us; 8 x 1080p: 132 -> 122 us; 512 threads on the narrow tile: 95 us; one 700x500 image,
 // whose 44 narrow tiles already leave most CUs idle: 31.7 -> 35.9 us, hence the workgroup-count condition).
-int pick_lognb(pb_ctx *ctx, const FftPlan *pl, int W, int P, bool wide_ok, int *threads) {
+int pick_lognb(pb_ctx *ctx, const FftPlan *pl, int W, int P, bool wide_ok, int *threads, bool fixed_maxima = false) {
     const int forced = ctx->fft_lognb;
     if (fft_lds_bytes(pl, 1) > kMaxLds) {          // lines through global memory (grad_cols_long_kernel): 8-column tiles
         int lognb = 2;
@@ -1526,7 +1526,10 @@ int pick_lognb(pb_ctx *ctx, const FftPlan *pl, int W, int P, bool wide_ok, int *
     int nt = NT;
     const bool wide_off = ctx->cols_wide == 0;
     if (wide_ok && !wide_off && forced < 0 && !pl->bluestein_m && pl->nstage >= 2 &&
-        fft_lds_bytes(pl, 2 << lognb) <= 140 * 1024 && (long)P * (W / (4 << lognb)) >= 200) {   // still fills the chip
+        fft_lds_bytes(pl, 2 << lognb) <= 140 * 1024 && (long)P * (W / (4 << lognb)) >= 200 &&   // still fills the chip
+        // (1080-point lines through lines_fixed.hip: two 512-thread workgroups per CU on 16-column tiles -- 69 KB each, one's
+        // requests under the other's stages -- beat one 1024-thread workgroup on a 32-column tile: 32 x 1080p 174 against 198 us)
+        !(fixed_maxima && pl->n == 1080 && (W % 16) == 0)) {
         ++lognb;
         nt = 512;
     }
@@ -1728,7 +1731,7 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
     if (!pl) return PB_ERR_NOMEM;
     const bool ext = plan_ext(pl);
     int nt = NT;
-    const int lognb = pick_lognb(ctx, pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt);
+    const int lognb = pick_lognb(ctx, pl, W, P, (mode == 1 && n_angles == 6) || mode == 0, &nt, mode == 1 && n_angles == 6 && !normalize && ctx->cols_fixed);
     const size_t lds = fft_lds_bytes(pl, 1 << lognb);
     const bool through_memory = fft_lds_bytes(pl, 1) > kMaxLds;
     // Which of the plan's radices the first and the last stage take -- the two that talk to global memory, the last one with
@@ -1867,7 +1870,7 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     const long HW = (long)H * W;
     const FftPlan *plh = pb_get_plan(ctx, H);
     if (!plh) return PB_ERR_NOMEM;
-    const int est_lognb = pick_lognb(ctx, plh, W, B, opt->n_angles == 6, nullptr);                   // as launch_cols
+    const int est_lognb = pick_lognb(ctx, plh, W, B, opt->n_angles == 6, nullptr, opt->n_angles == 6 && !(opt->q > 0.f) && ctx->cols_fixed);   // as launch_cols
     const int col_tiles = (W + (2 << est_lognb) - 1) / (2 << est_lognb);
     // (see below: transforms side by side + a maxima pass; an experiment that measured SLOWER -- 0.90 against 0.85 ms per 4K call,
     // 0.35 against 0.32 ms at 700 x 500: the column workgroups take a CU's whole LDS, so the row workgroups do not run beside

@@ -234,12 +234,17 @@ __device__ __forceinline__ void divmod(int t, int m, float inv_m, int &q, int &r
 // The R - 1 twiddles W^q of one butterfly, W = tw[m]: the powers 1, 2, 4, 8 (, 16) come from the table (exact), the others
 // are products of two of them or of an earlier product (at most three roundings) -- four gathers instead of fifteen,
 // and no integer multiply per gather.
+// (in two halves, so that a caller can request the table's values long before it needs the products: twiddle_fetch +
+// twiddle_fill == twiddle_powers, the same operations on the same operands)
 template <int R>
-__device__ __forceinline__ void twiddle_powers(cf (&w)[R], const float2 *__restrict__ tw, int m) {
+__device__ __forceinline__ void twiddle_fetch(cf (&w)[R], const float2 *__restrict__ tw, int m) {
 #pragma unroll
     for (int q = 1; q < R; ++q) {
         if ((q & (q - 1)) == 0) w[q] = reinterpret_cast<const cf *>(tw)[m * q];
     }
+}
+template <int R>
+__device__ __forceinline__ void twiddle_fill(cf (&w)[R]) {
 #pragma unroll
     for (int q = 3; q < R; ++q) {
         if ((q & (q - 1)) != 0) {
@@ -247,6 +252,11 @@ __device__ __forceinline__ void twiddle_powers(cf (&w)[R], const float2 *__restr
             w[q] = cmul(w[hi], w[q - hi]);
         }
     }
+}
+template <int R>
+__device__ __forceinline__ void twiddle_powers(cf (&w)[R], const float2 *__restrict__ tw, int m) {
+    twiddle_fetch<R>(w, tw, m);
+    twiddle_fill<R>(w);
 }
 
 // One in-place stage on all NB interleaved lines.  L = current block length (a multiple of R).

@@ -13,7 +13,6 @@
 //   * the twiddle table of the line (n complex values) sits in LDS beside the tile where the two fit 160 KB (2160- and
 //     1080-point lines), fetched by LDS-DMA with the tile: a stage's four twiddle bases are LDS reads, not four dependent
 //     gathers from L2 in front of every butterfly;
-//   * the epilogue's gx operands of BOTH trips of the last stage are requested before the first trip's butterfly.
 #include "common.h"
 #include "fft.h"
 #include "lines_fixed.h"
