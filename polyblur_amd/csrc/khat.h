@@ -167,6 +167,11 @@ __device__ __forceinline__ void khat128_body(const float *sk, float *out, int sl
     }
 }
 
+#ifndef PB_HALO_TOL
+#define PB_HALO_TOL 1e-8f
+#endif
+constexpr float KH_HALO_TOL = PB_HALO_TOL;     // tap mass (absolute values) a window halo may leave outside: see khat_body
+
 // Smallest r with  sum_{|i - n| > r} m[i] < tol  for the 2n+1 non-negative values m[0 .. 2n] (n <= 63): one wave, lane l
 // holds the pair of offsets +-(63 - l), a prefix sum over the lanes is the tail beyond each offset.
 template <typename F> __device__ __forceinline__ int tail_radius(F m, int n, float tol, int lane) {
@@ -226,9 +231,11 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     // only has to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error
     // of at most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero
     // (full support) -- 8 for sigma 0.6 whose taps beyond +-4 carry 1e-13 of the mass --, so the halo along an axis is the
-    // radius outside which the taps' absolute values, summed over the other axis, come to < 1e-10 (an aliasing term three
-    // orders below fp32 rounding; any caller-supplied taps are measured the same way).  An oblique Gaussian's marginals
-    // differ: sigma 1.66 / rho 1.0 at 66 degrees needs 7 samples along x and 10 along y.
+    // radius outside which the taps' absolute values, summed over the other axis, come to < KH_HALO_TOL = 1e-8: the aliasing
+    // term is at most that mass times the operand's range -- for samples in [0, 1] below a sixth of fp32's unit roundoff
+    // (6e-8), so it cannot move a result by more than a rounding does (rounds 3 - 5 asked for 1e-10: two samples more of halo
+    // on either side of every window for a term nothing can see; any caller-supplied taps are measured the same way).  An
+    // oblique Gaussian's marginals differ: sigma 1.66 / rho 1.0 at 66 degrees needs 6 samples along x and 9 along y.
     //   The one-pass polynomial's filter a3 K^3 + a2 K^2 + a1 K + b is measured the same way without being formed: the
     // marginal of |K * K| is at most the marginal of |K| convolved with itself, so |a3| m^3 + |a2| m^2 + |a1| m (1-D
     // convolution powers of the kernel's marginal m) bounds the composite's marginal from above -- 13 and 18 samples for the
@@ -271,7 +278,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         const int ax = wave & 1;
         int r;
         if (wave < 2) {
-            r = tail_radius([&](int i) { return s_m[ax][i]; }, PB_KRAD, 1e-10f, lane);
+            r = tail_radius([&](int i) { return s_m[ax][i]; }, PB_KRAD, KH_HALO_TOL, lane);
         } else if (ps.on) {
             const float c3 = fabsf(ps.a3), c2 = fabsf(ps.a2), c1 = fabsf(ps.a1);
             r = tail_radius([&](int i) {
@@ -279,7 +286,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
                     if (i >= PB_KRAD && i < PB_KRAD + K2) v += c2 * s_m2[ax][K1 - 1 + i - PB_KRAD];
                     if (i >= 2 * PB_KRAD && i < 2 * PB_KRAD + K1) v += c1 * s_m[ax][i - 2 * PB_KRAD];
                     return v;
-                }, 3 * PB_KRAD, 1e-10f, lane);
+                }, 3 * PB_KRAD, KH_HALO_TOL, lane);
         } else {
             r = 3 * PB_KRAD;
         }
