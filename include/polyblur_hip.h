@@ -185,8 +185,11 @@ typedef enum pb_dense_eval { PB_DENSE_STENCIL = 0, PB_DENSE_AUTO = 1 } pb_dense_
 int pb_set_dense_eval(pb_ctx *ctx, int mode, int min_phases);
 /* Diagnostics: how the B images of iteration `iteration` of the most recent pb_polyblur_batch call on this context were
  * evaluated (-1: the most recent estimation / reblurring pass of any entry point) --
- * host[6 b + 0..5] = { tile-spectrum body (1) or a stencil body (0), halo class of the workgroup form, rank-1 strip flag,
- * whole polynomial in one window pass (1) or three Horner steps (0), window halo along x, along y }.  The choice is made
+ * host[6 b + 0..5] = { tile-spectrum body (1) or a stencil body (0), halo class of the workgroup form (-1: a one-pass image
+ * whose taps the device did NOT find point-symmetric although the call's class vouched for it -- NaN taps: the output is
+ * then whatever the one-pass form makes of them), rank-1 strip flag,
+ * whole polynomial in one window pass (1 / 2: on 64 x 64 / 128 x 128 windows) or three Horner steps (0), window halo along x,
+ * along y }.  The choice is made
  * on the device from each record (no reference counterpart: filters.convolve2d, filters.py:14-49, has one evaluation);
  * bench.py labels its roofline line with it.  Synchronises the context's stream.                                   */
 int pb_body_selection(pb_ctx *ctx, int iteration, int *host, int B);

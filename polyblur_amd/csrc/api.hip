@@ -81,16 +81,19 @@ static int pitch4(int w) { return (w + 3) & ~3; }
 //   PB_TAPER_RING=0             the second and third blend of an edgetaper over the whole plane, not over the border ring
 //   PB_POLY_PADDED=0            the polynomial after an edgetaper keeps three Horner steps
 //   PB_POLY_ALWAYS=0            never PolySpec.always (issue every launch the records might need)
-//   PB_SIDE_STREAM=0, PB_SIDE_MIN_TILES=<n>, PB_MAIN_STREAM_BODY=0|1   the side stream of launches that may find no work
 //   PB_EST_GRAY_ROWS=0|1|2      gray + range + row transform in one launch: never | fp32 lines up to 4096 | any line in LDS
 //   PB_EST_LEAN=0               the parameter kernel forms the whole record before the spectra (no short chain)
 //   PB_DT_ROWS_REG=0            the domain-transform row pass through global memory instead of registers
 //   PB_DT_COLS_STRIP=0          the domain-transform column pass as two sweeps through global memory instead of strips
 //   PB_FFT_EXT_RADIX=0          greedy transform plans only (radices up to 16)
 //   PB_FFT_FIRST / _ROWS=0|r    the column / row transform's first and last stage: the greedy plan's order, or radix r (default: by line length)
-//   PB_FFT_LOGNB, PB_COLS_WIDE, PB_ROWS_NT, PB_WAVE_MIN_JOBS   shapes of the transform / wave-body launches
+//   PB_FFT_LOGNB, PB_WAVE_MIN_JOBS   shapes of the column-transform / wave-body launches
+//   PB_COLS_FIXED=0, PB_ROWS_FIXED=0   the line transforms always by the run-time-plan kernels (estimate.hip), also where
+//                               lines_fixed.hip holds the plan (the tests' bit-identity reference)
 //   PB_XT=2                     the x-t approximation through two launches of the general body
-//   PB_STRIP, PB_STRIP_SEG, PB_EST_OVERLAP   measured experiments, --experimental builds only
+//   PB_STRIP, PB_STRIP_SEG, PB_EST_OVERLAP   measured experiments: read in --experimental builds only
+// (retired in round 6, their alternatives measured and dropped in NOTEBOOK.md: PB_ROWS_NT, PB_COLS_WIDE, PB_MAIN_STREAM_BODY,
+// PB_SIDE_STREAM, PB_SIDE_MIN_TILES -- the fields keep their defaults)
 static void pb_read_knobs(pb_ctx *ctx) {
     auto geti = [](const char *n, int &v) { if (const char *e = getenv(n)) v = atoi(e); };
     auto getl = [](const char *n, long &v) { if (const char *e = getenv(n)) v = atol(e); };
@@ -101,14 +104,15 @@ static void pb_read_knobs(pb_ctx *ctx) {
     }
     if (const char *e = getenv("PB_FFT_BODY")) ctx->fft_wave = (e[0] == 'w' && e[1] == 'g') ? 0 : 1;
     if (const char *e = getenv("PB_XT")) ctx->xt_two_launch = e[0] == '2';
+#ifdef PB_EXPERIMENTAL
     geti("PB_STRIP", ctx->strip_mode); geti("PB_STRIP_SEG", ctx->strip_seg);
-    geti("PB_EST_GRAY_ROWS", ctx->est_gray_rows); geti("PB_EST_LEAN", ctx->est_lean); geti("PB_DT_ROWS_REG", ctx->dt_rows_reg); geti("PB_DT_COLS_STRIP", ctx->dt_cols_strip); geti("PB_EST_OVERLAP", ctx->est_overlap);
-    geti("PB_FFT_EXT_RADIX", ctx->fft_ext_radix); geti("PB_FFT_FIRST", ctx->fft_first); geti("PB_FFT_FIRST_ROWS", ctx->fft_first_rows); geti("PB_FFT_LOGNB", ctx->fft_lognb); geti("PB_COLS_WIDE", ctx->cols_wide); geti("PB_COLS_FIXED", ctx->cols_fixed); geti("PB_ROWS_FIXED", ctx->rows_fixed);
-    geti("PB_ROWS_NT", ctx->rows_nt); getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
+#endif
+    geti("PB_EST_GRAY_ROWS", ctx->est_gray_rows); geti("PB_EST_LEAN", ctx->est_lean); geti("PB_DT_ROWS_REG", ctx->dt_rows_reg); geti("PB_DT_COLS_STRIP", ctx->dt_cols_strip);
+    geti("PB_FFT_EXT_RADIX", ctx->fft_ext_radix); geti("PB_FFT_FIRST", ctx->fft_first); geti("PB_FFT_FIRST_ROWS", ctx->fft_first_rows); geti("PB_FFT_LOGNB", ctx->fft_lognb); geti("PB_COLS_FIXED", ctx->cols_fixed); geti("PB_ROWS_FIXED", ctx->rows_fixed);
+    getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
     geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);
     getf("PB_POLY_COST128", ctx->poly_cost128); getl("PB_POLY_MIN_PAIRS128", ctx->poly_min_pairs128);
-    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); geti("PB_TAPER_RING", ctx->taper_ring); geti("PB_ZERO_RING", ctx->zero_ring); getl("PB_ZERO_RING_MIN_PAIRS", ctx->zero_ring_min_pairs); geti("PB_ZERO_RING_ASIDE", ctx->zero_ring_aside); getl("PB_SIDE_MIN_TILES", ctx->side_min_tiles);
-    geti("PB_MAIN_STREAM_BODY", ctx->main_stream_body);
+    geti("PB_POLY_ALWAYS", ctx->poly_always); geti("PB_POLY_PADDED", ctx->poly_padded); geti("PB_TAPER_RING", ctx->taper_ring); geti("PB_ZERO_RING", ctx->zero_ring); getl("PB_ZERO_RING_MIN_PAIRS", ctx->zero_ring_min_pairs); geti("PB_ZERO_RING_ASIDE", ctx->zero_ring_aside);
 }
 
 extern "C" {
@@ -136,8 +140,7 @@ int pb_create(pb_ctx **out, int device, void *stream) {
     pb_read_knobs(ctx);
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) { delete ctx; return PB_ERR_HIP; }
-    const char *side = getenv("PB_SIDE_STREAM");
-    if (!(side && side[0] == '0')) {
+    {
         if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {

@@ -81,7 +81,7 @@ struct pb_ctx {
     int interp_na = 0, interp_ni = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_switch = nullptr;
     // A second stream for the launches of a polynomial that device-built records may leave without work (pb_launch_conv_poly):
-    // forked from and joined back into `stream` inside the call, idle between calls.  nullptr: not used (env PB_SIDE_STREAM=0).
+    // forked from and joined back into `stream` inside the call, idle between calls.  nullptr: its creation failed (the engine works without it).
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t est_done_bytes = 0;     // size of the zero-initialised arrival counters
@@ -141,8 +141,8 @@ struct pb_ctx {
     int dt_cols_strip = 1;               // env PB_DT_COLS_STRIP: 0 = the domain-transform column pass as two sweeps through global memory (dt_cols_fused_kernel)
     int dt_rows_reg = 1;                 // env PB_DT_ROWS_REG: 0 = the domain-transform row pass always through global memory (dt_rows_fused_kernel)
     int poly_always = 1;                 // env PB_POLY_ALWAYS: 0 = never PolySpec.always (every polynomial issues all the launches its records might need)
-    long side_min_tiles = 12288;         // env PB_SIDE_MIN_TILES: stencil tiles per launch from which the launches that may find no work go to the side stream
-    int main_stream_body = -1;           // env PB_MAIN_STREAM_BODY: which launch stays on the caller's stream when the others go to the side stream (0 = wave body, 1 = 128 x 128; -1 = by spec)
+    long side_min_tiles = 12288;         // (PB_SIDE_MIN_TILES until round 6) stencil tiles per launch from which the launches that may find no work go to the side stream
+    int main_stream_body = -1;           // (PB_MAIN_STREAM_BODY until round 6) which launch stays on the caller's stream when the others go to the side stream (0 = wave body, 1 = 128 x 128; -1 = by spec)
     int est_gray_rows = 1;               // env PB_EST_GRAY_ROWS: 1 = gray + range + row transform in one launch where measured faster (fp32 planes, lines of up to 4096 samples), 2 = for any line held in LDS, 0 = never
     int fft_ext_radix = 1;               // env PB_FFT_EXT_RADIX: 0 = greedy plans only (radices up to 16)
     int fft_first_rows = -1;             // env PB_FFT_FIRST_ROWS: the same for the row transforms (rows_plan)
@@ -152,8 +152,8 @@ struct pb_ctx {
     int fft_lognb = -1;                  // env PB_FFT_LOGNB: log2 of the complex lines per column workgroup (-1: by LDS size)
     int rows_fixed = 1;                  // env PB_ROWS_FIXED: the same for the row transforms (gray_rows_kernel / grad_rows_kernel)
     int cols_fixed = 1;                  // env PB_COLS_FIXED: 0 = the column transform always by the run-time-plan kernel (grad_cols_kernel), also where lines_fixed.hip holds the plan
-    int cols_wide = 1;                   // env PB_COLS_WIDE: 0 = never the double-width column tile
-    int rows_nt = 0;                     // env PB_ROWS_NT: threads per row workgroup (128 / 256 / 512; 0 = by line length and grid size)
+    int cols_wide = 1;                   // (PB_COLS_WIDE until round 6) 0 = never the double-width column tile
+    int rows_nt = 0;                     // (PB_ROWS_NT until round 6) threads per row workgroup (128 / 256 / 512; 0 = by line length and grid size)
     int xt_two_launch = 0;               // env PB_XT=2: the x-t approximation as two launches of the general body
     int est_overlap = -1;                // env PB_EST_OVERLAP (--experimental builds): rows and columns side by side on two streams
     int strip_seg = 0;                   // env PB_STRIP_SEG (--experimental builds): segment height of the strip body

@@ -1702,7 +1702,7 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 #define PB_GROWS_C(T, NTH) do { if (C == 3) PB_GROWS(T, 3, NTH); else PB_GROWS(T, 0, NTH); } while (0)
 #define PB_GROWS_T(NTH) PB_GROWS_C(float, NTH)
     // (as launch_rows; lines above 40 KB of LDS -- 8K rows -- leave room for two or three workgroups per CU: 512 threads each
-    // keep the CU's SIMDs supplied, PB_ROWS_NT=256 to compare)
+    // keep the CU's SIMDs supplied)
     const int nth = rows_threads(ctx, pl, lds, blocks);
     if (ctx->rows_fixed && (C == 3 || C == 1)) {                       // (as launch_rows)
         const int rcf = pb_launch_rows_fixed(ctx, static_cast<const float *>(in), C, gray, gx, pt, B, H, W, nth, pl);

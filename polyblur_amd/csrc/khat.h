@@ -211,7 +211,9 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     // (the short chain: the taps are the caller's LDS array as it is -- full support, nothing outside the box to mask -- and
     // point-symmetric by construction, PolySpec.always)
     const float *skp = lean ? rl->taps : sk;
-    if (!lean)
+    if (lean) {                                  // (only the check: NaN parameters make taps that compare unequal to themselves)
+        for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) sym = sym && skp[i] == skp[PB_KSIZE * PB_KSIZE - 1 - i];
+    } else
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
         const bool in = abs(u) <= R && abs(v) <= R;
@@ -226,7 +228,11 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     PB_PT(20);
     // (PolySpec.always: the host vouches for point-symmetric taps -- the estimation's own Gaussians -- and has no other launch
     // to fall back on; taps that compare unequal there are NaNs, which the one-pass form turns into the same zeros)
-    const bool symm = (__syncthreads_and(sym) || ps.always != 0) && min_phases >= 0;
+    // The reduction is kept under `always` too: what it finds is reported (pb_fft_sel.rf = -1, pb_body_selection's second
+    // column), so that a caller -- or a debug run -- can tell a record the host wrongly vouched for from a good one.
+    const bool sym_found = __syncthreads_and(sym) != 0;
+    const bool symm = (sym_found || ps.always != 0) && min_phases >= 0;
+    const bool vouched_wrongly = ps.always != 0 && !sym_found;
     // The window halo of the tile-spectrum body, per axis.  The spectrum below holds EVERY tap of the record's box; the halo
     // only has to cover the taps that matter to overlap-save: what lies beyond it wraps around inside the window, an error
     // of at most that mass times the range of the operand.  The record's radius counts taps until they underflow to zero
@@ -326,7 +332,7 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     const bool use = poly || use3;
     if (tid == 0 && slice == 0) {
         sel->use_fft = use ? 1 : 0;
-        sel->rf = poly ? (ps.on == 1 ? 12 : 0) : Rh;
+        sel->rf = poly ? (ps.on == 1 ? 12 : (vouched_wrongly ? -1 : 0)) : Rh;
         sel->hx = poly ? hxp : hxk; sel->hy = poly ? hyp : hyk;
         if (!lean) sel->strip = (separable != 0 && R > 8) ? 1 : 0;
         sel->poly = poly128 ? 2 : (poly ? 1 : 0);

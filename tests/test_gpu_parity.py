@@ -866,6 +866,27 @@ def test_direct_separable_matches_its_oracle(shape, seed):
     assert d.max() < 5e-2 and d.mean() < 5e-3, (d.max(), d.mean())
 
 
+def test_direct_separable_mixed_batch_default_build():
+    """the default library runs method='direct_separable' as two launches of the general body (the one-launch
+    csrc/conv_xt.hip is in the --experimental build only), which has no pass of its own for images whose exact kernel is
+    rank-1.  A batch that mixes a rank-1 blur (theta = 0), an oblique one and an isotropic one: against the oracle's x-t
+    restatement (intent of separable_gaussian2d.cpp:91-183), identical theta sequences, and every image bit for bit what it
+    gets alone."""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    from polyblur_amd.synthetic import synthetic_blurry_image
+    x = np.stack([synthetic_blurry_image(3, 150, 210, 500 + i, blur=b)[0]
+                  for i, b in enumerate([(2.0, 1.0, 0.0), (2.0, 1.0, 30.0), (1.5, 1.5, 0.0), (2.5, 0.8, 90.0)])]).astype(np.float32)
+    kw = dict(n_iter=2, method="direct_separable", **KW)
+    out, infos = polyblur_deblurring(torch.from_numpy(x).cuda(), return_info=True, **kw)
+    want, winfos = ref.polyblur_deblurring(x, return_info=True, **kw)
+    for k in range(x.shape[0]):
+        assert [float(i["theta"][k]) for i in infos] == [float(i["theta"][k]) for i in winfos]
+        alone = polyblur_deblurring(torch.from_numpy(x[k:k + 1]).cuda(), **kw)
+        assert torch.equal(alone, out[k:k + 1]), k
+    assert maxabs(out.cpu().numpy(), want) < 3e-5
+
+
 @pytest.mark.parametrize("sigma,rho,deg", [(2.0, 1.0, 30.0), (4.0, 0.3, 42.0), (0.74, 0.4, 24.0), (3.0, 2.0, 66.0), (2.0, 1.0, 0.0),
                                            (3.5, 0.5, 96.0), (1.5, 1.5, 48.0)])
 def test_direct_separable_records(eng, sigma, rho, deg):

@@ -242,3 +242,31 @@ def test_dt_columns_in_strips(engines, shape, dtype):
     assert np.abs(a.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
     a3 = engines["default"].dt_recursive_filter(x, 6.0, 0.4, 3)
     assert np.array_equal(a3, engines["dt_cols_sweeps"].dt_recursive_filter(x, 6.0, 0.4, 3))
+
+
+@pytest.mark.parametrize("kind", ["constant", "nan"])
+def test_degenerate_images_under_the_one_pass_class(engines, kind):
+    """under PolySpec.always the host vouches for point-symmetric taps and no stencil launch stands behind the
+    window launches.  The device still looks (csrc/khat.h: the symmetry reduction is kept, a violation is reported as
+    pb_body_selection's second column = -1).  A constant image has no gradient: the reference's estimate is NaN (0 / 0 in
+    blur_estimation.py:189-208, the oracle agrees); the engine's clamps (sigma, rho in [0.3, 4], fminf / fmaxf drop a NaN)
+    give it the widest isotropic Gaussian instead -- symmetric taps, not flagged, and a polynomial whose taps sum to 1 leaves
+    the constant where it is.  With a NaN sample in it the image is garbage in, garbage out; either way the good image in the
+    same batch is neither flagged nor changed by a bit, and nothing hangs or faults."""
+    eng = engines["default"]
+    good, _ = synthetic_blurry_batch(1, 3, 240, 320, seed0=5)
+    bad = np.full((1, 3, 240, 320), 0.5, np.float32)
+    if kind == "nan":
+        bad[0, 1, 100, 100] = np.nan
+    x = np.concatenate([good, bad])
+    out, _ = _run(eng, x, n_iter=2, **KW)
+    sel = eng.body_selection(2, 0)
+    assert sel[0, 1] != -1, sel
+    if kind == "constant":
+        assert sel[1, 1] != -1 and np.max(np.abs(out[1] - 0.5)) < 1e-5, (sel, float(np.max(np.abs(out[1] - 0.5))))
+    alone, _ = _run(eng, good, n_iter=2, **KW)
+    assert eng.body_selection(1, 0)[0, 1] != -1
+    assert np.array_equal(out[:1], alone)
+    assert np.isfinite(out[:1]).all()
+    want = ref.polyblur_deblurring(good, n_iter=2, c=0.362, b=0.468, alpha=6, beta=1)
+    assert np.max(np.abs(out[:1] - want)) < 2e-5
