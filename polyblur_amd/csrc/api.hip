@@ -681,10 +681,11 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     if (!ksize) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: sizes from 2 to %d are built", opt->ker_size, PB_KSIZE_MAX);
     if (opt->separable_approx && opt->edgetaping)
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "edgetaping is not defined for the separable approximation");
-    // (an even ker_size is the reference's off-centre tap grid, blur_estimation.py:222 / filters.py:78: the edgetaper weights
-    // and the 1-D kernels of the separable approximation are built on the centred grid only)
-    if (!(ksize & 1) && (opt->edgetaping || opt->separable_approx))
-        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for odd sizes only", ksize);
+    // (an even ker_size is the reference's off-centre tap grid, blur_estimation.py:222 / filters.py:78: the 1-D kernels of the
+    // separable approximation are built on the centred grid only; the edgetaper takes it since round 6 -- its weights are
+    // autocorrelations of the projections, which do not care where the taps sit)
+    if (!(ksize & 1) && opt->separable_approx)
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: the separable approximation is built for odd sizes only", ksize);
     // (kernels beyond the 25 x 25 record take conv_big.hip's pass: no edgetaper weights, no separable approximation there)
     if (ksize > PB_KSIZE && (opt->edgetaping || opt->separable_approx))
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);

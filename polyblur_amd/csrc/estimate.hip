@@ -1130,9 +1130,10 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         sym = 0.5f * (sky[tid] + sky[PB_KSIZE - 1 - tid]);
     }
     __syncthreads();
-    if (tid < PB_KSIZE) { skx[tid] = sxm; sky[tid] = sym; info->kx[tid] = sxm; info->ky[tid] = sym; }
-    __syncthreads();
-    PB_PT(5);
+    // The autocorrelations of the projections AS THEY ARE (edgetaper.py:11-21 transforms torch.sum(kernel, -1) itself): an even
+    // ker_size sits off-centre in the record (gaussian_taps), its projections are not symmetric about tap 12 -- an
+    // autocorrelation does not care where the taps sit, a symmetrised marginal does.  (Until round 6 the symmetrised
+    // marginals were correlated, and edgetaping with an even ker_size was refused.)
     if (tid < PB_KSIZE) {
         float ax = 0.f, ay = 0.f;
 #pragma unroll
@@ -1145,6 +1146,10 @@ __device__ void finish_record(pb_blur_info *info, int support, bool from_taps, f
         info->acorr_x[tid] = ax;
         info->acorr_y[tid] = ay;
     }
+    __syncthreads();
+    if (tid < PB_KSIZE) { skx[tid] = sxm; sky[tid] = sym; info->kx[tid] = sxm; info->ky[tid] = sym; }
+    __syncthreads();
+    PB_PT(5);
     for (int idx = tid; idx < (PB_KSIZE + 1) * 32; idx += NT) {
         const int y = idx >> 5, j = (idx & 31) - 3;
         const bool row = y < PB_KSIZE;                  // row 25: zeros, the taps of filler phases

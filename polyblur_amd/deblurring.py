@@ -73,8 +73,8 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
         # pad is ker_size // 2 (even sizes: off-centre, as the reference's grid arange(k) - (k - 1) // 2 and its two convolution
         # paths place them).  sigma is clamped to 4, so 49 holds +-6 sigma: nothing beyond it is built
         raise NotImplementedError("ker_size must be between 2 and 49")
-    if ker_size % 2 == 0 and (edgetaping or method == "direct_separable"):
-        raise NotImplementedError("an even ker_size is built for the plain 'fft' / 'direct' methods only (not with edgetaping or 'direct_separable')")
+    if ker_size % 2 == 0 and method == "direct_separable":
+        raise NotImplementedError("an even ker_size is built for the 'fft' / 'direct' methods only (not with 'direct_separable')")
     if ker_size > capi.PB_KSIZE and (edgetaping or method == "direct_separable"):
         raise NotImplementedError("a ker_size above 25 is built for the plain 'fft' / 'direct' methods only (not with edgetaping or 'direct_separable')")
     if not (0 <= q < 0.5):

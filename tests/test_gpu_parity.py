@@ -832,6 +832,28 @@ def test_even_kernel_sizes_link_by_link(golden, k, method):
     assert maxabs(out, xs[3]) < 3e-4
 
 
+@pytest.mark.parametrize("k", [4, 12, 24])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_even_kernel_sizes_with_edgetaping(golden, k, method):
+    """the reference's edgetaper takes a kernel of any size (edgetaper.py:10-23); an even ker_size with
+    edgetaping=True raised PB_ERR_UNSUPPORTED until round 6 (the record's autocorrelations were those of SYMMETRISED projections,
+    and an even size sits off-centre).  Link by link against the reference's own outputs (tests/golden/make_golden_even_taper.py),
+    the two links chained, and the oracle on another image."""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    g = golden("pipeline_even_taper.npz")
+    kw = dict(ker_size=k, method=method, edgetaping=True, **KW)
+    xs = [g["x0"]] + [g["k%d_%s_x%d" % (k, method, i)] for i in (1, 2)]
+    for i in range(2):
+        out = polyblur_deblurring(torch.from_numpy(xs[i]).cuda(), n_iter=1, **kw).cpu().numpy()
+        assert maxabs(out, xs[i + 1]) < 2e-5, (k, method, i, maxabs(out, xs[i + 1]))
+    out = polyblur_deblurring(torch.from_numpy(xs[0]).cuda(), n_iter=2, **kw).cpu().numpy()
+    assert maxabs(out, xs[2]) < 1e-4
+    x, _ = synthetic_blurry_batch(2, 3, 150, 200, seed0=63)
+    out = polyblur_deblurring(torch.from_numpy(x).cuda(), n_iter=1, **kw).cpu().numpy()
+    assert maxabs(out, ref.polyblur_deblurring(x, n_iter=1, **kw)) < 2e-5
+
+
 @pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64)), (2, (1, 3, 20, 17)), (8, (2, 1, 33, 40)), (22, (1, 3, 64, 70)),
                                      (27, (2, 3, 70, 133)), (26, (1, 1, 40, 33)), (48, (1, 3, 150, 97)), (49, (2, 1, 20, 30)), (35, (1, 3, 300, 517))])
 def test_kernel_sizes_against_oracle(k, shape):

@@ -232,3 +232,16 @@ def test_even_kernel_sizes_link_by_link(golden, k, method):
         assert np.max(np.abs(out - xs[i + 1])) < 1e-5, (k, method, i)
     out = ref.polyblur_deblurring(xs[0], n_iter=3, **kw)
     assert np.max(np.abs(out - xs[3])) < 3e-4
+
+
+@pytest.mark.parametrize("k", [4, 12, 24])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_even_kernel_sizes_with_edgetaping(golden, k, method):
+    """edgetaper_alpha takes a kernel of any size (edgetaper.py:10-23): the oracle against the reference's own outputs for an
+    even ker_size with edgetaping=True, link by link (tests/golden/make_golden_even_taper.py)."""
+    g = golden("pipeline_even_taper.npz")
+    kw = dict(ker_size=k, method=method, edgetaping=True, c=0.362, b=0.468, alpha=6, beta=1)
+    xs = [g["x0"]] + [g["k%d_%s_x%d" % (k, method, i)] for i in (1, 2)]
+    for i in range(2):
+        out = ref.polyblur_deblurring(xs[i], n_iter=1, **kw)
+        assert np.max(np.abs(out - xs[i + 1])) < 1e-5, (k, method, i)
