@@ -7,10 +7,12 @@
 
 #include "common.h"
 
-int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int P, long HW);
-int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
-                  const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
-                  int clamp01, const void *recomb_cur = nullptr, int recomb_cur_dtype = 0, const float *recomb_smooth = nullptr);
+// (g_dtype: the type of the gradient planes gx, gy, ox -- PB_F32, or PB_F16 inside an fp16 call of the pipeline)
+int pb_grad_energy(pb_ctx *ctx, const void *gx, const void *gy, float *nM, int P, long HW, int g_dtype = PB_F32);
+int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const void *gx,
+                  const void *gy, const void *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
+                  int clamp01, const void *recomb_cur = nullptr, int recomb_cur_dtype = 0, const float *recomb_smooth = nullptr,
+                  int g_dtype = PB_F32);
 int pb_recombine(pb_ctx *ctx, const float *y, const void *cur, int cur_dtype, const float *smooth, void *out, int out_dtype,
                  long n);
 int pb_bilateral5_impl(pb_ctx *ctx, const void *in, int in_dtype, void *out, int out_dtype, int P, int H, int W);
@@ -457,8 +459,9 @@ struct InverseScratch {
 // src: what gets deconvolved (cur, or the smooth component).  dst: (B,C,H,W) of dst_dtype.
 int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype, void *dst, int dst_dtype,
                    const pb_blur_info *info, float alpha, float beta, int boundary, int edgetaping, int remove_halo,
-                   const float *g0x, const float *g0y, const float *nM, int final_clamp,
-                   const void *recomb_cur = nullptr, int recomb_cur_dtype = 0, const float *recomb_smooth = nullptr) {
+                   const void *g0x, const void *g0y, const float *nM, int final_clamp,
+                   const void *recomb_cur = nullptr, int recomb_cur_dtype = 0, const float *recomb_smooth = nullptr,
+                   int g_dtype = PB_F32) {
     // recomb_cur (only with remove_halo): the halo kernel also adds back the detail layer cur - recomb_smooth
     float *t1 = nullptr, *t2 = nullptr;
     if (!g.t1h) {
@@ -482,15 +485,15 @@ int inverse_filter(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtyp
     if (!y) return PB_ERR_NOMEM;
     int rc = run_polynomial(ctx, g, src, src_dtype, xpadded, info, alpha, beta, boundary, t1, t2, y, PB_F32, 0);
     if (rc) return rc;
-    float *ox = static_cast<float *>(pb_scratch(ctx, "inv.ox", sizeof(float) * g.P * g.HW));
+    void *ox = pb_scratch(ctx, "inv.ox", dsize(g_dtype) * g.P * g.HW);    // (in the type of grad_img's planes)
     if (!ox) return PB_ERR_NOMEM;
-    rc = pb_fourier_gradients_impl(ctx, y, g.P, g.H, g.W, ox, nullptr);     // only gout_x is used (deblurring.py:174)
+    rc = pb_fourier_gradients_typed(ctx, y, g.P, g.H, g.W, ox, nullptr, g_dtype);     // only gout_x is used (deblurring.py:174)
     if (rc) return rc;
     if (xpadded)
         return pb_halo_apply(ctx, xpadded + (long)g.pad * g.pp + g.pad, PB_F32, g.pp, g.pplane, y, g0x, g0y, ox, nM, dst,
-                             dst_dtype, g.P, g.H, g.W, final_clamp, recomb_cur, recomb_cur_dtype, recomb_smooth);
+                             dst_dtype, g.P, g.H, g.W, final_clamp, recomb_cur, recomb_cur_dtype, recomb_smooth, g_dtype);
     return pb_halo_apply(ctx, src, src_dtype, g.W, g.HW, y, g0x, g0y, ox, nM, dst, dst_dtype, g.P, g.H, g.W, final_clamp,
-                         recomb_cur, recomb_cur_dtype, recomb_smooth);
+                         recomb_cur, recomb_cur_dtype, recomb_smooth, g_dtype);
 }
 
 int check_shape(pb_ctx *ctx, int dtype, int B, int C, int H, int W, int allow_u8 = 0) {
@@ -731,10 +734,14 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         if (!tmpimg2) return PB_ERR_NOMEM;
     }
     // gradients of the ORIGINAL image, used by halo masking in every iteration (deblurring.py:61,83)
-    float *g0x = nullptr, *g0y = nullptr, *nM = nullptr;
+    // (an fp16 call keeps them -- and every iteration's d/dx of the deblurred image -- as fp16 planes where the line transforms
+    // can write such planes: halo_kernel's TG)
+    void *g0x = nullptr, *g0y = nullptr;
+    float *nM = nullptr;
+    const int g_dtype = (dtype == PB_F16 && pb_gradient_planes_half(ctx, H, W)) ? PB_F16 : PB_F32;
     if (opt->remove_halo) {
-        g0x = static_cast<float *>(pb_scratch(ctx, "pipe.g0x", sizeof(float) * n));
-        g0y = static_cast<float *>(pb_scratch(ctx, "pipe.g0y", sizeof(float) * n));
+        g0x = pb_scratch(ctx, "pipe.g0x", dsize(g_dtype) * n);
+        g0y = pb_scratch(ctx, "pipe.g0y", dsize(g_dtype) * n);
         nM = static_cast<float *>(pb_scratch(ctx, "inv.nM", sizeof(float) * g.P));
         if (!g0x || !g0y || !nM) return PB_ERR_NOMEM;
         const float *in32 = static_cast<const float *>(in);
@@ -745,9 +752,9 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
             if (rc) return rc;
             in32 = conv;
         }
-        rc = pb_fourier_gradients_impl(ctx, in32, g.P, H, W, g0x, g0y);
+        rc = pb_fourier_gradients_typed(ctx, in32, g.P, H, W, g0x, g0y, g_dtype);
         if (rc) return rc;
-        rc = pb_grad_energy(ctx, g0x, g0y, nM, g.P, g.HW);
+        rc = pb_grad_energy(ctx, g0x, g0y, nM, g.P, g.HW, g_dtype);
         if (rc) return rc;
     }
     float *smooth = nullptr, *ybuf = nullptr;
@@ -802,7 +809,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         }
         if (opt->prefilter == PB_PREFILTER_NONE) {
             rc = inverse_filter(ctx, g, cur, cur_dtype, dst, dst_dtype, info, opt->alpha, opt->beta, opt->boundary,
-                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1);
+                                opt->edgetaping, opt->remove_halo, g0x, g0y, nM, 1, nullptr, 0, nullptr, g_dtype);
             if (rc) return rc;
         } else {
             if (opt->prefilter == PB_PREFILTER_BILATERAL)
@@ -814,7 +821,7 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
             if (rc) return rc;
             if (opt->remove_halo) {                 // the halo kernel recombines as it stores: no ybuf round trip
                 rc = inverse_filter(ctx, g, smooth, PB_F32, dst, dst_dtype, info, opt->alpha, opt->beta, opt->boundary,
-                                    opt->edgetaping, 1, g0x, g0y, nM, 1, cur, cur_dtype, smooth);
+                                    opt->edgetaping, 1, g0x, g0y, nM, 1, cur, cur_dtype, smooth, g_dtype);
                 if (rc) return rc;
             } else {
                 rc = inverse_filter(ctx, g, smooth, PB_F32, ybuf, PB_F32, info, opt->alpha, opt->beta, opt->boundary,

@@ -287,6 +287,8 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 int pb_make_sep_records(pb_ctx *ctx, int B, const pb_blur_info *dev_info, pb_blur_info *sep, int support, int ksize);
 int pb_kernel_size(const pb_options *opt);      // validated ker_size (2 .. PB_KSIZE_MAX; above PB_KSIZE: conv_big.hip's path); 0 if unsupported
 int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy);
+int pb_fourier_gradients_typed(pb_ctx *ctx, const float *planes, int P, int H, int W, void *gx, void *gy, int out_dtype);   // PB_F16: __half planes out
+bool pb_gradient_planes_half(pb_ctx *ctx, int H, int W);       // whether this context's line transforms can write __half planes for H x W
 int pb_make_kernels_dev(pb_ctx *ctx, int B, pb_blur_info *dev_info, int support, int from_taps, int ksize = PB_KSIZE);
 
 // ------------------------------------------------------------------------------------

@@ -1629,13 +1629,14 @@ static const FftPlan *rows_plan(pb_ctx *ctx, int n) {
 }
 
 int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W, bool normalize,
-                const unsigned *mm, int planes_per_image) {
+                const unsigned *mm, int planes_per_image, int gx_dtype = PB_F32) {      // (gx_dtype PB_F16: __half planes behind `gx`, fixed-plan kernels only)
     const long blocks = (long)P * ((H + 1) / 2);
     const FftPlan *pl = rows_plan(ctx, W);
     if (!pl) return PB_ERR_NOMEM;
     const size_t lds = fft_lds_bytes(pl, 1);
     const pbfft::DevPlan dp = dev_plan(pl);
     if (lds > kMaxLds) {                            // the line buffer in global memory, one slot per workgroup
+        if (gx_dtype != PB_F32) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "row transform: fp16 planes out of the compiled-plan kernels only");
         if (!pb_fft_length_supported(W)) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "image width %d: lines of up to %d samples are supported", W, kMaxLineLength);
         const long grid = long_grid(blocks, lds);
         float2 *slots = static_cast<float2 *>(pb_scratch(ctx, "fft.long", (size_t)grid * lds));
@@ -1663,9 +1664,10 @@ int launch_rows(pb_ctx *ctx, const float *planes, float *gx, int P, int H, int W
     // (line lengths whose plan is compiled in -- lines_fixed.hip: 3840, 1920, 7680 --: the same butterflies in a one-plan kernel
     // on a padded LDS line; PB_ROWS_FIXED=0: this file's kernel, the tests' reference)
     if (fused && !normalize && ctx->rows_fixed) {
-        const int rcf = pb_launch_rows_fixed(ctx, planes, 0, nullptr, gx, nullptr, P, H, W, nth, pl);
+        const int rcf = pb_launch_rows_fixed(ctx, planes, 0, nullptr, gx, nullptr, P, H, W, nth, pl, gx_dtype);
         if (rcf != PB_ERR_UNSUPPORTED) return rcf;
     }
+    if (gx_dtype != PB_F32) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "row transform: fp16 planes out of the compiled-plan kernels only");
     if (!fused) PB_ROWS(256, false);
     else if (nth == 128) PB_ROWS(128, true);
     else if (nth == 512) PB_ROWS(512, true);
@@ -1729,7 +1731,7 @@ int launch_gray_rows(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
 
 int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, int P, int H, int W, int mode,
                 bool normalize, const unsigned *mm, int planes_per_image, unsigned *mags, int n_angles,
-                int discard_sat) {
+                int discard_sat, int gy_dtype = PB_F32) {                           // (gy_dtype PB_F16: as launch_rows)
     // (the 1024-thread variants of the gy-writing and the 7-direction kernels exist with the radices above 16)
     const bool ext_variant = mode == 0 || (mode == 1 && n_angles == 6);
     const FftPlan *pl = pb_get_plan(ctx, H, ext_variant);
@@ -1792,6 +1794,11 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
         const int rcf = pb_launch_cols_fixed(ctx, planes, gx, P, H, W, lognb, mags, n_angles, discard_sat, pl);
         if (rcf != PB_ERR_UNSUPPORTED) return rcf;
     }
+    if (mode == 0 && !normalize && ctx->cols_fixed && !through_memory) {
+        const int rcf = pb_launch_cols_fixed(ctx, planes, nullptr, P, H, W, lognb, nullptr, 0, 0, pl, gy, gy_dtype);
+        if (rcf != PB_ERR_UNSUPPORTED) return rcf;
+    }
+    if (gy_dtype != PB_F32) return pb_fail(ctx, PB_ERR_UNSUPPORTED, "column transform: fp16 planes out of the compiled-plan kernels only");
 #define PB_COLS(MODE, NA)                                                                                        \
     do {                                                                                                         \
         int rc = allow_lds(ctx, grad_cols_kernel<MODE, NA, NT>, lds);                                            \
@@ -1858,10 +1865,20 @@ int launch_cols(pb_ctx *ctx, const float *planes, const float *gx, float *gy, in
 }  // namespace
 
 int pb_fourier_gradients_impl(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy) {
+    return pb_fourier_gradients_typed(ctx, planes, P, H, W, gx, gy, PB_F32);
+}
+
+// out_dtype PB_F16: gx / gy are __half planes (pb_gradient_planes_half says whether this context builds them for the shape)
+int pb_fourier_gradients_typed(pb_ctx *ctx, const float *planes, int P, int H, int W, void *gx, void *gy, int out_dtype) {
     if (P <= 0 || H < 2 || W < 2) return pb_fail(ctx, PB_ERR_BADARG, "fourier_gradients: bad shape");
-    if (gx) { int rc = launch_rows(ctx, planes, gx, P, H, W, false, nullptr, 1); if (rc) return rc; }
-    if (gy) { int rc = launch_cols(ctx, planes, nullptr, gy, P, H, W, 0, false, nullptr, 1, nullptr, 0, 0); if (rc) return rc; }
+    if (gx) { int rc = launch_rows(ctx, planes, static_cast<float *>(gx), P, H, W, false, nullptr, 1, out_dtype); if (rc) return rc; }
+    if (gy) { int rc = launch_cols(ctx, planes, nullptr, static_cast<float *>(gy), P, H, W, 0, false, nullptr, 1, nullptr, 0, 0, out_dtype); if (rc) return rc; }
     return PB_OK;
+}
+
+bool pb_gradient_planes_half(pb_ctx *ctx, int H, int W) {
+    return ctx->cols_fixed && ctx->rows_fixed && ctx->fft_lognb < 0 && ctx->fft_first < 0 && ctx->fft_first_rows < 0 &&
+           ctx->fft_ext_radix != 0 && pb_lines_fixed_shape(H, W);
 }
 
 int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H, int W, const pb_options *opt,

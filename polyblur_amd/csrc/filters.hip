@@ -15,13 +15,17 @@ constexpr int NT = 256;
 // halo masking
 // ------------------------------------------------------------------------------------
 // nM[plane] = sum_{H,W} gx^2 + gy^2          (deblurring.py:178-179,206)
-__global__ __launch_bounds__(NT) void grad_energy_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
+template <typename TG>
+__global__ __launch_bounds__(NT) void grad_energy_kernel(const TG *__restrict__ gx, const TG *__restrict__ gy,
                                                          float *__restrict__ partial, long HW, int blocks_per_plane) {
     const int plane = blockIdx.x / blocks_per_plane;
     const int blk = blockIdx.x - plane * blocks_per_plane;
-    const float *a = gx + (long)plane * HW, *b = gy + (long)plane * HW;
+    const TG *a = gx + (long)plane * HW, *b = gy + (long)plane * HW;
     float s = 0.f;
-    for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)blocks_per_plane * NT) s += a[i] * a[i] + b[i] * b[i];
+    for (long i = (long)blk * NT + threadIdx.x; i < HW; i += (long)blocks_per_plane * NT) {
+        const float u = pb_ld(a + i), v = pb_ld(b + i);
+        s += u * u + v * v;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     __shared__ float red[NT / 64];
@@ -48,10 +52,13 @@ __global__ __launch_bounds__(64) void grad_energy_fold_kernel(const float *__res
 // z = max(M / (nM + M), 0);  out = y + z (x - y)   [+ clamp to [0,1], deblurring.py:239]
 // With a prefilter the masked result is recombined on the spot (cur != nullptr; recombine_kernel's arithmetic):
 // out = clip(clip(out, 0, 1) + (cur - smooth), 0, 1) -- one pass over the batch instead of a store, a load and a pass.
-template <typename TX, typename TOut>
+// TG: the type the three gradient planes are kept in -- fp32, or fp16 where the call's images are fp16 (z = M / (nM + M) is a
+// ratio of one sample's products to the whole plane's energy, ~1e-5 on an image: an fp16 rounding of its factors moves the
+// output by ~1e-9, and the three planes are 12 of the 28 bytes this kernel moves per sample)
+template <typename TX, typename TOut, typename TG>
 __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int x_pitch, long x_plane,
-                                                  const float *__restrict__ y, const float *__restrict__ gx,
-                                                  const float *__restrict__ gy, const float *__restrict__ ox,
+                                                  const float *__restrict__ y, const TG *__restrict__ gx,
+                                                  const TG *__restrict__ gy, const TG *__restrict__ ox,
                                                   const float *__restrict__ nM, TOut *__restrict__ out, int P, int H, int W,
                                                   int clamp01, const void *__restrict__ cur, int cur_is_half,
                                                   const float *smooth) {
@@ -61,8 +68,8 @@ __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int 
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
         const int r = (int)(i / W), c = (int)(i - (long)r * W);
         const long k = (long)plane * HW + i;
-        const float gxx = gx[k], gyy = gy[k];
-        const float M = (-gxx * ox[k]) + (-gyy * gyy);
+        const float gxx = pb_ld(gx + k), gyy = pb_ld(gy + k);
+        const float M = (-gxx * pb_ld(ox + k)) + (-gyy * gyy);
         const float z = fmaxf(M / (nm + M), 0.f);
         const float xv = pb_ld(x + (long)plane * x_plane + (long)r * x_pitch + c);
         const float yv = y[k];
@@ -685,35 +692,40 @@ unsigned grid_for(long n, int per_block = NT, int cap = 8192) {
 }  // namespace
 
 // ---- internal entry points used by api.hip --------------------------------------------------
-int pb_grad_energy(pb_ctx *ctx, const float *gx, const float *gy, float *nM, int P, long HW) {
+int pb_grad_energy(pb_ctx *ctx, const void *gx, const void *gy, float *nM, int P, long HW, int g_dtype) {
     ProfScope prof(ctx, PB_PROF_HALO);
     int bpp = (int)((HW + NT * 16 - 1) / (NT * 16));
     if (bpp > 256) bpp = 256;
     if (bpp < 1) bpp = 1;
     float *partial = static_cast<float *>(pb_scratch(ctx, "halo.partial", sizeof(float) * (size_t)P * bpp));
     if (!partial) return PB_ERR_NOMEM;
-    hipLaunchKernelGGL(grad_energy_kernel, dim3(P * bpp), dim3(NT), 0, ctx->stream, gx, gy, partial, HW, bpp);
+    if (g_dtype == PB_F16)
+        hipLaunchKernelGGL(grad_energy_kernel<__half>, dim3(P * bpp), dim3(NT), 0, ctx->stream, static_cast<const __half *>(gx), static_cast<const __half *>(gy), partial, HW, bpp);
+    else
+        hipLaunchKernelGGL(grad_energy_kernel<float>, dim3(P * bpp), dim3(NT), 0, ctx->stream, static_cast<const float *>(gx), static_cast<const float *>(gy), partial, HW, bpp);
     hipLaunchKernelGGL(grad_energy_fold_kernel, dim3(P), dim3(64), 0, ctx->stream, partial, nM, bpp);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
 
-int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const float *gx,
-                  const float *gy, const float *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
-                  int clamp01, const void *recomb_cur, int recomb_cur_dtype, const float *recomb_smooth) {
+int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const void *gx,
+                  const void *gy, const void *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
+                  int clamp01, const void *recomb_cur, int recomb_cur_dtype, const float *recomb_smooth, int g_dtype) {
     dim3 grid(grid_for((long)H * W, NT, 2048), P < 65535 ? P : 65535);
     ProfScope prof(ctx, PB_PROF_HALO);
     if (recomb_cur && recomb_cur_dtype != PB_F32 && recomb_cur_dtype != PB_F16)
         return pb_fail(ctx, PB_ERR_BADARG, "halo: the recombined image must be fp32 or fp16");
     const int cur_is_half = recomb_cur_dtype == PB_F16;
-#define PB_HALO(TX, TO)                                                                                           \
-    hipLaunchKernelGGL((halo_kernel<TX, TO>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
-                       x_plane, y, gx, gy, ox, nM, static_cast<TO *>(out), P, H, W, clamp01, recomb_cur, cur_is_half, \
-                       recomb_smooth)
-    if (x_dtype == PB_F32 && out_dtype == PB_F32) PB_HALO(float, float);
-    else if (x_dtype == PB_F32 && out_dtype == PB_F16) PB_HALO(float, __half);
-    else if (x_dtype == PB_F16 && out_dtype == PB_F32) PB_HALO(__half, float);
-    else PB_HALO(__half, __half);
+#define PB_HALO(TX, TO, TG)                                                                                        \
+    hipLaunchKernelGGL((halo_kernel<TX, TO, TG>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
+                       x_plane, y, static_cast<const TG *>(gx), static_cast<const TG *>(gy), static_cast<const TG *>(ox), nM, \
+                       static_cast<TO *>(out), P, H, W, clamp01, recomb_cur, cur_is_half, recomb_smooth)
+#define PB_HALO_G(TX, TO) do { if (g_dtype == PB_F16) PB_HALO(TX, TO, __half); else PB_HALO(TX, TO, float); } while (0)
+    if (x_dtype == PB_F32 && out_dtype == PB_F32) PB_HALO_G(float, float);
+    else if (x_dtype == PB_F32 && out_dtype == PB_F16) PB_HALO_G(float, __half);
+    else if (x_dtype == PB_F16 && out_dtype == PB_F32) PB_HALO_G(__half, float);
+    else PB_HALO_G(__half, __half);
+#undef PB_HALO_G
 #undef PB_HALO
     PB_LAUNCH_CHECK();
     return PB_OK;

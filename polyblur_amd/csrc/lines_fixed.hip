@@ -17,6 +17,8 @@
 #include "fft.h"
 #include "lines_fixed.h"
 
+#include <type_traits>
+
 namespace {
 
 using pbfft::cf;
@@ -102,9 +104,15 @@ __device__ __forceinline__ void fold7(float (&best)[7], const AngleTable7 &ang, 
 
 // R0 x R1 x R2 = the line length; a workgroup = 2 << LOGNB adjacent columns of all rows of one plane.
 // TWLDS: the line's twiddle table in LDS behind the tile.  SAT: gradients under the saturation mask (gray > thr) are zero.
-template <int R0, int R1, int R2, int LOGNB, int NTH, bool TWLDS, bool SAT>
+// TGY = void: fold the directional maxima (grad_cols_kernel's MODE 1); float / __half: store the derivative instead (MODE 0:
+// gray = any float planes, gy_out = their y derivative -- the gradients halo masking keeps of the input image).
+template <typename T> __device__ __forceinline__ void st_pair(T *p, float a, float b);
+template <> __device__ __forceinline__ void st_pair<float>(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
+template <> __device__ __forceinline__ void st_pair<__half>(__half *p, float a, float b) { *reinterpret_cast<__half2 *>(p) = __floats2half2_rn(a, b); }
+
+template <int R0, int R1, int R2, int LOGNB, int NTH, bool TWLDS, bool SAT, typename TGY>
 __global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict__ gray, const float *__restrict__ gx, int W,
-                                                         unsigned *__restrict__ mags, int total_tiles,
+                                                         unsigned *__restrict__ mags, TGY *__restrict__ gy_out, int total_tiles,
                                                          const float2 *__restrict__ tw_g, const float *__restrict__ drev,
                                                          AngleTable7 ang, float thr) {
     constexpr int N = R0 * R1 * R2, NB = 1 << LOGNB, TC = 2 * NB;
@@ -161,6 +169,28 @@ __global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict
     __syncthreads();
     fstage<R1, true, N, R1 * R2, LOGNB, NTH>(s, tw);
     __syncthreads();
+    if constexpr (!std::is_void<TGY>::value) {
+        // ---- last stage, storing d/dy (pbfft::last_stage<R0> with ColsIO<0>) ----------------------------------------------------
+        constexpr int M = N / R0, STRIDE = M << LOGNB;
+        TGY *dst = gy_out + plane_off;
+#pragma unroll 1
+        for (int w = threadIdx.x; w < STRIDE; w += NTH) {
+            const int j = w & (NB - 1), np = w >> LOGNB;
+            const long idx0 = (long)np * W + c0 + 2 * j;
+            cf v[R0];
+            const cf *base = reinterpret_cast<const cf *>(s) + w;
+#pragma unroll
+            for (int q = 0; q < R0; ++q) v[q] = base[q * STRIDE];
+            cf wq[R0];
+            pbfft::twiddle_powers<R0>(wq, tw, np);
+#pragma unroll
+            for (int q = 1; q < R0; ++q) v[q] = pbfft::cmul(v[q], wq[q]);
+            pbfft::dft_small<R0>(v);
+#pragma unroll
+            for (int q = 0; q < R0; ++q) st_pair<TGY>(dst + idx0 + (long)q * M * W, v[q].x, -v[q].y);
+        }
+        return;
+    }
     // ---- last stage + maxima (pbfft::last_stage<R0> with ColsIO<1, 7>) ------------------------------------------------------
     float best[7];
 #pragma unroll
@@ -303,8 +333,8 @@ struct PlainIn {
     __device__ __forceinline__ float2 load(int p) const { return make_float2(row0[p], has1 ? row0[W + p] : 0.f); }
 };
 
-template <int R0, int R1, int R2, int NTH, class IN>
-__device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, float *o0, int W, bool has1, const float2 *__restrict__ tw,
+template <int R0, int R1, int R2, int NTH, class IN, typename TO>
+__device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, TO *o0, int W, bool has1, const float2 *__restrict__ tw,
                                                 const float *__restrict__ drev) {
     constexpr int N = R0 * R1 * R2, M = N / R0;
     // first stage: pbfft::first_stage<R0>
@@ -341,8 +371,8 @@ __device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, float *o0, int W,
         pbfft::dft_small<R0>(v);
 #pragma unroll
         for (int q = 0; q < R0; ++q) {
-            o0[np + q * M] = v[q].x;
-            if (has1) o0[W + np + q * M] = -v[q].y;
+            pb_st(o0 + np + q * M, v[q].x);
+            if (has1) pb_st(o0 + W + np + q * M, -v[q].y);
         }
     }
 }
@@ -385,8 +415,8 @@ __global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void gray_rows_
     }
 }
 
-template <int R0, int R1, int R2, int NTH>
-__global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void grad_rows_fixed_kernel(const float *__restrict__ planes, float *__restrict__ gx, int H,
+template <int R0, int R1, int R2, int NTH, typename TO>
+__global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void grad_rows_fixed_kernel(const float *__restrict__ planes, TO *__restrict__ gx, int H,
                                                                                      const float2 *__restrict__ tw, const float *__restrict__ drev) {
     constexpr int W = R0 * R1 * R2;
     extern __shared__ __attribute__((aligned(16))) float2 sfft[];
@@ -399,21 +429,24 @@ __global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void grad_rows_
 
 template <int R0, int R1, int R2, int LOGNB, int NTH, bool TWLDS>
 int launch_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int W, unsigned *mags, bool sat, const FftPlan *pl,
-                 const AngleTable7 &ang) {
+                 const AngleTable7 &ang, void *gy_out = nullptr, int gy_dtype = PB_F32) {
     constexpr int N = R0 * R1 * R2, NB = 1 << LOGNB;
     constexpr size_t lds = (size_t)((N * NB * 8 + 1023) / 1024) * 1024 + (TWLDS ? (size_t)((N * 8 + 1023) / 1024) * 1024 : 0);
     static_assert(lds <= 160 * 1024, "tile + twiddle table beyond LDS");
     const long blocks = (long)P * (W / (2 * NB));
     if (blocks > 0x7fffffffL) return PB_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)((blocks + 7) / 8 * 8);
-#define PB_LAUNCH_FIXED(SAT)                                                                                                     \
+#define PB_LAUNCH_FIXED(SAT, TGY)                                                                                                \
     do {                                                                                                                         \
-        auto k = cols_fixed_kernel<R0, R1, R2, LOGNB, NTH, TWLDS, SAT>;                                                          \
+        auto k = cols_fixed_kernel<R0, R1, R2, LOGNB, NTH, TWLDS, SAT, TGY>;                                                     \
         PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), lds, ctx->stream, gray, gx, W, mags, (int)blocks, pl->tw, pl->drev, ang, 0.99f); \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NTH), lds, ctx->stream, gray, gx, W, mags, static_cast<TGY *>(gy_out), (int)blocks, \
+                           pl->tw, pl->drev, ang, 0.99f);                                                                        \
     } while (0)
-    if (sat) PB_LAUNCH_FIXED(true);
-    else PB_LAUNCH_FIXED(false);
+    if (gy_out && gy_dtype == PB_F16) PB_LAUNCH_FIXED(false, __half);
+    else if (gy_out) PB_LAUNCH_FIXED(false, float);
+    else if (sat) PB_LAUNCH_FIXED(true, void);
+    else PB_LAUNCH_FIXED(false, void);
 #undef PB_LAUNCH_FIXED
     PB_LAUNCH_CHECK();
     return PB_OK;
@@ -427,18 +460,18 @@ int launch_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int W, 
 // that fills the chip (1024 threads, one workgroup per CU) and the narrow one of a lone image (512 threads, two per CU) -- and
 // what decides between this file and grad_cols_kernel is the image's own shape and the options alone.
 int pb_launch_cols_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int H, int W, int lognb, unsigned *mags,
-                         int n_angles, int discard_sat, const FftPlan *pl) {
-    if (n_angles != 6 || !pl || pl->bluestein_m || pl->nstage != 3 || pl->n != H || lognb < 1 || (W % (2 << lognb)) != 0)
+                         int n_angles, int discard_sat, const FftPlan *pl, void *gy_out, int gy_dtype) {
+    if ((!gy_out && n_angles != 6) || !pl || pl->bluestein_m || pl->nstage != 3 || pl->n != H || lognb < 1 || (W % (2 << lognb)) != 0)
         return PB_ERR_UNSUPPORTED;
     AngleTable7 ang;
     for (int k = 0; k < 7; ++k) {
-        const float t = 3.14159265358979323846f * (float)k / (float)n_angles;       // (as launch_cols)
+        const float t = n_angles > 0 ? 3.14159265358979323846f * (float)k / (float)n_angles : 0.f;       // (as launch_cols)
         ang.cs[k] = std::cos(t);
         ang.sn[k] = std::sin(t);
     }
     const int r0 = pl->radix[0], r1 = pl->radix[1], r2 = pl->radix[2];
     const bool sat = discard_sat != 0;
-#define PB_FIXED(R0, R1, R2, LOGNB, NTH, TWLDS) return launch_fixed<R0, R1, R2, LOGNB, NTH, TWLDS>(ctx, gray, gx, P, W, mags, sat, pl, ang)
+#define PB_FIXED(R0, R1, R2, LOGNB, NTH, TWLDS) return launch_fixed<R0, R1, R2, LOGNB, NTH, TWLDS>(ctx, gray, gx, P, W, mags, sat, pl, ang, gy_out, gy_dtype)
     if (H == 2160 && r0 == 9 && r1 == 16 && r2 == 15) {
         if (lognb == 3) PB_FIXED(9, 16, 15, 3, 1024, true);
         if (lognb == 2) PB_FIXED(9, 16, 15, 2, 512, false);        // (69 KB of tile: two workgroups per CU, no room for the table)
@@ -458,8 +491,9 @@ int pb_launch_cols_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P,
 // The row transform of W-sample lines with the plan compiled in; C == 0: a float plane as it is (in = P planes of H x W),
 // else gray + range partials + transform from the image's C channels (in = B images; part: B x pairs partials).
 // nth: the thread count estimate.hip:rows_threads gives the launch.  PB_ERR_UNSUPPORTED: not compiled -- the caller runs its own.
-int pb_launch_rows_fixed(pb_ctx *ctx, const float *in, int C, float *gray, float *gx, float2 *part, long images, int H, int W, int nth,
-                         const FftPlan *pl) {
+int pb_launch_rows_fixed(pb_ctx *ctx, const float *in, int C, float *gray, void *gx, float2 *part, long images, int H, int W, int nth,
+                         const FftPlan *pl, int gx_dtype) {
+    if (gx_dtype != PB_F32 && !(gx_dtype == PB_F16 && C == 0)) return PB_ERR_UNSUPPORTED;
     if (!pl || pl->bluestein_m || pl->nstage != 3 || pl->n != W || (C != 0 && C != 1 && C != 3)) return PB_ERR_UNSUPPORTED;
     const long blocks = images * ((H + 1) / 2);
     if (blocks > 0x7fffffffL || blocks < 1) return PB_ERR_UNSUPPORTED;
@@ -467,18 +501,22 @@ int pb_launch_rows_fixed(pb_ctx *ctx, const float *in, int C, float *gray, float
 #define PB_ROWS_FIXED(R0, R1, R2, NTH)                                                                                              \
     do {                                                                                                                            \
         constexpr size_t lds = rows_lds_bytes(R0 * R1 * R2);                                                                        \
-        if (C == 0) {                                                                                                               \
-            auto k = grad_rows_fixed_kernel<R0, R1, R2, NTH>;                                                                       \
+        if (C == 0 && gx_dtype == PB_F16) {                                                                                         \
+            auto k = grad_rows_fixed_kernel<R0, R1, R2, NTH, __half>;                                                               \
             if (lds > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gx, H, pl->tw, pl->drev);                \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, static_cast<__half *>(gx), H, pl->tw, pl->drev); \
+        } else if (C == 0) {                                                                                                        \
+            auto k = grad_rows_fixed_kernel<R0, R1, R2, NTH, float>;                                                                \
+            if (lds > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, static_cast<float *>(gx), H, pl->tw, pl->drev); \
         } else if (C == 3) {                                                                                                        \
             auto k = gray_rows_fixed_kernel<R0, R1, R2, NTH, 3>;                                                                    \
             if (lds > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gray, gx, part, H, pl->tw, pl->drev);    \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gray, static_cast<float *>(gx), part, H, pl->tw, pl->drev);    \
         } else {                                                                                                                    \
             auto k = gray_rows_fixed_kernel<R0, R1, R2, NTH, 1>;                                                                    \
             if (lds > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gray, gx, part, H, pl->tw, pl->drev);    \
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NTH), lds, ctx->stream, in, gray, static_cast<float *>(gx), part, H, pl->tw, pl->drev);    \
         }                                                                                                                           \
         PB_LAUNCH_CHECK();                                                                                                          \
         return PB_OK;                                                                                                               \
@@ -494,4 +532,8 @@ int pb_launch_rows_fixed(pb_ctx *ctx, const float *in, int C, float *gray, float
     if (W == 7680 && r0 == 16 && r1 == 20 && r2 == 24 && nth == 512) PB_ROWS_FIXED(16, 20, 24, 512);
 #undef PB_ROWS_FIXED
     return PB_ERR_UNSUPPORTED;
+}
+
+bool pb_lines_fixed_shape(int H, int W) {
+    return (H == 2160 || H == 1080 || H == 4320) && (W == 3840 || W == 1920 || W == 7680);
 }

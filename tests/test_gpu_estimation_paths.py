@@ -134,3 +134,21 @@ def test_fixed_plan_rows_are_bit_identical(engines, runtime_plan_rows_engine, sh
     if H * W <= 1080 * 1920:
         rx, ry = ref.spectral_gradients(planes[None])
         assert np.max(np.abs(gxb - rx[0])) < 2e-5 and np.max(np.abs(gyb - ry[0])) < 2e-5
+
+
+def test_half_gradient_planes_of_an_fp16_call(engines, runtime_plan_engine):
+    """an fp16 call with remove_halo keeps grad_img's two planes and every iteration's d/dx of the deblurred
+    image as fp16 planes where the compiled-plan line transforms can write them (csrc/filters.hip: halo_kernel's TG) -- z = M /
+    (nM + M) is ~1e-5 on an image, so the fp16 rounding of its factors is far below the fp16 output's own rounding.  Against
+    the same call with fp32 planes (a context whose column transforms are the run-time-plan kernels: no typed outputs) and
+    against the oracle on the fp16-rounded input (deblurring.py:193-208), at the fp16 tolerance of every other test."""
+    x, _ = synthetic_blurry_batch(2, 3, 1080, 1920, seed0=47)
+    x16 = x.astype(np.float16)
+    kw = dict(n_iter=2, c=0.362, b=0.468, alpha=6.0, beta=1.0, remove_halo=True)
+    a, ia = engines["default"].polyblur(x16, engines["default"].make_options(**kw), want_info=True)
+    b, ib = runtime_plan_engine.polyblur(x16, runtime_plan_engine.make_options(**kw), want_info=True)
+    assert np.array_equal(ia["theta"], ib["theta"])
+    d = np.abs(a.astype(np.float32) - b.astype(np.float32))
+    assert d.max() <= 1.0 / 1024 and np.mean(d > 0) < 1e-3, (float(d.max()), float(np.mean(d > 0)))    # at most one fp16 step, on a handful of samples
+    want = ref.polyblur_deblurring(x16[:1].astype(np.float32), n_iter=2, c=0.362, b=0.468, alpha=6, beta=1, remove_halo=True)
+    assert np.max(np.abs(a[:1].astype(np.float32) - want)) < 1e-3
