@@ -18,6 +18,9 @@ resident run also carries a short from_root measurement in `context` (SURVEY 8e:
 the timed region is bracketed by a barrier + device synchronise on both sides and the maximum over ranks is
 reported.
 
+Between the W warm-up steps and the K timed steps the device gets ~60 ms of the same (untimed) steps to settle its clocks
+(`settle_steps` in the line): the timed region of a 4K run is 10 ms, and without them its first steps run 5 % slow.
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      -- the dominant kernel class (the reblurring pass), from hipEvents on the engine's stream around every
                    launch of a second, identical run of the K steps (the headline `value` is timed without them).
@@ -270,6 +273,20 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    # The device's clocks need tens of milliseconds of work to settle (a 4K step is 0.5 ms: behind W = 5 warm-up steps the
+    # first timed steps of round 5's line still ran 5 % slow -- VERDICT r5 weak #11, mean against median of the same run).
+    # Untimed steps until ~60 ms of work have been issued and finished; how many is in the line (`settle_steps`).
+    settle_steps = 0
+    if not from_root:
+        sync_all()
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < 0.06 and settle_steps < 400:
+            for _ in range(4):
+                out = step()
+            torch.cuda.synchronize(dev)
+            settle_steps += 4
+        if use_dist:                                                       # every rank settles the same number of steps' worth of time; then all start together
+            dist.barrier()
     dt, out = timed(args.steps, step)                                      # the headline: no per-launch events
     ms_per_step = 1e3 * dt / args.steps
     mp_per_step = B * H * W * world / 1e6
@@ -740,7 +757,7 @@ def main():
         desc += ", " + ", ".join("%s=%s" % kv for kv in sorted(cfg["opts"].items()))
     line = {
         "metric": "megapixels/sec (n_iter=3, alpha=6, beta=1)", "value": round(value, 1), "unit": "MP/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps, "ms_per_step": round(ms_per_step, 4),
         "ms_per_step_device": (dict(median=round(step_ms[len(step_ms) // 2], 4), min=round(step_ms[0], 4), max=round(step_ms[-1], 4),
                                     n=len(step_ms), note="one event between steps, device time; `value` is the contract's total / K")
                                if step_ms else None),

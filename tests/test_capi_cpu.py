@@ -64,7 +64,7 @@ def test_argument_validation_before_any_device_work():
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=31, edgetaping=True)
     with pytest.raises(NotImplementedError):
-        polyblur_deblurring(x, ker_size=12, edgetaping=True)
+        polyblur_deblurring(x, ker_size=12, method="direct_separable")     # (an even size with edgetaping is built since round 6)
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, method="direct_separable", edgetaping=True)
     with pytest.raises(ValueError):
