@@ -55,7 +55,26 @@ __global__ __launch_bounds__(64) void grad_energy_fold_kernel(const float *__res
 // TG: the type the three gradient planes are kept in -- fp32, or fp16 where the call's images are fp16 (z = M / (nM + M) is a
 // ratio of one sample's products to the whole plane's energy, ~1e-5 on an image: an fp16 rounding of its factors moves the
 // output by ~1e-9, and the three planes are 12 of the 28 bytes this kernel moves per sample)
-template <typename TX, typename TOut, typename TG>
+// four consecutive samples of a plane as floats (16 bytes of fp32, 8 of fp16): the streaming kernels' unit where rows allow it
+template <typename T> __device__ __forceinline__ float4 ld4v(const T *p);
+template <> __device__ __forceinline__ float4 ld4v<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 ld4v<__half>(const __half *p) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&u.x)), b = __half22float2(*reinterpret_cast<const __half2 *>(&u.y));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+template <typename T> __device__ __forceinline__ void st4v(T *p, float4 v);
+template <> __device__ __forceinline__ void st4v<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+template <> __device__ __forceinline__ void st4v<__half>(__half *p, float4 v) {
+    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+    uint2 u;
+    u.x = *reinterpret_cast<const unsigned *>(&a); u.y = *reinterpret_cast<const unsigned *>(&b);
+    *reinterpret_cast<uint2 *>(p) = u;
+}
+
+// VEC: every plane's rows start on a boundary of four samples (W, the x operand's pitch and plane stride multiples of 4): four
+// samples per thread and trip -- the same operations per sample, 16-byte (fp16: 8-byte) accesses, no 64-bit division per sample
+template <typename TX, typename TOut, typename TG, bool VEC>
 __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int x_pitch, long x_plane,
                                                   const float *__restrict__ y, const TG *__restrict__ gx,
                                                   const TG *__restrict__ gy, const TG *__restrict__ ox,
@@ -63,17 +82,54 @@ __global__ __launch_bounds__(NT) void halo_kernel(const TX *__restrict__ x, int 
                                                   int clamp01, const void *__restrict__ cur, int cur_is_half,
                                                   const float *smooth) {
     const long HW = (long)H * W;
+    if constexpr (VEC) {
+        const int W4 = W >> 2;
+        const long n4 = HW >> 2;
+        for (int plane = blockIdx.y; plane < P; plane += gridDim.y) {
+            const float nm = nM[plane];
+            for (long i4 = (long)blockIdx.x * NT + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * NT) {
+                const int r = (int)((unsigned)i4 / (unsigned)W4), c = 4 * ((int)i4 - r * W4);       // (H W / 4 < 2^32: sides up to 65536)
+                const long k = (long)plane * HW + 4 * i4;
+                const float4 gxx = ld4v(gx + k), gyy = ld4v(gy + k), oxx = ld4v(ox + k), yv = ld4v(y + k);
+                const float4 xv = ld4v(x + (long)plane * x_plane + (long)r * x_pitch + c);
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f), sm = cv;
+                if (cur) {
+                    cv = cur_is_half ? ld4v(static_cast<const __half *>(cur) + k) : ld4v(static_cast<const float *>(cur) + k);
+                    sm = ld4v(smooth + k);
+                }
+                const float g1[4] = {gxx.x, gxx.y, gxx.z, gxx.w}, g2[4] = {gyy.x, gyy.y, gyy.z, gyy.w}, o1[4] = {oxx.x, oxx.y, oxx.z, oxx.w};
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+                const float cs[4] = {cv.x, cv.y, cv.z, cv.w}, ss[4] = {sm.x, sm.y, sm.z, sm.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float M = fmaf(-g1[e], o1[e], -__fmul_rn(g2[e], g2[e]));      // (roundings written out: both forms of the kernel give the same bits)
+                    const float z = fmaxf(M / (nm + M), 0.f);
+                    float v = fmaf(z, xs[e] - ys[e], ys[e]);
+                    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+                    if (cur) {
+                        const float d = cs[e] - ss[e];
+                        v = fminf(fmaxf(v, 0.f), 1.f) + d;
+                        v = fminf(fmaxf(v, 0.f), 1.f);
+                    }
+                    o[e] = v;
+                }
+                st4v(out + k, make_float4(o[0], o[1], o[2], o[3]));
+            }
+        }
+        return;
+    }
     for (int plane = blockIdx.y; plane < P; plane += gridDim.y) {      // (grid.y is capped at 65535)
     const float nm = nM[plane];
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
         const int r = (int)(i / W), c = (int)(i - (long)r * W);
         const long k = (long)plane * HW + i;
         const float gxx = pb_ld(gx + k), gyy = pb_ld(gy + k);
-        const float M = (-gxx * pb_ld(ox + k)) + (-gyy * gyy);
+        const float M = fmaf(-gxx, pb_ld(ox + k), -__fmul_rn(gyy, gyy));
         const float z = fmaxf(M / (nm + M), 0.f);
         const float xv = pb_ld(x + (long)plane * x_plane + (long)r * x_pitch + c);
         const float yv = y[k];
-        float v = yv + z * (xv - yv);
+        float v = fmaf(z, xv - yv, yv);
         if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
         if (cur) {
             const float cv = cur_is_half ? pb_ld(static_cast<const __half *>(cur) + k) : static_cast<const float *>(cur)[k];
@@ -711,15 +767,21 @@ int pb_grad_energy(pb_ctx *ctx, const void *gx, const void *gy, float *nM, int P
 int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_plane, const float *y, const void *gx,
                   const void *gy, const void *ox, const float *nM, void *out, int out_dtype, int P, int H, int W,
                   int clamp01, const void *recomb_cur, int recomb_cur_dtype, const float *recomb_smooth, int g_dtype) {
-    dim3 grid(grid_for((long)H * W, NT, 2048), P < 65535 ? P : 65535);
+    // four samples per thread where every row of every plane starts on a boundary of four samples (and x's first sample does:
+    // the interior of a padded plane starts pad (pp + 1) samples in)
+    const size_t xb = x_dtype == PB_F16 ? 2 : 4;
+    const bool vec = (W & 3) == 0 && (x_pitch & 3) == 0 && (x_plane & 3) == 0 && (reinterpret_cast<size_t>(x) % (4 * xb)) == 0 &&
+                     (long)H * W / 4 < 0xffffffffL;
+    dim3 grid(grid_for((long)H * W / (vec ? 4 : 1), NT, 2048), P < 65535 ? P : 65535);
     ProfScope prof(ctx, PB_PROF_HALO);
     if (recomb_cur && recomb_cur_dtype != PB_F32 && recomb_cur_dtype != PB_F16)
         return pb_fail(ctx, PB_ERR_BADARG, "halo: the recombined image must be fp32 or fp16");
     const int cur_is_half = recomb_cur_dtype == PB_F16;
-#define PB_HALO(TX, TO, TG)                                                                                        \
-    hipLaunchKernelGGL((halo_kernel<TX, TO, TG>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
+#define PB_HALO_V(TX, TO, TG, VEC)                                                                                 \
+    hipLaunchKernelGGL((halo_kernel<TX, TO, TG, VEC>), grid, dim3(NT), 0, ctx->stream, static_cast<const TX *>(x), x_pitch, \
                        x_plane, y, static_cast<const TG *>(gx), static_cast<const TG *>(gy), static_cast<const TG *>(ox), nM, \
                        static_cast<TO *>(out), P, H, W, clamp01, recomb_cur, cur_is_half, recomb_smooth)
+#define PB_HALO(TX, TO, TG) do { if (vec) PB_HALO_V(TX, TO, TG, true); else PB_HALO_V(TX, TO, TG, false); } while (0)
 #define PB_HALO_G(TX, TO) do { if (g_dtype == PB_F16) PB_HALO(TX, TO, __half); else PB_HALO(TX, TO, float); } while (0)
     if (x_dtype == PB_F32 && out_dtype == PB_F32) PB_HALO_G(float, float);
     else if (x_dtype == PB_F32 && out_dtype == PB_F16) PB_HALO_G(float, __half);
@@ -727,6 +789,7 @@ int pb_halo_apply(pb_ctx *ctx, const void *x, int x_dtype, int x_pitch, long x_p
     else PB_HALO_G(__half, __half);
 #undef PB_HALO_G
 #undef PB_HALO
+#undef PB_HALO_V
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

@@ -187,6 +187,23 @@ def test_zero_boundary_ring_strong_blur(engines):
     assert np.array_equal(c, b)
 
 
+def test_zero_boundary_ring_at_the_default_threshold(engines):
+    """the tests above force the ring form with PB_ZERO_RING_MIN_PAIRS=1; at the DEFAULT threshold (4096
+    three-step window pairs per image: 2800 x 1600 x 3 is 4200) only bench.py's context entry ran it.  The default context on
+    such an image: the interior took a one-pass form, the result is what three steps over the whole image give (rounding
+    only) for n_iter = 3, and one iteration matches the oracle's method='direct' (filters.py:40-49; main.py:109-112)."""
+    from polyblur_amd import _capi as capi
+    x, _ = synthetic_blurry_batch(1, 3, 1600, 2800, seed0=79)
+    kw = dict(KW, boundary=capi.PB_ZERO)
+    a, _ = _run(engines["default"], x, n_iter=3, **kw)
+    s0 = engines["default"].body_selection(1, 0)
+    assert (s0[:, 0] == 1).all() and (s0[:, 3] != 0).all(), s0          # the window pass + ring form, not three plain steps
+    b, _ = _run(engines["direct_three_steps"], x, n_iter=3, **kw)
+    assert np.abs(a - b).max() < 8e-6
+    a1, _ = _run(engines["default"], x, n_iter=1, **kw)
+    assert np.abs(a1 - ref.polyblur_deblurring(x, n_iter=1, method="direct", **KW)).max() < 2e-5
+
+
 # ---- which of a plan's radices the line transforms' first / last stage take (csrc/estimate.hip: rows_plan, launch_cols) ----
 STAGE_ORDER_SHAPES = [(1, 1, 512, 512), (1, 1, 720, 1280), (1, 1, 1080, 1920), (1, 1, 700, 500), (1, 1, 1200, 1280),
                       (1, 1, 1024, 2048), (1, 1, 2160, 1440), (3, 1, 600, 360)]
