@@ -19,6 +19,61 @@
 
 #include <type_traits>
 
+// Lab build only (tools/build_variant.sh lftrace "-DPB_EXPERIMENTAL -DPB_LINES_TRACE" lines_fixed.hip): wall-clock stamps (100 MHz)
+// of the one-plan line transforms -- stage by stage from thread 0 of workgroups 0, 1/4, 1/2 and the last of the launch (the
+// first 4 x 8 slots the row kernel's, the next the column kernel's; a stamp sees its own wave), and entry / exit / XCC of
+// EVERY workgroup (exit = its stores completed) -- read by tools/lines_fixed_trace.py.  Not in the product build.
+#if defined(PB_EXPERIMENTAL) && defined(PB_LINES_TRACE)
+__device__ unsigned long long g_lines_fixed_trace[2 * 4 * 8];
+__device__ unsigned long long g_lines_fixed_span[4];
+__device__ unsigned long long g_lines_fixed_wg[2 * 2048 * 3];
+__device__ __forceinline__ void pb_lf_stamp(int kernel, int i) {
+    if (threadIdx.x != 0) return;
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    const int w = b == 0 ? 0 : (b == g / 4 ? 1 : (b == g / 2 ? 2 : (b == g - 9 ? 3 : -1)));
+    if (w >= 0) g_lines_fixed_trace[(kernel * 4 + w) * 8 + i] = wall_clock64();
+}
+__device__ __forceinline__ void pb_lf_enter(int kernel) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t = wall_clock64();
+        atomicMin(&g_lines_fixed_span[2 * kernel], t);
+        if (blockIdx.x < 2048) {
+            g_lines_fixed_wg[(kernel * 2048 + blockIdx.x) * 3] = t;
+            g_lines_fixed_wg[(kernel * 2048 + blockIdx.x) * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+        }
+    }
+}
+__device__ __forceinline__ void pb_lf_exit(int kernel) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = wall_clock64();
+        atomicMax(&g_lines_fixed_span[2 * kernel + 1], t);
+        if (blockIdx.x < 2048) g_lines_fixed_wg[(kernel * 2048 + blockIdx.x) * 3 + 1] = t;
+    }
+}
+#define PB_LF(k, i) pb_lf_stamp(k, i)
+#define PB_LF_ENTER(k) pb_lf_enter(k)
+#define PB_LF_EXIT(k) pb_lf_exit(k)
+extern "C" int pb_debug_lines_fixed_trace(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lines_fixed_trace), sizeof(unsigned long long) * 64);
+}
+extern "C" int pb_debug_lines_fixed_span(unsigned long long *host, int reset) {
+    if (reset) {
+        const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lines_fixed_span), init, sizeof(init));
+    }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lines_fixed_span), sizeof(unsigned long long) * 4);
+}
+extern "C" int pb_debug_lines_fixed_wg(unsigned long long *host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lines_fixed_wg), sizeof(unsigned long long) * 2 * 2048 * 3);
+}
+#else
+#define PB_LF(k, i)
+#define PB_LF_ENTER(k)
+#define PB_LF_EXIT(k)
+#endif
+
 namespace {
 
 using pbfft::cf;
@@ -136,6 +191,8 @@ __global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict
     const float *src = gray + plane_off;
     const float *gxp = gx + plane_off;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    PB_LF(1, 0);
+    PB_LF_ENTER(1);
     // ---- every request of the tile (and of the twiddle table) at entry: global -> LDS, no register in between -------------
     {
         const brsrc rg = rsrc_of(src, (long)N * W * 4);
@@ -156,19 +213,25 @@ __global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict
 #pragma unroll 1
             for (int i = wave; i < TW_DMAS; i += NTH / 64) dma16(rt, tb + i * 1024, (unsigned)(lane * 16), i * 1024);
         }
+        PB_LF(1, 1);
         wait_vm0();
+        PB_LF(1, 2);
     }
     __syncthreads();
     const float2 *tw = TWLDS ? twl : tw_g;
     // ---- the five stages --------------------------------------------------------------------------------------------------
     fstage<R0, false, N, N, LOGNB, NTH>(s, tw);
     __syncthreads();
+    PB_LF(1, 3);
     fstage<R1, false, N, N / R0, LOGNB, NTH>(s, tw);
     __syncthreads();
+    PB_LF(1, 4);
     fcentre<R2, N, LOGNB, NTH>(s, drev);
     __syncthreads();
+    PB_LF(1, 5);
     fstage<R1, true, N, R1 * R2, LOGNB, NTH>(s, tw);
     __syncthreads();
+    PB_LF(1, 6);
     if constexpr (!std::is_void<TGY>::value) {
         // ---- last stage, storing d/dy (pbfft::last_stage<R0> with ColsIO<0>) ----------------------------------------------------
         constexpr int M = N / R0, STRIDE = M << LOGNB;
@@ -224,6 +287,7 @@ __global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict
             }
         }
     }
+    PB_LF(1, 7);
     __syncthreads();
     // workgroup maximum of every direction -> one partial per column tile (estimate.hip: reduce_maxima)
     float *red = reinterpret_cast<float *>(sfft);
@@ -240,6 +304,7 @@ __global__ __launch_bounds__(NTH) void cols_fixed_kernel(const float *__restrict
         for (int w = 1; w < NTH / 64; ++w) m = fmaxf(m, red[w * PB_MAX_ANGLES + threadIdx.x]);
         mags_tile[(long)threadIdx.x * tiles_pad] = __float_as_uint(m);   // m >= 0
     }
+    PB_LF_EXIT(1);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -337,6 +402,8 @@ template <int R0, int R1, int R2, int NTH, class IN, typename TO>
 __device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, TO *o0, int W, bool has1, const float2 *__restrict__ tw,
                                                 const float *__restrict__ drev) {
     constexpr int N = R0 * R1 * R2, M = N / R0;
+    PB_LF(0, 0);
+    PB_LF_ENTER(0);
     // first stage: pbfft::first_stage<R0>
 #pragma unroll 1
     for (int np = threadIdx.x; np < M; np += NTH) {
@@ -351,13 +418,18 @@ __device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, TO *o0, int W, bo
 #pragma unroll
         for (int q = 0; q < R0; ++q) s[PHI(np + q * M)] = v[q];
     }
+    PB_LF(0, 1);
     __syncthreads();
+    PB_LF(0, 2);
     rstage<R1, false, N, N / R0, NTH>(s, tw);
     __syncthreads();
+    PB_LF(0, 3);
     rcentre<R2, N, NTH>(s, drev);
     __syncthreads();
+    PB_LF(0, 4);
     rstage<R1, true, N, R1 * R2, NTH>(s, tw);
     __syncthreads();
+    PB_LF(0, 5);
     // last stage: pbfft::last_stage<R0> with RowsIO::store
 #pragma unroll 1
     for (int np = threadIdx.x; np < M; np += NTH) {
@@ -375,6 +447,8 @@ __device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, TO *o0, int W, bo
             if (has1) pb_st(o0 + W + np + q * M, -v[q].y);
         }
     }
+    PB_LF(0, 6);
+    PB_LF_EXIT(0);
 }
 
 constexpr int rows_lds_bytes(int n) { return (n + (n >> 5) + 1) * 8; }
