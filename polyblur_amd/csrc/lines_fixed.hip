@@ -454,7 +454,10 @@ __device__ __forceinline__ void rows_fixed_body(cf *s, IN &in, TO *o0, int W, bo
 constexpr int rows_lds_bytes(int n) { return (n + (n >> 5) + 1) * 8; }
 // (the second launch bound = waves per SIMD the register allocation must leave room for: five 256-thread workgroups per CU
 // -- what 31.7 KB of LDS allow a 3840-point line -- are five waves per SIMD)
-constexpr int rows_waves(int n, int nth) { return nth == 512 ? 4 : (n > 2048 && nth == 128 ? 3 : 5); }
+constexpr int rows_waves(int n, int nth) {
+    const int wgs = 163840 / rows_lds_bytes(n), w = (wgs * nth + 255) / 256;       // what LDS lets a CU hold, in waves per SIMD
+    return w < 1 ? 1 : (w > 5 ? 5 : w);
+}
 
 template <int R0, int R1, int R2, int NTH, int CC>
 __global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void gray_rows_fixed_kernel(const float *__restrict__ in, float *__restrict__ gray,
@@ -501,6 +504,12 @@ __global__ __launch_bounds__(NTH, rows_waves(R0 * R1 * R2, NTH)) void grad_rows_
     rows_fixed_body<R0, R1, R2, NTH>(reinterpret_cast<cf *>(sfft), io, gx + ((long)plane * H + r0) * W, W, io.has1, tw, drev);
 }
 
+// whether the line's twiddle table joins the tile in LDS: both (rounded up to whole 1-KB LDS-DMA requests) within what a
+// workgroup of that size may take -- all 160 KB on 1024 threads (one per CU), half of it on 512 (two per CU)
+constexpr bool cols_twlds(int n, int lognb, int nth) {
+    return ((n * (1 << lognb) * 8 + 1023) / 1024 + (n * 8 + 1023) / 1024) * 1024 <= (nth == 1024 ? 160 : 80) * 1024;
+}
+
 template <int R0, int R1, int R2, int LOGNB, int NTH, bool TWLDS>
 int launch_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P, int W, unsigned *mags, bool sat, const FftPlan *pl,
                  const AngleTable7 &ang, void *gy_out = nullptr, int gy_dtype = PB_F32) {
@@ -545,20 +554,24 @@ int pb_launch_cols_fixed(pb_ctx *ctx, const float *gray, const float *gx, int P,
     }
     const int r0 = pl->radix[0], r1 = pl->radix[1], r2 = pl->radix[2];
     const bool sat = discard_sat != 0;
-#define PB_FIXED(R0, R1, R2, LOGNB, NTH, TWLDS) return launch_fixed<R0, R1, R2, LOGNB, NTH, TWLDS>(ctx, gray, gx, P, W, mags, sat, pl, ang, gy_out, gy_dtype)
-    if (H == 2160 && r0 == 9 && r1 == 16 && r2 == 15) {
-        if (lognb == 3) PB_FIXED(9, 16, 15, 3, 1024, true);
-        if (lognb == 2) PB_FIXED(9, 16, 15, 2, 512, false);        // (69 KB of tile: two workgroups per CU, no room for the table)
+    // The compiled plans: line length = R0 x R1 x R2 in the order launch_cols gives it (smallest radix from 5 up -- or the one whose
+    // butterflies are one trip -- first), with the two tile widths pick_lognb can give that length: NARROW on 512 threads (two
+    // workgroups per CU) and WIDE on 1024 (one), 0 = that width does not occur.  The BASELINE lengths first; then the common
+    // picture sizes (720p, 1440p, 2K ...), where the same kernels run 1.3 - 2 x faster than the run-time-plan ones.
+    // The twiddle table joins the tile in LDS where both fit (cols_twlds).
+#define PB_COLS_PLANS(X)                                                                          \
+    X(2160, 9, 16, 15, 2, 3) X(1080, 6, 15, 12, 3, 4) X(4320, 15, 16, 18, 1, 2)                    \
+    X(512, 2, 16, 16, 3, 4) X(640, 4, 16, 10, 3, 4) X(720, 3, 16, 15, 3, 4) X(768, 3, 16, 16, 3, 4) \
+    X(800, 5, 16, 10, 3, 4) X(960, 4, 16, 15, 3, 4) X(1024, 4, 16, 16, 3, 4) X(1200, 5, 16, 15, 3, 0) \
+    X(1280, 5, 16, 16, 3, 0) X(1440, 6, 16, 15, 2, 3) X(1536, 6, 16, 16, 2, 3) X(1600, 10, 16, 10, 2, 3) \
+    X(2048, 8, 16, 16, 2, 3) X(2560, 10, 16, 16, 2, 0) X(3072, 12, 16, 16, 1, 2) X(4096, 16, 16, 16, 1, 2)
+#define PB_COLS_CASE(N_, R0, R1, R2, LN, LW)                                                                                   \
+    if (H == N_ && r0 == R0 && r1 == R1 && r2 == R2) {                                                                         \
+        if (LW != 0 && lognb == LW) return launch_fixed<R0, R1, R2, (LW ? LW : 1), 1024, cols_twlds(N_, (LW ? LW : 1), 1024)>(ctx, gray, gx, P, W, mags, sat, pl, ang, gy_out, gy_dtype); \
+        if (lognb == LN) return launch_fixed<R0, R1, R2, LN, 512, cols_twlds(N_, LN, 512)>(ctx, gray, gx, P, W, mags, sat, pl, ang, gy_out, gy_dtype); \
     }
-    if (H == 1080 && r0 == 6 && r1 == 15 && r2 == 12) {
-        if (lognb == 4) PB_FIXED(6, 15, 12, 4, 1024, true);
-        if (lognb == 3) PB_FIXED(6, 15, 12, 3, 512, true);         // (69 + 9 KB: two per CU with the table)
-    }
-    if (H == 4320 && r0 == 15 && r1 == 16 && r2 == 18) {
-        if (lognb == 2) PB_FIXED(15, 16, 18, 2, 1024, false);
-        if (lognb == 1) PB_FIXED(15, 16, 18, 1, 512, false);
-    }
-#undef PB_FIXED
+    PB_COLS_PLANS(PB_COLS_CASE)
+#undef PB_COLS_CASE
     return PB_ERR_UNSUPPORTED;
 }
 
@@ -595,19 +608,31 @@ int pb_launch_rows_fixed(pb_ctx *ctx, const float *in, int C, float *gray, void 
         PB_LAUNCH_CHECK();                                                                                                          \
         return PB_OK;                                                                                                               \
     } while (0)
-    if (W == 3840 && r0 == 15 && r1 == 16 && r2 == 16) {
-        if (nth == 256) PB_ROWS_FIXED(15, 16, 16, 256);
-        if (nth == 128) PB_ROWS_FIXED(15, 16, 16, 128);
+    // (the compiled plans, in the order rows_plan gives them: the BASELINE widths, then the common picture widths)
+#define PB_ROWS_PLANS(X)                                                                         \
+    X(3840, 15, 16, 16) X(1920, 8, 16, 15)                                                       \
+    X(512, 2, 16, 16) X(640, 4, 16, 10) X(720, 3, 16, 15) X(768, 3, 16, 16) X(800, 5, 16, 10) X(960, 4, 16, 15) \
+    X(1024, 4, 16, 16) X(1200, 5, 16, 15) X(1280, 5, 16, 16) X(1440, 6, 16, 15) X(1536, 6, 16, 16) X(1600, 10, 16, 10) \
+    X(2048, 8, 16, 16) X(2560, 10, 16, 16) X(3072, 12, 16, 16) X(4096, 16, 16, 16)
+#define PB_ROWS_CASE(N_, R0, R1, R2)                                   \
+    if (W == N_ && r0 == R0 && r1 == R1 && r2 == R2) {                 \
+        if (nth == 256) PB_ROWS_FIXED(R0, R1, R2, 256);                \
+        if (nth == 128) PB_ROWS_FIXED(R0, R1, R2, 128);                \
     }
-    if (W == 1920 && r0 == 8 && r1 == 16 && r2 == 15) {
-        if (nth == 256) PB_ROWS_FIXED(8, 16, 15, 256);
-        if (nth == 128) PB_ROWS_FIXED(8, 16, 15, 128);
-    }
+    PB_ROWS_PLANS(PB_ROWS_CASE)
+#undef PB_ROWS_CASE
     if (W == 7680 && r0 == 16 && r1 == 20 && r2 == 24 && nth == 512) PB_ROWS_FIXED(16, 20, 24, 512);
 #undef PB_ROWS_FIXED
     return PB_ERR_UNSUPPORTED;
 }
 
 bool pb_lines_fixed_shape(int H, int W) {
-    return (H == 2160 || H == 1080 || H == 4320) && (W == 3840 || W == 1920 || W == 7680);
+    bool h = false, w = W == 7680;
+#define PB_H_CASE(N_, R0, R1, R2, LN, LW) h = h || H == N_;
+#define PB_W_CASE(N_, R0, R1, R2) w = w || W == N_;
+    PB_COLS_PLANS(PB_H_CASE)
+    PB_ROWS_PLANS(PB_W_CASE)
+#undef PB_H_CASE
+#undef PB_W_CASE
+    return h && w && (W % 32) == 0;
 }

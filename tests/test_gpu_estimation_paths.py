@@ -152,3 +152,32 @@ def test_half_gradient_planes_of_an_fp16_call(engines, runtime_plan_engine):
     assert d.max() <= 1.0 / 1024 and np.mean(d > 0) < 1e-3, (float(d.max()), float(np.mean(d > 0)))    # at most one fp16 step, on a handful of samples
     want = ref.polyblur_deblurring(x16[:1].astype(np.float32), n_iter=2, c=0.362, b=0.468, alpha=6, beta=1, remove_halo=True)
     assert np.max(np.abs(a[:1].astype(np.float32) - want)) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 720, 1280), (8, 1, 720, 1280), (1, 3, 1440, 2560), (4, 1, 1440, 2560), (1, 1, 1024, 1024),
+                                   (6, 1, 1024, 2048), (1, 3, 1200, 1600), (1, 3, 2048, 2048), (3, 1, 2048, 2048), (2, 3, 512, 640),
+                                   (12, 1, 512, 640), (1, 3, 960, 768), (8, 1, 960, 768), (1, 1, 3072, 4096), (2, 1, 4096, 3072),
+                                   (1, 3, 1600, 800), (6, 1, 1600, 800), (1, 3, 1536, 2048), (1, 3, 1280, 1200), (1, 1, 2560, 1440),
+                                   (10, 1, 640, 512), (10, 1, 768, 960), (10, 1, 800, 1024)])
+def test_fixed_plans_of_the_common_sizes_are_bit_identical(engines, runtime_plan_engine, runtime_plan_rows_engine, shape):
+    """the one-plan kernels of csrc/lines_fixed.hip beyond the BASELINE line lengths (512 ... 4096-point lines: 720p, 1440p, 2K
+    ...; narrow tiles for a lone image, wide ones for a batch that fills the chip) against the run-time-plan kernels: records
+    and both gradient planes bit-identical, and the gradients within tolerance of the oracle (filters.py:159-186)"""
+    B, C, H, W = shape
+    nd = min(B, 2)
+    img, _ = synthetic_blurry_batch(nd, C, H, W, seed0=53)
+    img = np.concatenate([img] * ((B + nd - 1) // nd))[:B]
+    o = opts(c=0.362, b=0.468)
+    b = engines["default"].estimate_blur(img, o)
+    for ref_eng in (runtime_plan_engine, runtime_plan_rows_engine):
+        a = ref_eng.estimate_blur(img, o)
+        for f in FIELDS:
+            assert np.array_equal(np.asarray(a[f]), np.asarray(b[f])), f
+    planes = img.reshape(B * C, H, W)[:2]
+    gxb, gyb = engines["default"].fourier_gradients(planes)
+    gxa, _ = runtime_plan_rows_engine.fourier_gradients(planes)
+    _, gya = runtime_plan_engine.fourier_gradients(planes)
+    assert np.array_equal(gxa, gxb) and np.array_equal(gya, gyb)
+    if H * W <= 1440 * 2560:
+        rx, ry = ref.spectral_gradients(planes[None])
+        assert np.max(np.abs(gxb - rx[0])) < 2e-5 and np.max(np.abs(gyb - ry[0])) < 2e-5
