@@ -695,8 +695,9 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     PB_HIP(hipSetDevice(ctx->device));
     // (every iteration's choices of body keep a slot of their own; whichever way the call ends, later passes on this context
     // read and write slot 0 again, and what one-pass spec the call asked for is forgotten)
-    struct SlotGuard { pb_ctx *c; ~SlotGuard() { c->sel_slot = 0; c->poly_want = no_poly(); } } slot_guard{ctx};
+    struct SlotGuard { pb_ctx *c; ~SlotGuard() { c->sel_slot = 0; c->poly_want = no_poly(); c->poly_want2 = no_poly(); } } slot_guard{ctx};
     ctx->sel_slot = 0;
+    ctx->sel2_mask = 0;
     Geometry g = geometry(B, C, H, W, ksize / 2);
     const bool poly_eligible = (opt->boundary == PB_WRAP || ctx->zero_ring) && !opt->edgetaping && !opt->separable_approx && ksize <= PB_KSIZE;
     g.est_gaussians = (ksize & 1) && ksize <= PB_KSIZE && !opt->separable_approx;
@@ -793,10 +794,29 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
             ConvPass steps[3];
             make_steps(g, cur, src_dtype, nullptr, info, opt->alpha, opt->beta, opt->boundary, nullptr, nullptr, dst, last_out, 1, steps);
             ctx->poly_want = poly_spec(ctx, steps, opt->alpha, opt->beta, (ksize & 1) != 0);
+            // (the zero boundary in its window-pass + ring form: the ring steps run with the kernels' OWN spectra -- the estimation
+            // builds them as its second set instead of a khat_kernel launch in front of the ring)
+            if (opt->boundary == PB_ZERO && ctx->poly_want.always == 1) { ctx->poly_want2 = no_poly(); ctx->poly_want2.always = 2; }
         }
-        else if (g.taper_windows) { ctx->poly_want = no_poly(); ctx->poly_want.always = 2; }      // (the blends come first: the kernels' own spectra, window form for all)
+        else if (g.taper_windows) {
+            ctx->poly_want = no_poly(); ctx->poly_want.always = 2;      // (the blends come first: the kernels' own spectra, window form for all)
+            // (... and the polynomial behind them wants ITS spectra: the second set, under the spec run_polynomial will ask for --
+            // its source is the padded, tapered plane)
+            if (ctx->poly_padded) {
+                const int src_dtype = opt->prefilter != PB_PREFILTER_NONE ? PB_F32 : cur_dtype;
+                const int last_out = (opt->remove_halo || opt->prefilter != PB_PREFILTER_NONE) ? PB_F32 : dst_dtype;
+                ConvPass steps[3];
+                float *pa = static_cast<float *>(pb_scratch(ctx, "inv.pa", sizeof(float) * g.P * g.pplane));
+                if (!pa) return PB_ERR_NOMEM;
+                make_steps(g, cur, src_dtype, pa, info, opt->alpha, opt->beta, opt->boundary, nullptr, nullptr, dst, last_out, 1, steps);
+                const PolySpec want = ctx->poly_want;
+                ctx->poly_want2 = poly_spec(ctx, steps, opt->alpha, opt->beta, true);
+                ctx->poly_want = want;
+                if (opt->boundary == PB_ZERO) ctx->poly_want2 = no_poly();      // (the ring there wants a third set: left to its own launch)
+            }
+        }
         rc = pb_estimate_impl(ctx, cur, cur_dtype, B, C, H, W, opt, info);
-        ctx->poly_want = no_poly();
+        ctx->poly_want = no_poly(); ctx->poly_want2 = no_poly();
         if (rc) return rc;
         if (ksize > PB_KSIZE) {
             rc = pb_build_big_taps(ctx, info, B, ksize, (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, &g.big_taps);
@@ -884,7 +904,12 @@ int pb_body_selection(pb_ctx *ctx, int iteration, int *host, int B) {
         return pb_fail(ctx, PB_ERR_BADARG, "pb_body_selection: no selection for %d images on this context", B);
     const int slot = (iteration < 0 ? ctx->sel_last : iteration) % PB_SEL_SLOTS;
     std::vector<pb_fft_sel> h((size_t)B);
-    PB_HIP(hipMemcpyAsync(h.data(), static_cast<const pb_fft_sel *>(it->second.p) + (size_t)slot * B, sizeof(pb_fft_sel) * (size_t)B,
+    // (an iteration whose polynomial read the second set's selections -- behind an edgetaper -- is reported from there)
+    const pb_fft_sel *src = static_cast<const pb_fft_sel *>(it->second.p);
+    const auto it2 = ctx->scratch.find("conv.fftsel2");
+    if ((ctx->sel2_mask >> slot) & 1u && it2 != ctx->scratch.end() && it2->second.bytes >= sizeof(pb_fft_sel) * (size_t)B * PB_SEL_SLOTS)
+        src = static_cast<const pb_fft_sel *>(it2->second.p);
+    PB_HIP(hipMemcpyAsync(h.data(), src + (size_t)slot * B, sizeof(pb_fft_sel) * (size_t)B,
                           hipMemcpyDeviceToHost, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < B; ++b) {

@@ -119,6 +119,16 @@ struct pb_ctx {
     // side stream (1.182 -> 1.195 ms): issued under the adaptive policy only.
     int poly_mode = 3;
     PolySpec poly_built = no_poly(), poly_want = no_poly();
+    // A SECOND set of spectra + selections ("conv.khat2" / "conv.fftsel2"), built by the estimation beside the first where the
+    // call will need both -- the zero boundary's ring steps want the kernels' own spectra next to the polynomial's, the
+    // polynomial behind an edgetaper wants its own next to the kernels' -- instead of by a khat_kernel launch of its own
+    // between the estimation and the pass (measured: 23 us per iteration of a 4K method='direct' call, 9 us with edgetaping).
+    // poly_want2: what the estimation in progress is asked to build there (on == 0 && always == 0: nothing).
+    PolySpec poly_want2 = no_poly(), khat2_spec = no_poly();
+    const void *khat2_owner = nullptr;   // record set whose spectra the second set holds (nullptr: none)
+    int khat2_B = 0;
+    const void *khat2_buf = nullptr;
+    unsigned sel2_mask = 0;              // iterations (slots of "conv.fftsel2", as of "conv.fftsel") whose polynomial read the SECOND set's selections: pb_body_selection reports those
     // cost model of the general one-pass form (PolySpec.on == 2; env PB_POLY_GAIN, PB_POLY_MIN_AREA): an image takes it when
     // its composite tile has at least poly_min_area samples and -- an image that would otherwise take three tile-spectrum
     // passes -- 3 x that area is at least poly_gain x the tile area of its three-step windows (cost per output sample, in
@@ -259,6 +269,7 @@ int pb_launch_conv_xt(pb_ctx *ctx, const ConvPass &p);                       // 
 int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch);
 int pb_build_khat_ring(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel);   // conv_fft.hip: the kernels' OWN spectra, every symmetric kernel on three-step windows, in a second scratch set
 int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel);   // the scratch alone (the estimation fills it itself)
+int pb_khat2_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel);  // ... of the second set
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // conv.hip: after the host (re)built these records
 void pb_forget_records(pb_ctx *ctx, const void *info, int B);                 // B records at info are about to be rewritten; nullptr: all
 void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory

@@ -717,9 +717,13 @@ void pb_forget_records(pb_ctx *ctx, const void *info, int B) {
         // (spectra of a run of records that overlaps the rewritten ones anywhere, not only at its first record)
         const char *oe = o ? o + sizeof(pb_blur_info) * (size_t)ctx->khat_B : nullptr;
         if (o && o < b && a < oe) { ctx->khat_owner = nullptr; ctx->khat_B = 0; ctx->khat_by_estimate = false; }
+        const char *o2 = static_cast<const char *>(ctx->khat2_owner);
+        const char *oe2 = o2 ? o2 + sizeof(pb_blur_info) * (size_t)ctx->khat2_B : nullptr;
+        if (o2 && o2 < b && a < oe2) { ctx->khat2_owner = nullptr; ctx->khat2_B = 0; }
         return;
     }
     ctx->rec_cache.clear();
+    ctx->khat2_owner = nullptr; ctx->khat2_B = 0;
     ctx->khat_owner = nullptr;
     ctx->khat_B = 0;
     ctx->khat_by_estimate = false;

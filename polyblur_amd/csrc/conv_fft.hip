@@ -346,12 +346,38 @@ int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel) {
     return PB_OK;
 }
 
+int pb_khat2_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel) {
+    float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat2", sizeof(float) * PB_KHAT_STRIDE * (size_t)B));
+    pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel2", sizeof(pb_fft_sel) * (size_t)B * PB_SEL_SLOTS));
+    if (!k || !s) return PB_ERR_NOMEM;
+    s += (size_t)(ctx->sel_slot % PB_SEL_SLOTS) * B;          // (one slot per iteration, as pb_khat_buffers)
+    if (k != ctx->khat2_buf) { ctx->khat2_buf = k; ctx->khat2_owner = nullptr; ctx->khat2_B = 0; }      // (the scratch buffer was reallocated)
+    *khat = k; *sel = s;
+    return PB_OK;
+}
+// whether the second set holds the spectra of these records under this spec (the estimation built them: estimate.hip)
+static bool khat2_holds(pb_ctx *ctx, const pb_blur_info *info, int B, const PolySpec &spec) {
+    return ctx->khat2_owner && ctx->khat2_owner == info && ctx->khat2_B == B && same_spec(ctx->khat2_spec, spec) &&
+           (spec.on != 0 || ctx->khat2_spec.always == spec.always);
+}
 int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel, bool launch) {
     float *k = nullptr; pb_fft_sel *s = nullptr;
     const int rcb = pb_khat_buffers(ctx, B, &k, &s);
     if (rcb) return rcb;
     // (spectra of other records, of fewer records than this pass covers, or of the kernel where the pass wants the polynomial's)
     // (... or selections written to another slot than the one this pass reads)
+    // (the estimation may have built what this pass wants into the SECOND set: the polynomial behind an edgetaper)
+    if ((!ctx->khat_owner || ctx->khat_owner != info || ctx->khat_B != B || !same_spec(ctx->poly_built, ctx->poly_want)) &&
+        ctx->poly_want.on != 0 && khat2_holds(ctx, info, B, ctx->poly_want)) {
+        float *k2 = nullptr; pb_fft_sel *s2 = nullptr;
+        const int rc2 = pb_khat2_buffers(ctx, B, &k2, &s2);
+        if (rc2) return rc2;
+        if (khat2_holds(ctx, info, B, ctx->poly_want)) {
+            ctx->sel2_mask |= 1u << (ctx->sel_slot % PB_SEL_SLOTS);
+            *khat = k2; *sel = s2;
+            return PB_OK;
+        }
+    }
     if (!ctx->khat_owner || ctx->khat_owner != info || ctx->khat_B != B || !same_spec(ctx->poly_built, ctx->poly_want) ||
         ctx->khat_slot != ctx->sel_slot % PB_SEL_SLOTS) launch = true;
     if (launch) {
@@ -370,14 +396,17 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
 // three-step window form: what the border ring of a zero-boundary polynomial runs its three Horner steps with while the
 // first set holds the polynomial's spectra of the interior's one window pass (pb_launch_conv_poly).  One launch, not cached.
 int pb_build_khat_ring(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel) {
-    float *k = static_cast<float *>(pb_scratch(ctx, "conv.khat2", sizeof(float) * PB_KHAT_STRIDE * (size_t)B));
-    pb_fft_sel *s = static_cast<pb_fft_sel *>(pb_scratch(ctx, "conv.fftsel2", sizeof(pb_fft_sel) * (size_t)B));
-    if (!k || !s) return PB_ERR_NOMEM;
+    float *k = nullptr; pb_fft_sel *s = nullptr;
+    const int rcb = pb_khat2_buffers(ctx, B, &k, &s);
+    if (rcb) return rcb;
     PolySpec ps = no_poly();
     ps.always = 2;
-    ProfScope prof(ctx, PB_PROF_PARAMS);
-    hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases, ps);
-    PB_LAUNCH_CHECK();
+    if (!khat2_holds(ctx, info, B, ps)) {
+        ProfScope prof(ctx, PB_PROF_PARAMS);
+        hipLaunchKernelGGL(khat_kernel, dim3((unsigned)B, KH_SLICES), dim3(KH_NT), 0, ctx->stream, info, k, s, ctx->fft_min_phases, ps);
+        PB_LAUNCH_CHECK();
+        ctx->khat2_owner = info; ctx->khat2_B = B; ctx->khat2_spec = ps;
+    }
     *khat = k; *sel = s;
     return PB_OK;
 }

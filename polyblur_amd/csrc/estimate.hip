@@ -1238,7 +1238,17 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
                                                          float c, float b, int support, float force_theta_deg,
                                                          int tiles_per_image, int ksize, int shift,
                                                          const float2 *__restrict__ part, int blocks_per_image, unsigned *mm_out,
-                                                         float *khat, pb_fft_sel *fsel, int min_phases, const PolySpec ps, int lean) {
+                                                         float *khat_1, pb_fft_sel *fsel_1, int min_phases, const PolySpec ps_1, int lean,
+                                                         float *khat_2, pb_fft_sel *fsel_2, const PolySpec ps_2, int set2_from) {
+    // set2_from > 0: the workgroups blockIdx.y >= set2_from form a SECOND set of spectra + selections (khat_2, fsel_2) under the
+    // spec ps_2 -- what a khat_kernel launch of its own between the estimation and the pass used to build (common.h:
+    // poly_want2).  They walk the same chain from the same maxima BESIDE the first set's workgroups (the chip is empty under
+    // this kernel: 65 workgroups per image), so the chain to the first set's spectra is not a cycle longer.
+    const bool second = set2_from > 0 && (int)blockIdx.y >= set2_from;
+    const int slice_y = second ? (int)blockIdx.y - set2_from : (int)blockIdx.y;
+    float *khat = second ? khat_2 : khat_1;
+    pb_fft_sel *fsel = second ? fsel_2 : fsel_1;
+    const PolySpec ps = second ? ps_2 : ps_1;
     // lean (PolySpec.always under full support: every image takes a one-pass form, nobody reads the record's stencil parts
     // before the kernel ends): the grid is KH_SLICES_LEAN + 1 workgroups per image.  Workgroups 0 .. KH_SLICES_LEAN - 1 walk
     // the SHORT chain -- maxima, interpolation, (theta, sigma, rho), taps, halos, choice of window, their slice of the spectrum
@@ -1246,7 +1256,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     // lists ...) beside them, off the critical path: the same taps from the same instructions.
     // (tools/params_trace.py, 4K: the chain to the stored spectrum 48.6 k shader cycles with the record in it and 16 slices,
     // 35.6 k without the record, 27.6 k with 64 slices; the record workgroup ends at 25.2 k)
-    const bool lean_wg = lean && (int)blockIdx.y < KH_SLICES_LEAN, rec_wg = !lean_wg;
+    const bool lean_wg = lean && slice_y < KH_SLICES_LEAN, rec_wg = !lean_wg;
     __shared__ float red[NT / 64];
     __shared__ float s_mags[PB_MAX_ANGLES], s_interp[PB_MAX_INTERP];
     __shared__ float s_lo[NT / 64], s_hi[NT / 64];
@@ -1400,7 +1410,8 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
         __syncthreads();
         PB_PT(4);
         const RecLds rlean{sk_lean, PB_KRAD, 0, 0};
-        khat_body<KH_SLICES_LEAN>(nullptr, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps, &rlean, true);
+        khat_body<KH_SLICES_LEAN>(nullptr, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, slice_y, ps, &rlean, true);
+        if (second && threadIdx.x == 0 && slice_y == 0) fsel[blockIdx.x].strip = 0;       // (the first set's comes from the record workgroup)
         return;
     }
     RecLds rl;
@@ -1414,7 +1425,7 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
     // redundant latency-bound work, identical values) and now forms its slice -- one launch less on every iteration's
     // critical path than a kernel of its own behind this one.
     if (khat)      // (the record as finish_record left it in LDS: no wait for its stores, no read back)
-        khat_body(info, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, (int)blockIdx.y, ps, &rl);
+        khat_body(info, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, slice_y, ps, &rl);
 #ifdef PB_PT_WANT
     __syncthreads();
     }
@@ -2017,12 +2028,24 @@ int pb_estimate_impl(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
     }
     // (PolySpec.always under full support: the short chain to the spectra, the record beside it -- see the kernel)
     const int lean = (khat && ctx->poly_want.always == 1 && opt->support == PB_SUPPORT_FULL && ctx->est_lean) ? 1 : 0;
+    // (the second set: where the call in progress has said it will need one -- api.hip sets poly_want2 around the estimation)
+    float *khat2 = nullptr;
+    pb_fft_sel *fsel2 = nullptr;
+    const PolySpec ps2 = ctx->poly_want2;
+    ctx->khat2_owner = ctx->khat2_owner == dev_info ? nullptr : ctx->khat2_owner;       // (these records are being rewritten)
+    if (khat && (ps2.on != 0 || ps2.always != 0)) {
+        rc = pb_khat2_buffers(ctx, B, &khat2, &fsel2);
+        if (rc) return rc;
+    }
     ProfScope prof(ctx, PB_PROF_PARAMS);
-    hipLaunchKernelGGL(blur_params_kernel, dim3(B, khat ? (lean ? KH_SLICES_LEAN + 1 : KH_SLICES) : 1), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
+    const int set1 = khat ? (lean ? KH_SLICES_LEAN + 1 : KH_SLICES) : 1;
+    const int set2 = khat2 ? (lean ? KH_SLICES_LEAN : KH_SLICES) : 0;
+    hipLaunchKernelGGL(blur_params_kernel, dim3(B, set1 + set2), dim3(NT), 0, ctx->stream, dev_info, mm, mags, wts, opt->n_angles,
                        opt->n_interpolated_angles, opt->c, opt->b, opt->support, opt->force_theta_deg, est_tiles, ksize,
                        (!(ksize & 1) && opt->boundary == PB_WRAP) ? 1 : 0, norm ? nullptr : part_q0, bpi_q0, mm, khat, fsel,
-                       ctx->fft_min_phases, ctx->poly_want, lean);
+                       ctx->fft_min_phases, ctx->poly_want, lean, khat2, fsel2, ps2, set2 ? set1 : 0);
     PB_LAUNCH_CHECK();
+    if (khat2) { ctx->khat2_owner = dev_info; ctx->khat2_B = B; ctx->khat2_spec = ps2; }
     if (khat) { ctx->khat_owner = dev_info; ctx->khat_B = B; ctx->khat_by_estimate = true; ctx->poly_built = ctx->poly_want; ctx->khat_slot = ctx->sel_slot % PB_SEL_SLOTS; }
     return PB_OK;
 }
