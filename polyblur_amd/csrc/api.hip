@@ -913,7 +913,7 @@ int pb_body_selection(pb_ctx *ctx, int iteration, int *host, int B) {
                           hipMemcpyDeviceToHost, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < B; ++b) {
-        host[6 * b] = h[b].use_fft; host[6 * b + 1] = h[b].rf; host[6 * b + 2] = h[b].strip;
+        host[6 * b] = h[b].use_fft; host[6 * b + 1] = h[b].pad_[1] == 1 ? -1 : h[b].rf; host[6 * b + 2] = h[b].strip;      // (pad_[1]: the short chain's record workgroup found asymmetric taps)
         host[6 * b + 3] = h[b].poly; host[6 * b + 4] = h[b].hx; host[6 * b + 5] = h[b].hy;
     }
     return PB_OK;

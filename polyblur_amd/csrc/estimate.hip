@@ -1411,13 +1411,21 @@ __global__ __launch_bounds__(NT) void blur_params_kernel(pb_blur_info *infos, co
         PB_PT(4);
         const RecLds rlean{sk_lean, PB_KRAD, 0, 0};
         khat_body<KH_SLICES_LEAN>(nullptr, khat + (long)blockIdx.x * PB_KHAT_STRIDE, fsel + blockIdx.x, min_phases, slice_y, ps, &rlean, true);
-        if (second && threadIdx.x == 0 && slice_y == 0) fsel[blockIdx.x].strip = 0;       // (the first set's comes from the record workgroup)
+        if (second && threadIdx.x == 0 && slice_y == 0) { fsel[blockIdx.x].strip = 0; fsel[blockIdx.x].pad_[1] = 0; }      // (the first set's come from the record workgroup)
         return;
     }
     RecLds rl;
     finish_record(info, support, false, red, ksize, s_par, shift, &rl);
-    if (lean) {                                      // (the record workgroup of a lean grid: the one fact of the selection only it knows)
-        if (threadIdx.x == 0) fsel[blockIdx.x].strip = (rl.separable != 0 && rl.radius > 8) ? 1 : 0;
+    if (lean) {                                      // (the record workgroup of a lean grid: the facts of the selection only it knows)
+        // ... among them whether the taps ARE point-symmetric, as PolySpec.always vouches (NaN parameters make taps that compare
+        // unequal to themselves): looked at here, off the critical path of the short chain; pb_body_selection reports it
+        bool sym = true;
+        for (int i = threadIdx.x; i < PB_KSIZE * PB_KSIZE; i += NT) sym = sym && rl.taps[i] == rl.taps[PB_KSIZE * PB_KSIZE - 1 - i];
+        const int all_sym = __syncthreads_and(sym);
+        if (threadIdx.x == 0) {
+            fsel[blockIdx.x].strip = (rl.separable != 0 && rl.radius > 8) ? 1 : 0;
+            fsel[blockIdx.x].pad_[1] = all_sym ? 0 : 1;
+        }
         return;
     }
     // The spectrum of the kernel just built and the image's choice of body for the reblurring passes (khat.h): the grid is

@@ -211,9 +211,9 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
     // (the short chain: the taps are the caller's LDS array as it is -- full support, nothing outside the box to mask -- and
     // point-symmetric by construction, PolySpec.always)
     const float *skp = lean ? rl->taps : sk;
-    if (lean) {                                  // (only the check: NaN parameters make taps that compare unequal to themselves)
-        for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) sym = sym && skp[i] == skp[PB_KSIZE * PB_KSIZE - 1 - i];
-    } else
+    // (lean: the short chain does not look -- the record workgroup beside it does, off the critical path, and reports what it
+    // finds in pb_fft_sel.pad_[1]: estimate.hip)
+    if (!lean)
     for (int i = tid; i < PB_KSIZE * PB_KSIZE; i += KH_THREADS) {
         const int u = i / PB_KSIZE - PB_KRAD, v = i % PB_KSIZE - PB_KRAD;
         const bool in = abs(u) <= R && abs(v) <= R;
@@ -336,7 +336,8 @@ __device__ __forceinline__ void khat_body(const pb_blur_info *info, float *out, 
         sel->hx = poly ? hxp : hxk; sel->hy = poly ? hyp : hyk;
         if (!lean) sel->strip = (separable != 0 && R > 8) ? 1 : 0;
         sel->poly = poly128 ? 2 : (poly ? 1 : 0);
-        sel->pad_[0] = 0; sel->pad_[1] = 0;
+        sel->pad_[0] = 0;
+        if (!lean) sel->pad_[1] = 0;                 // (lean: the record workgroup's word -- 1 = taps not point-symmetric)
     }
     PB_PT(23);
     if (poly128) { khat128_body<SL>(skp, out, slice, ps, c8, s8); PB_PT(22); return; }
