@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--no-context", action="store_true",
                     help="skip the labelled side measurements, so that a profiler sees only the headline workload's kernels")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed steps for this long between the warm-up and the timed region (clocks settle); 0 under a profiler, whose passes must see the same launches")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU check of the N-rank launch path: rendezvous over gloo, all-reduce, print the line, no compute")
     return ap.parse_args()
@@ -280,7 +282,7 @@ def main():
     if not from_root:
         sync_all()
         t_s = time.perf_counter()
-        while time.perf_counter() - t_s < 0.06 and settle_steps < 400:
+        while time.perf_counter() - t_s < args.settle_ms * 1e-3 and settle_steps < 400:
             for _ in range(4):
                 out = step()
             torch.cuda.synchronize(dev)

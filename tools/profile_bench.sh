@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 if [ "$CFG" = cfg2 ]; then NAME=$TAG; STEPS=10; else NAME=${TAG}_bench_$CFG; STEPS=3; fi
 OUT=gpurun_out/$NAME
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-context"
+CMD="python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-context --settle-ms 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $CMD > /dev/null 2> "$OUT/pmc_fetch.log"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- $CMD > /dev/null 2> "$OUT/pmc_write.log"
