@@ -1,18 +1,28 @@
-// Column transform + directional maxima of the estimation (blur_estimation.py:112-134, filters.py:159-186) for the line
-// lengths whose plan is known when the library is compiled: 2160 = 9 x 16 x 15 (4K), 1080 = 6 x 15 x 12 (1080p), 4320 =
-// 15 x 16 x 18 (8K) -- the orders estimate.hip:launch_cols gives those lengths.
+// The line transforms of the estimation (blur_estimation.py:112-134, filters.py:159-186) for the line lengths whose plan is
+// known when the library is compiled -- the BASELINE sides (columns 2160 = 9 x 16 x 15, 1080 = 6 x 15 x 12, 4320 = 15 x 16 x 18;
+// rows 3840 = 15 x 16 x 16, 1920 = 8 x 16 x 15, 7680 = 16 x 20 x 24) and sixteen common picture sides from 512 to 4096
+// (PB_COLS_PLANS / PB_ROWS_PLANS below), in the stage orders estimate.hip:launch_cols / rows_plan give those lengths:
+//   cols_fixed_kernel        the column transform with the directional maxima folded behind it (grad_cols_kernel's MODE 1), or
+//                            storing the y derivative as float / fp16 planes (MODE 0: the gradients halo masking keeps);
+//   gray_rows_fixed_kernel   gray + range partials + the row transform from the image's channels (gray_rows_kernel);
+//   grad_rows_fixed_kernel   the row transform of float planes, float or fp16 planes out (grad_rows_kernel<.., true>).
 //
-// What grad_cols_kernel<1, 7, 1024> computes, operation for operation (the butterflies, the twiddle products and the fold of
-// the maxima are the SAME inline functions of fft.h, so every record is bit-identical to the run-time-plan kernel's --
-// tests/test_gpu_estimation_paths.py), but as a kernel that holds ONE plan:
-//   * no switch over fifteen radices per stage: the run-time-plan kernel is 60 k lines of ISA whose register allocation is
+// What the run-time-plan kernels of estimate.hip compute, operation for operation (the butterflies, the twiddle products and
+// the fold of the maxima are the SAME inline functions of fft.h -- every multiply-add in them an explicit FMA --, so every
+// record and every gradient sample is bit-identical: tests/test_gpu_estimation_paths.py), but as kernels that hold ONE plan:
+//   * no switch over fifteen radices per stage: grad_cols_kernel<1, 7, 1024> is 60 k lines of ISA whose register allocation is
 //     that of its widest butterfly (10 vector + 176 scalar registers spilled under the 128-register cap of a 1024-thread
-//     workgroup); this one is the five stages it runs, every trip count and index division a constant;
-//   * the gray tile travels global -> LDS by LDS-DMA (16 bytes per lane, 16 rows of a 16-column tile per wave instruction,
-//     no staging register), every request of the tile issued at entry; the first stage is then an ordinary in-place LDS stage;
-//   * the twiddle table of the line (n complex values) sits in LDS beside the tile where the two fit 160 KB (2160- and
-//     1080-point lines), fetched by LDS-DMA with the tile: a stage's four twiddle bases are LDS reads, not four dependent
-//     gathers from L2 in front of every butterfly;
+//     workgroup); these are the five stages they run, every trip count and index division a constant, nothing
+//     spilled in any of the 300 instantiations;
+//   * columns: the gray tile travels global -> LDS by LDS-DMA (16 bytes per lane, 16 rows of a 16-column tile per wave
+//     instruction, no staging register), every request of the tile issued at entry; the first stage is then an ordinary
+//     in-place LDS stage.  The twiddle table of the line (n complex values) sits in LDS beside the tile where the two fit,
+//     fetched by LDS-DMA with the tile: a stage's four twiddle bases are LDS reads, not four dependent gathers from L2 in
+//     front of every butterfly;
+//   * rows: the complex line sits in LDS with one pad element per 32 (PHI): no stage of the 3840-point plan is left with
+//     more than the two passes a 64-lane 8-byte access takes anyway (the run-time-plan kernel: 61 % bank-conflict cycles).
+// Which kernel transforms a line is a function of the image's own shape and the options alone: an image gets the same bits
+// alone and in a batch.  PB_COLS_FIXED=0 / PB_ROWS_FIXED=0 select the run-time-plan kernels (the tests' reference).
 #include "common.h"
 #include "fft.h"
 #include "lines_fixed.h"
