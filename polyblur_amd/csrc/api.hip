@@ -318,6 +318,18 @@ int run_edgetaper(pb_ctx *ctx, const Geometry &g, const void *src, int src_dtype
     set_in_virtual(p, g, src, src_dtype);
     set_x_virtual(p, g, src, src_dtype);
     set_out_padded(p, g, pa);
+    if (g.big_taps) {
+        // (a kernel beyond the 25 x 25 record: the three blends through conv_big.hip's pass, weights from its own autocorrelations)
+        int rcb = pb_launch_conv_big(ctx, p, g.big_taps, g.big_ksize);
+        if (rcb) return rcb;
+        set_in_padded(p, g, pa); set_x_padded(p, g, pa); set_out_padded(p, g, pb);
+        rcb = pb_launch_conv_big(ctx, p, g.big_taps, g.big_ksize);
+        if (rcb) return rcb;
+        set_in_padded(p, g, pb); set_x_padded(p, g, pb); set_out_padded(p, g, pa);
+        rcb = pb_launch_conv_big(ctx, p, g.big_taps, g.big_ksize);
+        *result = pa;
+        return rcb;
+    }
     // (the spec the estimation built these records' spectra under: every kernel on the window form, one launch per blend)
     struct SpecScope { pb_ctx *c; ~SpecScope() { c->poly_want = no_poly(); } } scope{ctx};
     if (g.taper_windows) { ctx->poly_want = no_poly(); ctx->poly_want.always = 2; }
@@ -689,9 +701,9 @@ int pb_polyblur_batch(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
     // autocorrelations of the projections, which do not care where the taps sit)
     if (!(ksize & 1) && opt->separable_approx)
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: the separable approximation is built for odd sizes only", ksize);
-    // (kernels beyond the 25 x 25 record take conv_big.hip's pass: no edgetaper weights, no separable approximation there)
-    if (ksize > PB_KSIZE && (opt->edgetaping || opt->separable_approx))
-        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: edgetaping and the separable approximation are built for sizes up to %d", ksize, PB_KSIZE);
+    // (kernels beyond the 25 x 25 record take conv_big.hip's pass: no separable approximation there; the edgetaper since round 6)
+    if (ksize > PB_KSIZE && opt->separable_approx)
+        return pb_fail(ctx, PB_ERR_UNSUPPORTED, "ker_size %d: the separable approximation is built for sizes up to %d", ksize, PB_KSIZE);
     PB_HIP(hipSetDevice(ctx->device));
     // (every iteration's choices of body keep a slot of their own; whichever way the call ends, later passes on this context
     // read and write slot 0 again, and what one-pass spec the call asked for is forgotten)

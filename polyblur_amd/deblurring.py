@@ -75,8 +75,8 @@ def _build_options(C, n_iter, c, b, alpha, beta, sigma_r, sigma_s, ker_size, q, 
         raise NotImplementedError("ker_size must be between 2 and 49")
     if ker_size % 2 == 0 and method == "direct_separable":
         raise NotImplementedError("an even ker_size is built for the 'fft' / 'direct' methods only (not with 'direct_separable')")
-    if ker_size > capi.PB_KSIZE and (edgetaping or method == "direct_separable"):
-        raise NotImplementedError("a ker_size above 25 is built for the plain 'fft' / 'direct' methods only (not with edgetaping or 'direct_separable')")
+    if ker_size > capi.PB_KSIZE and method == "direct_separable":
+        raise NotImplementedError("a ker_size above 25 is built for the 'fft' / 'direct' methods only (not with 'direct_separable')")
     if not (0 <= q < 0.5):
         raise ValueError("q must be in [0, 0.5)")
     if multichannel_kernel and C not in (1, 3):

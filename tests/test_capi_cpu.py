@@ -62,7 +62,7 @@ def test_argument_validation_before_any_device_work():
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=51)
     with pytest.raises(NotImplementedError):
-        polyblur_deblurring(x, ker_size=31, edgetaping=True)
+        polyblur_deblurring(x, ker_size=31, method="direct_separable")   # (above 25 with edgetaping is built since round 6)
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(x, ker_size=12, method="direct_separable")     # (an even size with edgetaping is built since round 6)
     with pytest.raises(NotImplementedError):

@@ -854,6 +854,28 @@ def test_even_kernel_sizes_with_edgetaping(golden, k, method):
     assert maxabs(out, ref.polyblur_deblurring(x, n_iter=1, **kw)) < 2e-5
 
 
+@pytest.mark.parametrize("k", [31, 48])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_large_kernel_sizes_with_edgetaping(golden, k, method):
+    """a ker_size above 25 with edgetaping=True (the reference's edgetaper takes any size, edgetaper.py:10-23):
+    the blends run through csrc/conv_big.hip with the weights of the large kernel's own autocorrelations.  Link by link against
+    the reference's outputs (tests/golden/make_golden_big_taper.py), the two links chained, and the oracle on a batch with
+    other dtypes' worth of options (halo masking behind the polynomial)."""
+    import torch
+    from polyblur_amd import polyblur_deblurring
+    g = golden("pipeline_big_taper.npz")
+    kw = dict(ker_size=k, method=method, edgetaping=True, **KW)
+    xs = [g["x0"]] + [g["k%d_%s_x%d" % (k, method, i)] for i in (1, 2)]
+    for i in range(2):
+        out = polyblur_deblurring(torch.from_numpy(xs[i]).cuda(), n_iter=1, **kw).cpu().numpy()
+        assert maxabs(out, xs[i + 1]) < 2e-5, (k, method, i, maxabs(out, xs[i + 1]))
+    out = polyblur_deblurring(torch.from_numpy(xs[0]).cuda(), n_iter=2, **kw).cpu().numpy()
+    assert maxabs(out, xs[2]) < (1e-4 if k % 2 == 0 else 3e-5)
+    x, _ = synthetic_blurry_batch(2, 3, 130, 170, seed0=65)
+    out = polyblur_deblurring(torch.from_numpy(x).cuda(), n_iter=1, remove_halo=True, **kw).cpu().numpy()
+    assert maxabs(out, ref.polyblur_deblurring(x, n_iter=1, remove_halo=True, **kw)) < 2e-5
+
+
 @pytest.mark.parametrize("k,shape", [(3, (1, 1, 9, 11)), (9, (2, 3, 40, 33)), (23, (1, 3, 70, 64)), (2, (1, 3, 20, 17)), (8, (2, 1, 33, 40)), (22, (1, 3, 64, 70)),
                                      (27, (2, 3, 70, 133)), (26, (1, 1, 40, 33)), (48, (1, 3, 150, 97)), (49, (2, 1, 20, 30)), (35, (1, 3, 300, 517))])
 def test_kernel_sizes_against_oracle(k, shape):
@@ -967,7 +989,7 @@ def test_direct_separable_fp16_and_kernel_size():
 
 def test_large_kernel_size_with_options_and_dtypes():
     """ker_size above 25 with halo removal, a prefilter, quantiles, fp16 and 8-bit images (every dtype combination of the
-    large-kernel pass); edgetaping and 'direct_separable' are not built for it"""
+    large-kernel pass); 'direct_separable' is not built for it"""
     import torch
     from polyblur_amd import polyblur_deblurring, polyblur_deblurring_uint8
     x, _ = synthetic_blurry_batch(2, 3, 120, 176, seed0=62)
@@ -985,8 +1007,6 @@ def test_large_kernel_size_with_options_and_dtypes():
     wantu = ref.polyblur_deblurring_uint8(u8, **kw)
     assert np.mean(got != wantu) < 2e-3 and np.abs(got.astype(int) - wantu.astype(int)).max() <= 1
     hwc = np.ascontiguousarray(x[0].transpose(1, 2, 0))
-    with pytest.raises(NotImplementedError):
-        polyblur_deblurring(hwc, ker_size=31, edgetaping=True)
     with pytest.raises(NotImplementedError):
         polyblur_deblurring(hwc, ker_size=31, method="direct_separable")
     with pytest.raises(NotImplementedError):

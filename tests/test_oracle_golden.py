@@ -245,3 +245,16 @@ def test_even_kernel_sizes_with_edgetaping(golden, k, method):
     for i in range(2):
         out = ref.polyblur_deblurring(xs[i], n_iter=1, **kw)
         assert np.max(np.abs(out - xs[i + 1])) < 1e-5, (k, method, i)
+
+
+@pytest.mark.parametrize("k", [31, 48])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_large_kernel_sizes_with_edgetaping(golden, k, method):
+    """the oracle against the reference's own outputs for a ker_size above 25 with edgetaping=True, link by link
+    (tests/golden/make_golden_big_taper.py; edgetaper.py:10-33)."""
+    g = golden("pipeline_big_taper.npz")
+    kw = dict(ker_size=k, method=method, edgetaping=True, c=0.362, b=0.468, alpha=6, beta=1)
+    xs = [g["x0"]] + [g["k%d_%s_x%d" % (k, method, i)] for i in (1, 2)]
+    for i in range(2):
+        out = ref.polyblur_deblurring(xs[i], n_iter=1, **kw)
+        assert np.max(np.abs(out - xs[i + 1])) < 1e-5, (k, method, i)

@@ -18,7 +18,7 @@ def case(i):
         short = int(rng.integers(2 * k + 2, 2 * k + 40))
         H, W = (short, long_side) if rng.integers(0, 2) else (long_side, short)
         B = 1
-    plain = k > 25                                   # edgetaping is built for sizes up to 25 (even ones since round 6)
+    plain = False                                    # edgetaping takes every size since round 6 (even ones; above 25 through conv_big.hip)
     kw = dict(n_iter=int(rng.integers(1, 4)), method=str(rng.choice(["fft", "direct"])), ker_size=k,
               remove_halo=bool(rng.integers(0, 2)), edgetaping=(not plain) and bool(rng.integers(0, 2)),
               prefiltering=bool(rng.integers(0, 3) == 0), discard_saturation=bool(rng.integers(0, 2)),
