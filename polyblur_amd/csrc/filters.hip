@@ -619,16 +619,24 @@ __global__ __launch_bounds__(NT) void dt_cols_fused_kernel(const TJ *__restrict_
 // sweep over them, one store per sample: 3 words.  5 words instead of 6, and one exponential per sample and column instead
 // of two (the up sweep's weight of row r + 1 is the down sweep's, domain_transform.py:62-85: |J[r+1] - J[r]| either way).
 // Bit-identical to dt_cols_fused_kernel (tests/test_gpu_round5_forms.py).
+// Round 6: where J is C fp32 channels the up sweep reads C words per pixel only to form one weight again, so the down sweep
+// stores the weight it has (WV: one word per pixel, 1 / C per sample) and dt_cols_upw_kernel reads that instead of J: 2 / C words
+// against 1, 4.67 + 2 / S per sample at C = 3 -- and, no J in its registers, strips of 32 rows.  The weight is the value the
+// down sweep used, the operations on it are the same: the same bits again.  (fp16 J, or one channel: J costs no more than the
+// weight would -- those keep dt_cols_up_kernel.)
 template <int C> __device__ __forceinline__ float dt_weight(const float (&jr)[C], const float (&jp)[C], float ratio, float log_a) {
     float dy = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) dy += fabsf(jr[c] - jp[c]);
     return expf((1.f + ratio * dy) * log_a);
 }
-constexpr int DT_STRIP = 16;
-template <typename TJ, int C>
+#ifndef PB_DT_STRIP_W
+#define PB_DT_STRIP_W 32
+#endif
+constexpr int DT_STRIP = 16, DT_STRIP_W = PB_DT_STRIP_W;
+template <typename TJ, int C, int S, bool WV>
 __global__ __launch_bounds__(NT) void dt_cols_down_kernel(const TJ *__restrict__ J, const float *__restrict__ F, float *__restrict__ carry,
-                                                          int H, int W, float ratio, float log_a, long cols_total) {
+                                                          float *__restrict__ wts, int H, int W, float ratio, float log_a, long cols_total) {
     const long id = (long)blockIdx.x * NT + threadIdx.x;   // over B*W: one thread = one column, all channels
     if (id >= cols_total) return;
     const long b = id / W;
@@ -636,6 +644,7 @@ __global__ __launch_bounds__(NT) void dt_cols_down_kernel(const TJ *__restrict__
     const long HW = (long)H * W;
     const float *f = F + b * C * HW + col;
     const TJ *j = J + b * C * HW + col;
+    float *wt = WV ? wts + b * HW + col : nullptr;         // wts[b][r][col] = the weight of row r (rows 1 .. H - 1)
     float prev[C], pj[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) { prev[c] = f[c * HW]; pj[c] = pb_ld(j + c * HW); }
@@ -653,15 +662,74 @@ __global__ __launch_bounds__(NT) void dt_cols_down_kernel(const TJ *__restrict__
             const int r = r0 + u;
             if (r < H) {
                 const float v = dt_weight<C>(js[u], pj, ratio, log_a);
+                if constexpr (WV) wt[(long)r * W] = v;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     pj[c] = js[u][c];
                     prev[c] = xs[u][c] + v * (prev[c] - xs[u][c]);
                 }
-                if ((r & (DT_STRIP - 1)) == DT_STRIP - 1 && r + 1 < H) {
+                if ((r & (S - 1)) == S - 1 && r + 1 < H) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) carry[((long)(r / DT_STRIP) * C + c) * cols_total + id] = prev[c];
+                    for (int c = 0; c < C; ++c) carry[((long)(r / S) * C + c) * cols_total + id] = prev[c];
                 }
+            }
+        }
+    }
+}
+// the up sweep over strips of S rows with the down sweep's weights read back (see above); F only, no J
+template <int C, int S>
+__global__ __launch_bounds__(NT) void dt_cols_upw_kernel(float *__restrict__ F, const float *__restrict__ carry, const float *__restrict__ wts,
+                                                         int H, int W, long cols_total) {
+    const long id = (long)blockIdx.x * NT + threadIdx.x;
+    if (id >= cols_total) return;
+    const long b = id / W;
+    const int col = (int)(id - b * W);
+    const long HW = (long)H * W;
+    float *f = F + b * C * HW + col;
+    const float *wt = wts + b * HW + col;
+    const int nstrips = (H + S - 1) / S;
+    float fnext[C], vnext = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) fnext[c] = 0.f;
+    for (int s = nstrips - 1; s >= 0; --s) {
+        const int a = s * S;
+        float xs[S][C], prev[C], v[S];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int r = min(a + u, H - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) xs[u][c] = f[c * HW + (long)r * W];
+            v[u] = wt[(long)max(r, 1) * W];                  // (row 0 has no weight: its slot is never written, never used)
+        }
+        if (s > 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) prev[c] = carry[((long)(s - 1) * C + c) * cols_total + id];
+        }
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int r = a + u;
+            if (r == 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) prev[c] = xs[u][c];
+            } else if (r < H) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    prev[c] = xs[u][c] + v[u] * (prev[c] - xs[u][c]);
+                    xs[u][c] = prev[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = S - 1; u >= 0; --u) {
+            const int r = a + u;
+            if (r < H) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (r < H - 1) fnext[c] = xs[u][c] + vnext * (fnext[c] - xs[u][c]);
+                    else fnext[c] = xs[u][c];
+                    f[c * HW + (long)r * W] = fnext[c];
+                }
+                vnext = v[u];
             }
         }
     }
@@ -845,13 +913,27 @@ static int dt_filter_fused(pb_ctx *ctx, const T *in, const T *J, float *out, int
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, T, C>), rgrid, dim3(NT), 0, ctx->stream, J, in, out, H, W, ratio, log_a, rows_total);
         else
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, float, C>), rgrid, dim3(NT), 0, ctx->stream, J, out, out, H, W, ratio, log_a, rows_total);
-        float *carry = nullptr;
+        float *carry = nullptr, *wts = nullptr;
+        // (the weights pay where J costs the up sweep more than a word to write and a word to read per pixel: fp32 J of 3 channels;
+        //  PB_DT_COLS_STRIP=2: always J again)
+        constexpr bool weights_pay = C * sizeof(T) > 2 * sizeof(float);
+        const bool weights = weights_pay && ctx->dt_cols_strip == 1 && H >= 4 * DT_STRIP_W;
+        const int strip = weights ? DT_STRIP_W : DT_STRIP;
         if (ctx->dt_cols_strip && H >= 4 * DT_STRIP) {
-            carry = static_cast<float *>(pb_scratch(ctx, "dt.carry", sizeof(float) * (size_t)((H + DT_STRIP - 1) / DT_STRIP) * C * (size_t)cols_total));
+            carry = static_cast<float *>(pb_scratch(ctx, "dt.carry", sizeof(float) * (size_t)((H + strip - 1) / strip) * C * (size_t)cols_total));
             if (!carry) return PB_ERR_NOMEM;
+            if (weights) {
+                wts = static_cast<float *>(pb_scratch(ctx, "dt.weights", sizeof(float) * (size_t)H * (size_t)cols_total));
+                if (!wts) return PB_ERR_NOMEM;
+            }
         }
-        if (carry) {
-            hipLaunchKernelGGL((dt_cols_down_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, carry, H, W, ratio, log_a, cols_total);
+        if (wts) {
+            if constexpr (weights_pay) {
+                hipLaunchKernelGGL((dt_cols_down_kernel<T, C, DT_STRIP_W, true>), cgrid, dim3(NT), 0, ctx->stream, J, out, carry, wts, H, W, ratio, log_a, cols_total);
+                hipLaunchKernelGGL((dt_cols_upw_kernel<C, DT_STRIP_W>), cgrid, dim3(NT), 0, ctx->stream, out, carry, wts, H, W, cols_total);
+            }
+        } else if (carry) {
+            hipLaunchKernelGGL((dt_cols_down_kernel<T, C, DT_STRIP, false>), cgrid, dim3(NT), 0, ctx->stream, J, out, carry, static_cast<float *>(nullptr), H, W, ratio, log_a, cols_total);
             hipLaunchKernelGGL((dt_cols_up_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, carry, H, W, ratio, log_a, cols_total);
         } else {
             hipLaunchKernelGGL((dt_cols_fused_kernel<T, C>), cgrid, dim3(NT), 0, ctx->stream, J, out, H, W, ratio, log_a, cols_total);

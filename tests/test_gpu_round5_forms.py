@@ -39,7 +39,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0), "dt_cols_sweeps": _engine(PB_DT_COLS_STRIP=0), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "dt_cols_sweeps": _engine(PB_DT_COLS_STRIP=0), "dt_cols_reread": _engine(PB_DT_COLS_STRIP=2), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -245,20 +245,29 @@ def test_stage_order_does_not_depend_on_the_batch(engines):
 
 
 @pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 203, 333), np.float16), ((1, 1, 1081, 700), np.float32),
-                                         ((3, 3, 64, 97), np.float32), ((1, 3, 65, 40), np.float16), ((1, 1, 1600, 2100), np.float32)])
+                                         ((3, 3, 64, 97), np.float32), ((1, 3, 65, 40), np.float16), ((1, 1, 1600, 2100), np.float32),
+                                         ((2, 3, 128, 70), np.float32), ((1, 3, 161, 300), np.float32)])
 def test_dt_columns_in_strips(engines, shape, dtype):
     """the column pass of the domain transform (domain_transform.py:56-85) with the down sweep's values formed again strip by
-    strip from one carry per 16 rows (csrc/filters.hip: dt_cols_down_kernel / dt_cols_up_kernel) against the two sweeps
-    through global memory: the same bits -- heights that are and are not multiples of the strip, one and three channels,
-    one and three iterations of the filter -- and the oracle"""
+    strip from one carry per strip (csrc/filters.hip: dt_cols_down_kernel, then dt_cols_up_kernel with the weights formed again
+    from J over 16 rows, or -- three fp32 channels, 128 rows and up -- dt_cols_upw_kernel with the weights the down sweep stored,
+    over 32 rows) against the two sweeps through global memory: the same bits -- heights that are and are not multiples of the
+    strip, one and three channels, one and three iterations of the filter -- and the oracle"""
     rng = np.random.default_rng(29)
     x = rng.random(shape, dtype=np.float32).astype(dtype)
     a = engines["default"].dt_recursive_filter(x, 2.0, 0.8, 1)
     assert np.array_equal(a, engines["dt_cols_sweeps"].dt_recursive_filter(x, 2.0, 0.8, 1))
+    assert np.array_equal(a, engines["dt_cols_reread"].dt_recursive_filter(x, 2.0, 0.8, 1))
     tol = 5e-6 if dtype == np.float32 else 1e-3
     assert np.abs(a.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
     a3 = engines["default"].dt_recursive_filter(x, 6.0, 0.4, 3)
     assert np.array_equal(a3, engines["dt_cols_sweeps"].dt_recursive_filter(x, 6.0, 0.4, 3))
+    assert np.array_equal(a3, engines["dt_cols_reread"].dt_recursive_filter(x, 6.0, 0.4, 3))
+    # a joint image that is not the input (the prefilter's later calls: deblurring.py:80-88)
+    jt = rng.random(shape, dtype=np.float32).astype(dtype)
+    aj = engines["default"].dt_recursive_filter(x, 3.0, 0.5, 2, joint=jt)
+    assert np.array_equal(aj, engines["dt_cols_sweeps"].dt_recursive_filter(x, 3.0, 0.5, 2, joint=jt))
+    assert np.abs(aj.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 3.0, 0.5, 2, jt.astype(np.float32))).max() < tol
 
 
 @pytest.mark.parametrize("kind", ["constant", "nan"])
