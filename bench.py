@@ -612,7 +612,12 @@ def main():
         ms_st = 1e3 * dt_st / args.steps
         side["end_to_end_dense_stencil_body"] = dict(ms_per_step=round(ms_st, 4), mp_per_s=round(B * H * W / 1e6 / (ms_st * 1e-3), 1))
         # the reference's own choice of method on a GPU (main.py:109-112): the zero boundary; and the edgetaper option
-        for name, kw_x in (("end_to_end_method_direct", dict(kw, method="direct")), ("end_to_end_edgetaping", dict(kw, edgetaping=True))):
+        # ... and the other optional stages on the headline image, one at a time (deblurring.py:80-88,172-208; prefiltering=True
+        # is the bilateral filter in the reference, filters.py:107-148, the domain transform its commented-out alternative)
+        for name, kw_x in (("end_to_end_method_direct", dict(kw, method="direct")), ("end_to_end_edgetaping", dict(kw, edgetaping=True)),
+                           ("end_to_end_remove_halo", dict(kw, remove_halo=True)),
+                           ("end_to_end_prefiltering_bilateral", dict(kw, prefiltering=True)),
+                           ("end_to_end_prefiltering_domain_transform", dict(kw, prefiltering=True, prefilter="domain_transform"))):
             try:
                 for _ in range(2):
                     polyblur_deblurring(x, **kw_x)

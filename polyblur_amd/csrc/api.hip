@@ -109,7 +109,7 @@ static void pb_read_knobs(pb_ctx *ctx) {
 #ifdef PB_EXPERIMENTAL
     geti("PB_STRIP", ctx->strip_mode); geti("PB_STRIP_SEG", ctx->strip_seg);
 #endif
-    geti("PB_EST_GRAY_ROWS", ctx->est_gray_rows); geti("PB_EST_LEAN", ctx->est_lean); geti("PB_DT_ROWS_REG", ctx->dt_rows_reg); geti("PB_DT_COLS_STRIP", ctx->dt_cols_strip);
+    geti("PB_EST_GRAY_ROWS", ctx->est_gray_rows); geti("PB_EST_LEAN", ctx->est_lean); geti("PB_DT_ROWS_REG", ctx->dt_rows_reg); geti("PB_DT_COLS_STRIP", ctx->dt_cols_strip); geti("PB_DT_COLS_COOP", ctx->dt_cols_coop);
     geti("PB_FFT_EXT_RADIX", ctx->fft_ext_radix); geti("PB_FFT_FIRST", ctx->fft_first); geti("PB_FFT_FIRST_ROWS", ctx->fft_first_rows); geti("PB_FFT_LOGNB", ctx->fft_lognb); geti("PB_COLS_FIXED", ctx->cols_fixed); geti("PB_ROWS_FIXED", ctx->rows_fixed);
     getl("PB_WAVE_MIN_JOBS", ctx->wave_min_jobs);
     geti("PB_POLY1", ctx->poly_mode); getf("PB_POLY_GAIN", ctx->poly_gain); geti("PB_POLY_MIN_AREA", ctx->poly_min_area);

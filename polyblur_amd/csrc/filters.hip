@@ -630,10 +630,7 @@ template <int C> __device__ __forceinline__ float dt_weight(const float (&jr)[C]
     for (int c = 0; c < C; ++c) dy += fabsf(jr[c] - jp[c]);
     return expf((1.f + ratio * dy) * log_a);
 }
-#ifndef PB_DT_STRIP_W
-#define PB_DT_STRIP_W 32
-#endif
-constexpr int DT_STRIP = 16, DT_STRIP_W = PB_DT_STRIP_W;
+constexpr int DT_STRIP = 16, DT_STRIP_W = 32;
 template <typename TJ, int C, int S, bool WV>
 __global__ __launch_bounds__(NT) void dt_cols_down_kernel(const TJ *__restrict__ J, const float *__restrict__ F, float *__restrict__ carry,
                                                           float *__restrict__ wts, int H, int W, float ratio, float log_a, long cols_total) {
@@ -799,6 +796,161 @@ __global__ __launch_bounds__(NT) void dt_cols_up_kernel(const TJ *__restrict__ J
     }
 }
 
+// ---- the column pass of few columns (round 6) -------------------------------------------------------------------------------
+// One thread per column is B W threads: a single 1080p image is 30 waves, each allowed 63 requests in flight -- 16 KB -- against
+// a latency of ~1.3 us: 0.37 TB/s however the loop is written (measured: down + up sweep 176 + 206 us at B = 1 and at B = 4
+// alike, where the planes' 250 MB would take 50 us).  Here a workgroup owns CG adjacent columns (16 of three channels, 64 of one:
+// 64 bytes per row and channel) and ALL its lanes fetch: blocks of DTC_R rows of F and J straight into LDS (16 bytes per lane,
+// the next block in flight under the present one's arithmetic), all lanes form the block's weights, and one wave -- lane =
+// (channel, column) -- runs the recurrence down the block out of LDS; carries per block; then the blocks bottom-up: the down
+// sweep's values of the block formed again from the carry above it, the up sweep over them in registers, the rows stored 16
+// bytes per lane.  The same operations on the same operands in the same order as dt_cols_fused_kernel: the same bits
+// (tests/test_gpu_round5_forms.py::test_dt_columns_in_strips).  5 words per sample like the strips; the launch is taken where the
+// per-column form cannot fill the chip (pb_dt_filter: cols_total below DTC_MAX_COLS).
+typedef __amdgpu_buffer_rsrc_t dt_rsrc;
+typedef __attribute__((address_space(3))) void dt_lds_void;
+constexpr unsigned DTC_NO_ACCESS = 0x80000000u;        // (an image's planes are smaller than 2 GiB: checked on the host)
+constexpr int DTC_R3 = 96, DTC_R1 = 64;            // rows of a block: three channels (78 KB of LDS, two workgroups per CU), one channel
+constexpr int DTC_CH = 32;                          // rows the recurrence's wave holds in registers at a time
+constexpr long DTC_MAX_COLS = 24576;              // up to here the per-column forms leave CUs idle (tools/bench_dt.py)
+__device__ __forceinline__ void dtc_dma16(dt_rsrc r, void *dst, unsigned voffset) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (dt_lds_void *)dst, 16, (int)voffset, 0, 0, 0);
+#pragma clang diagnostic pop
+}
+template <typename TJ, int C, int R> struct DtCoop {
+    static constexpr int CG = C == 1 ? 64 : 16, L = C * CG;
+    static constexpr int FB = R * L * 4;                                                     // bytes of a block of F: whole KB
+    static constexpr int JB = ((R + 1) * L * (int)sizeof(TJ) + 1023) / 1024 * 1024;         // of J: the row above the block too
+    static constexpr int LDS = 2 * FB + 2 * JB + R * CG * 4;
+    static_assert(FB % 1024 == 0 && R % DTC_CH == 0, "a block of F is whole wave requests and whole chunks of the chain");
+};
+template <typename TJ, int C, int R>
+__global__ __launch_bounds__(NT) void dt_cols_coop_kernel(const TJ *__restrict__ J, float *__restrict__ F, float *__restrict__ carry,
+                                                          int H, int W, float ratio, float log_a, int groups) {
+    using G = DtCoop<TJ, C, R>;
+    constexpr int CG = G::CG, L = G::L, FB = G::FB, JB = G::JB, CH = DTC_CH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dtc_smem[];
+    unsigned char *smem = dtc_smem;
+    float *vb = reinterpret_cast<float *>(smem + 2 * FB + 2 * JB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / groups, col0 = (blockIdx.x - b * groups) * CG;
+    const long HW = (long)H * W;
+    const int nb = (H + R - 1) / R;
+    float *Fi = F + (long)b * C * HW;
+    const dt_rsrc rF = __builtin_amdgcn_make_buffer_rsrc(Fi, 0, (int)(C * HW * 4), 0x00020000);
+    const dt_rsrc rJ = __builtin_amdgcn_make_buffer_rsrc(const_cast<TJ *>(J + (long)b * C * HW), 0, (int)(C * HW * (long)sizeof(TJ)), 0x00020000);
+    float *cw = carry + (long)blockIdx.x * nb * L;
+    auto fbuf = [&](int k) { return reinterpret_cast<float *>(smem + (k & 1) * FB); };
+    auto jbuf = [&](int k) { return reinterpret_cast<TJ *>(smem + 2 * FB + (k & 1) * JB); };
+    // (waves 1 .. 3 fetch; wave 0 runs the recurrence and has no request of its own to wait for in the middle of it)
+    auto request = [&](int k) {
+        if (wave == 0) return;
+        const int r0 = k * R;
+        for (int i = wave - 1; i < FB / 1024; i += NT / 64 - 1) {
+            const int e = (i * 1024 + lane * 16) / 4;
+            const int u = e / L, idx = e - u * L, c = idx / CG, col = idx - c * CG;
+            const bool ok = r0 + u < H && col0 + col < W;
+            dtc_dma16(rF, reinterpret_cast<unsigned char *>(fbuf(k)) + i * 1024, ok ? (unsigned)((c * HW + (long)(r0 + u) * W + col0 + col) * 4) : DTC_NO_ACCESS);
+        }
+        for (int i = wave - 1; i < JB / 1024; i += NT / 64 - 1) {
+            const int e = (i * 1024 + lane * 16) / (int)sizeof(TJ);
+            const int u = e / L, idx = e - u * L, c = idx / CG, col = idx - c * CG, row = r0 - 1 + u;
+            const bool ok = u <= R && row >= 0 && row < H && col0 + col < W;
+            dtc_dma16(rJ, reinterpret_cast<unsigned char *>(jbuf(k)) + i * 1024, ok ? (unsigned)((c * HW + (long)row * W + col0 + col) * (long)sizeof(TJ)) : DTC_NO_ACCESS);
+        }
+    };
+    // the weights of the block's rows (row 0 of the plane has none)
+    auto weights = [&](int k) {
+        const TJ *jb = jbuf(k);
+        for (int p = tid; p < R * CG; p += NT) {
+            const int u = p / CG, col = p - u * CG, r = k * R + u;
+            float jr[C], jp[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { jr[c] = pb_ld(jb + (u + 1) * L + c * CG + col); jp[c] = pb_ld(jb + u * L + c * CG + col); }
+            vb[p] = r >= 1 && r < H ? dt_weight<C>(jr, jp, ratio, log_a) : 0.f;
+        }
+    };
+    // Order of a block's steps: the requests go out AFTER the weights (the compiler waits for every outstanding request before an
+    // LDS read that follows one: behind the weights a request flies under the recurrence instead of being waited for), and the
+    // up sweep's rows are stored one step late, by the fetching waves, while wave 0 is in the next block's recurrence.
+    // Rows 0 and H - 1 need no case of their own: the weight of row 0, and of rows past the end, is 0 (weights()) and
+    // x + 0 (p - x) = x -- the row keeps its value --; rows past the end hold the zeros the requests returned.
+    const int ccol = lane % CG;
+    auto store_rows = [&](int k) {
+        const float *fb = fbuf(k);
+        for (int i = wave - 1; i < FB / 1024; i += NT / 64 - 1) {    // (a wave stores the KB it fetches: its next request into them follows its own reads)
+            const int e = i * 256 + lane * 4, u = e / L, idx = e - u * L, c = idx / CG, col = idx - c * CG, r = k * R + u;
+            if (r < H && col0 + col < W) *reinterpret_cast<float4 *>(Fi + c * HW + (long)r * W + col0 + col) = *reinterpret_cast<const float4 *>(fb + e);
+        }
+    };
+    float prev = 0.f;
+    request(0);
+    for (int k = 0; k < nb; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        weights(k);
+        __syncthreads();
+        if (k + 1 < nb) {                                        // (the last block's down values are formed by the up sweep below)
+            if (wave > 0) {
+                request(k + 1);
+            } else if (lane < L) {
+                const float *fb = fbuf(k);
+                for (int q = 0; q < R; q += CH) {
+                    float x[CH], v[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) { x[u] = fb[(q + u) * L + lane]; v[u] = vb[(q + u) * CG + ccol]; }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) prev = x[u] + v[u] * (prev - x[u]);
+                }
+                cw[k * L + lane] = prev;
+            }
+        }
+    }
+    float fnext = 0.f, vnext = 0.f;
+    for (int k = nb - 1; k >= 0; --k) {
+        if (k != nb - 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            weights(k);
+            __syncthreads();
+        }
+        if (wave > 0) {
+            if (k + 1 < nb) store_rows(k + 1);
+            if (k > 0) request(k - 1);                           // (into the buffer of block k + 1, read out just above)
+        } else if (lane < L) {
+            float *fb = fbuf(k);
+            // the down sweep's values of the block, into LDS in place, ...
+            prev = k > 0 ? cw[(k - 1) * L + lane] : 0.f;
+            for (int q = 0; q < R; q += CH) {
+                float x[CH], v[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) { x[u] = fb[(q + u) * L + lane]; v[u] = vb[(q + u) * CG + ccol]; }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    prev = x[u] + v[u] * (prev - x[u]);
+                    fb[(q + u) * L + lane] = prev;
+                }
+            }
+            // ... and the up sweep over them
+            for (int q = R - CH; q >= 0; q -= CH) {
+                float x[CH], v[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) { x[u] = fb[(q + u) * L + lane]; v[u] = vb[(q + u) * CG + ccol]; }
+#pragma unroll
+                for (int u = CH - 1; u >= 0; --u) {
+                    fnext = x[u] + vnext * (fnext - x[u]);
+                    fb[(q + u) * L + lane] = fnext;
+                    vnext = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave > 0) store_rows(0);
+}
+
 template <typename T> __global__ void to_float_kernel(const T *__restrict__ in, float *__restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = pb_ld(in + i);
 }
@@ -903,16 +1055,38 @@ static int dt_filter_fused(pb_ctx *ctx, const T *in, const T *J, float *out, int
         const float a = (float)std::exp(-std::sqrt(2.0) / sigma_i);
         const float log_a = std::log(a);
         const dim3 rgrid((unsigned)((rows_total + 3) / 4)), cgrid((unsigned)((cols_total + NT - 1) / NT));
-        // (the first iteration of a filter guided by its own input, rows of up to 2048 samples: the row lives in registers)
-        const bool reg_rows = i == 0 && J == in && W <= 2048 && ctx->dt_rows_reg;
+        // (the first iteration of a filter guided by its own input, rows of up to 4096 samples: the row lives in registers)
+        const bool reg_rows = i == 0 && J == in && W <= 4096 && ctx->dt_rows_reg;
         if (reg_rows && W <= 1024)
             hipLaunchKernelGGL((dt_rows_reg_kernel<T, C, 16>), rgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a, rows_total);
-        else if (reg_rows)
+        else if (reg_rows && W <= 2048)
             hipLaunchKernelGGL((dt_rows_reg_kernel<T, C, 32>), rgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a, rows_total);
+        else if (reg_rows)                                       // (a 4K row: one wave per SIMD, ~300 registers)
+            hipLaunchKernelGGL((dt_rows_reg_kernel<T, C, 64>), rgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a, rows_total);
         else if (i == 0)
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, T, C>), rgrid, dim3(NT), 0, ctx->stream, J, in, out, H, W, ratio, log_a, rows_total);
         else
             hipLaunchKernelGGL((dt_rows_fused_kernel<T, float, C>), rgrid, dim3(NT), 0, ctx->stream, J, out, out, H, W, ratio, log_a, rows_total);
+        // few columns: workgroups of CG columns whose lanes all fetch (dt_cols_coop_kernel); 16-byte requests want rows, planes and
+        // operands on 16-byte boundaries
+        {
+            constexpr int CG = C == 1 ? 64 : 16;
+            const int per16 = 16 / (int)sizeof(T);
+            const bool aligned = W % 4 == 0 && W % per16 == 0 && (reinterpret_cast<uintptr_t>(J) | reinterpret_cast<uintptr_t>(out)) % 16 == 0 &&
+                                 (long)C * H * W * 4 < (1l << 31);
+            if (ctx->dt_cols_coop && aligned && (ctx->dt_cols_coop == 2 || cols_total <= DTC_MAX_COLS)) {
+                constexpr int R = C == 1 ? DTC_R1 : DTC_R3;
+                using G = DtCoop<T, C, R>;
+                const int groups = (W + CG - 1) / CG, nb = (H + R - 1) / R;
+                float *cc = static_cast<float *>(pb_scratch(ctx, "dt.carry", sizeof(float) * (size_t)B * groups * nb * C * CG));
+                if (!cc) return PB_ERR_NOMEM;
+                auto k = dt_cols_coop_kernel<T, C, R>;
+                if (G::LDS > 48 * 1024) PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+                hipLaunchKernelGGL(k, dim3((unsigned)(B * groups)), dim3(NT), G::LDS, ctx->stream, J, out, cc, H, W, ratio, log_a, groups);
+                PB_LAUNCH_CHECK();
+                continue;
+            }
+        }
         float *carry = nullptr, *wts = nullptr;
         // (the weights pay where J costs the up sweep more than a word to write and a word to read per pixel: fp32 J of 3 channels;
         //  PB_DT_COLS_STRIP=2: always J again)

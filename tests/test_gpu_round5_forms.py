@@ -39,7 +39,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0), "dt_cols_sweeps": _engine(PB_DT_COLS_STRIP=0), "dt_cols_reread": _engine(PB_DT_COLS_STRIP=2), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "dt_cols_sweeps": _engine(PB_DT_COLS_STRIP=0, PB_DT_COLS_COOP=0), "dt_cols_reread": _engine(PB_DT_COLS_STRIP=2, PB_DT_COLS_COOP=0), "dt_cols_threads": _engine(PB_DT_COLS_COOP=0), "dt_cols_coop": _engine(PB_DT_COLS_COOP=2), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -107,10 +107,12 @@ def test_wide_rank1_kernels_take_one_pass_too(engines):
     assert np.abs(out - out2).max() < 5e-6                                              # (another form: rounding only)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 37, 203), (1, 3, 90, 1920), (1, 1, 33, 1024), (3, 3, 5, 2048), (1, 3, 17, 64), (2, 1, 9, 2)])
+@pytest.mark.parametrize("shape", [(2, 3, 37, 203), (1, 3, 90, 1920), (1, 1, 33, 1024), (3, 3, 5, 2048), (1, 3, 17, 64), (2, 1, 9, 2),
+                                   (1, 3, 21, 3840), (2, 3, 3, 4096), (1, 1, 7, 2500), (1, 3, 4, 4100)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 def test_dt_rows_register_form(engines, shape, dtype):
-    """ragged tails, exactly-full chunks, the widest row the register form takes (2048), two-sample rows; fp32 and fp16"""
+    """ragged tails, exactly-full chunks, the widest rows the three register forms take (1024, 2048, 4096 -- a 4K row), one row
+    beyond them, two-sample rows; fp32 and fp16"""
     rng = np.random.default_rng(23)
     x = rng.random(shape, dtype=np.float32).astype(dtype)
     a = engines["default"].dt_recursive_filter(x, 2.0, 0.8, 1)
@@ -244,30 +246,37 @@ def test_stage_order_does_not_depend_on_the_batch(engines):
                 assert np.array_equal(np.asarray(infos[k][f])[i], np.asarray(oinfos[k][f])[0]), (i, k, f)
 
 
+DT_COLUMN_FORMS = ("default", "dt_cols_threads", "dt_cols_reread", "dt_cols_coop")
+
+
 @pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 203, 333), np.float16), ((1, 1, 1081, 700), np.float32),
                                          ((3, 3, 64, 97), np.float32), ((1, 3, 65, 40), np.float16), ((1, 1, 1600, 2100), np.float32),
-                                         ((2, 3, 128, 70), np.float32), ((1, 3, 161, 300), np.float32)])
+                                         ((2, 3, 128, 70), np.float32), ((1, 3, 161, 300), np.float32), ((2, 3, 203, 336), np.float16),
+                                         ((1, 3, 31, 64), np.float32), ((2, 1, 96, 136), np.float16)])
 def test_dt_columns_in_strips(engines, shape, dtype):
-    """the column pass of the domain transform (domain_transform.py:56-85) with the down sweep's values formed again strip by
-    strip from one carry per strip (csrc/filters.hip: dt_cols_down_kernel, then dt_cols_up_kernel with the weights formed again
-    from J over 16 rows, or -- three fp32 channels, 128 rows and up -- dt_cols_upw_kernel with the weights the down sweep stored,
-    over 32 rows) against the two sweeps through global memory: the same bits -- heights that are and are not multiples of the
-    strip, one and three channels, one and three iterations of the filter -- and the oracle"""
+    """the column pass of the domain transform (domain_transform.py:56-85) in its forms (csrc/filters.hip) against the two sweeps
+    through global memory -- the same bits -- and the oracle:
+    * one thread per column, the down sweep's values formed again strip by strip from one carry per strip: dt_cols_down_kernel,
+      then dt_cols_up_kernel with the weights formed again from J over 16 rows, or -- three fp32 channels, 128 rows and up --
+      dt_cols_upw_kernel with the weights the down sweep stored, over 32 rows;
+    * few columns (what a small batch gets; forced here): dt_cols_coop_kernel, a workgroup per 16 (one channel: 64) columns that
+      streams blocks of 32 rows through LDS -- widths that are and are not whole groups, where rows are not on 16-byte boundaries
+      the per-column forms stand in;
+    heights that are and are not multiples of the strip, one and three channels, one and three iterations of the filter, a joint
+    image of its own"""
     rng = np.random.default_rng(29)
     x = rng.random(shape, dtype=np.float32).astype(dtype)
-    a = engines["default"].dt_recursive_filter(x, 2.0, 0.8, 1)
-    assert np.array_equal(a, engines["dt_cols_sweeps"].dt_recursive_filter(x, 2.0, 0.8, 1))
-    assert np.array_equal(a, engines["dt_cols_reread"].dt_recursive_filter(x, 2.0, 0.8, 1))
-    tol = 5e-6 if dtype == np.float32 else 1e-3
-    assert np.abs(a.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
-    a3 = engines["default"].dt_recursive_filter(x, 6.0, 0.4, 3)
-    assert np.array_equal(a3, engines["dt_cols_sweeps"].dt_recursive_filter(x, 6.0, 0.4, 3))
-    assert np.array_equal(a3, engines["dt_cols_reread"].dt_recursive_filter(x, 6.0, 0.4, 3))
-    # a joint image that is not the input (the prefilter's later calls: deblurring.py:80-88)
     jt = rng.random(shape, dtype=np.float32).astype(dtype)
-    aj = engines["default"].dt_recursive_filter(x, 3.0, 0.5, 2, joint=jt)
-    assert np.array_equal(aj, engines["dt_cols_sweeps"].dt_recursive_filter(x, 3.0, 0.5, 2, joint=jt))
-    assert np.abs(aj.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 3.0, 0.5, 2, jt.astype(np.float32))).max() < tol
+    tol = 5e-6 if dtype == np.float32 else 1e-3
+    want = engines["dt_cols_sweeps"].dt_recursive_filter(x, 2.0, 0.8, 1)
+    want3 = engines["dt_cols_sweeps"].dt_recursive_filter(x, 6.0, 0.4, 3)
+    wantj = engines["dt_cols_sweeps"].dt_recursive_filter(x, 3.0, 0.5, 2, joint=jt)   # (the prefilter's later calls: deblurring.py:80-88)
+    assert np.abs(want.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
+    assert np.abs(wantj.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 3.0, 0.5, 2, jt.astype(np.float32))).max() < tol
+    for form in DT_COLUMN_FORMS:
+        assert np.array_equal(want, engines[form].dt_recursive_filter(x, 2.0, 0.8, 1)), form
+        assert np.array_equal(want3, engines[form].dt_recursive_filter(x, 6.0, 0.4, 3)), form
+        assert np.array_equal(wantj, engines[form].dt_recursive_filter(x, 3.0, 0.5, 2, joint=jt)), form
 
 
 @pytest.mark.parametrize("kind", ["constant", "nan"])

@@ -1,5 +1,6 @@
-"""The domain-transform filter on resident tensors: PB_DT_COLS_STRIP = 1 (weights stored where they pay) / 2 (J again) / 0 (two
-sweeps): time per call and the same bits.  python tools/bench_dt.py [B H W f32|f16 N]"""
+"""The domain-transform filter on resident tensors: the column pass by workgroups of columns (coop), as the library chooses
+(default), one thread per column with PB_DT_COLS_STRIP = 1 (weights stored where they pay) / 2 (J again) / 0 (two sweeps): time
+per call and the same bits as the two sweeps.  python tools/bench_dt.py [B H W f32|f16 N]"""
 import os, sys, json, ctypes, numpy as np, torch
 sys.path.insert(0, '.')
 from polyblur_amd.engine import Engine, _DT
@@ -10,10 +11,12 @@ tdt = torch.float16 if dt == np.float16 else torch.float32
 g = torch.Generator(device="cuda").manual_seed(3)
 x = torch.rand((B, 3, H, W), device="cuda", generator=g).to(tdt).contiguous()
 res, outs = {}, {}
-for mode in (1, 2, 0):
-    os.environ["PB_DT_COLS_STRIP"] = str(mode)
+MODES = {"coop": dict(PB_DT_COLS_COOP=2), "default": {}, "1": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=1), "2": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=2),
+         "0": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=0)}
+for mode, env in MODES.items():
+    os.environ.update({k: str(v) for k, v in env.items()})
     eng = Engine(0)
-    del os.environ["PB_DT_COLS_STRIP"]
+    for k in env: del os.environ[k]
     out = torch.empty((B, 3, H, W), device="cuda", dtype=tdt)
     def call():
         eng._check(eng.lib.pb_dt_recursive_filter(eng.ctx, ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(out.data_ptr()), _DT[np.dtype(dt)], B, 3, H, W, 2.0, 0.8, N))
@@ -28,4 +31,4 @@ for mode in (1, 2, 0):
     res[mode] = round(float(np.median(ts)), 4)
     outs[mode] = out.clone()
 print(json.dumps(dict(shape=[B, 3, H, W], dtype=str(np.dtype(dt)), N=N, ms=res,
-                      same_bits_1_2=bool(torch.equal(outs[1], outs[2])), same_bits_1_0=bool(torch.equal(outs[1], outs[0])))))
+                      same_bits={k: bool(torch.equal(outs[k], outs["0"])) for k in outs})))
