@@ -336,22 +336,34 @@ __global__ __launch_bounds__(NT) void dt_cols_kernel(float *__restrict__ F, cons
 // Wave-level inclusive scan of affine maps (shared slope ma, one intercept per channel) with DPP moves instead of LDS
 // permutes: four row_shr steps inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into
 // rows 2 and 3.  Lanes without a source take the identity map (1, 0), under which compose() returns its argument exactly.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_take(float identity, float src) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+// Round 6: a step is the instructions themselves -- v_fmac_f32_dpp mb, mb(lane - k), ma and v_mul_f32_dpp ma, ma(lane - k), ma, in
+// place: a lane without a source, or in a masked row, is not written and keeps its map, which is what composing with the identity
+// gave it (the builtin form spent a move of the identity and a move_dpp per operand on top of the arithmetic: 72 instructions
+// per scan of three channels against 24; the row kernels are bound by instruction issue once the chip is full).  The products
+// and sums are those of compose().  s_nop 1: a DPP operand wants two wait states behind the VALU write of its register, and the
+// compiler's hazard pass does not look inside asm.
+#define PB_DPP_SHR1 "row_shr:1 row_mask:0xf bank_mask:0xf"
+#define PB_DPP_SHR2 "row_shr:2 row_mask:0xf bank_mask:0xf"
+#define PB_DPP_SHR4 "row_shr:4 row_mask:0xf bank_mask:0xf"
+#define PB_DPP_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf"
+#define PB_DPP_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define PB_DPP_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+#define PB_SCAN_STEP1(CTRL)                                                                                          \
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " CTRL "\n\tv_mul_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 1"            \
+        : "+v"(mb[0]), "+v"(ma))
+#define PB_SCAN_STEP3(CTRL)                                                                                          \
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %3 " CTRL "\n\tv_fmac_f32_dpp %1, %1, %3 " CTRL                          \
+        "\n\tv_fmac_f32_dpp %2, %2, %3 " CTRL "\n\tv_mul_f32_dpp %3, %3, %3 " CTRL                                  \
+        : "+v"(mb[0]), "+v"(mb[1]), "+v"(mb[2]), "+v"(ma))
+template <int C> __device__ __forceinline__ void scan_affine(float &ma, float (&mb)[C]);
+template <> __device__ __forceinline__ void scan_affine<1>(float &ma, float (&mb)[1]) {
+    PB_SCAN_STEP1(PB_DPP_SHR1); PB_SCAN_STEP1(PB_DPP_SHR2); PB_SCAN_STEP1(PB_DPP_SHR4); PB_SCAN_STEP1(PB_DPP_SHR8);
+    PB_SCAN_STEP1(PB_DPP_BC15); PB_SCAN_STEP1(PB_DPP_BC31);
 }
-template <int CTRL, int ROW_MASK, int C> __device__ __forceinline__ void scan_step(float &ma, float (&mb)[C]) {
-    const float pa = dpp_take<CTRL, ROW_MASK>(1.f, ma);
-#pragma unroll
-    for (int c = 0; c < C; ++c) mb[c] = fmaf(ma, dpp_take<CTRL, ROW_MASK>(0.f, mb[c]), mb[c]);
-    ma = ma * pa;
-}
-template <int C> __device__ __forceinline__ void scan_affine(float &ma, float (&mb)[C]) {
-    scan_step<0x111, 0xf>(ma, mb);      // row_shr:1
-    scan_step<0x112, 0xf>(ma, mb);      // row_shr:2
-    scan_step<0x114, 0xf>(ma, mb);      // row_shr:4
-    scan_step<0x118, 0xf>(ma, mb);      // row_shr:8
-    scan_step<0x142, 0xa>(ma, mb);      // row_bcast:15 -> rows 1, 3
-    scan_step<0x143, 0xc>(ma, mb);      // row_bcast:31 -> rows 2, 3
+template <> __device__ __forceinline__ void scan_affine<3>(float &ma, float (&mb)[3]) {
+    PB_SCAN_STEP3(PB_DPP_SHR1); PB_SCAN_STEP3(PB_DPP_SHR2); PB_SCAN_STEP3(PB_DPP_SHR4); PB_SCAN_STEP3(PB_DPP_SHR8);
+    PB_SCAN_STEP3(PB_DPP_BC15); PB_SCAN_STEP3(PB_DPP_BC31);
+    asm("s_nop 1" : "+v"(mb[0]), "+v"(mb[1]), "+v"(mb[2]), "+v"(ma));
 }
 
 template <typename TJ, typename TIN, int C>
@@ -485,8 +497,8 @@ __global__ __launch_bounds__(NT, NCH == 32 ? 3 : 1) void dt_rows_reg_kernel(cons
             float dx = 0.f;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                float left = __shfl_up(x[k][c], 1);
-                if (lane == 0) left = last[c];                               // (sample base - 1: lane 63 of the previous chunk)
+                // sample i - 1: the lane before (wave_shr:1), lane 0 keeps the operand's old value -- lane 63 of the previous chunk
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last[c]), __float_as_int(x[k][c]), 0x138, 0xf, 0xf, false));
                 last[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[k][c]), 63));
                 if (i < W && i > 0) dx += fabsf(x[k][c] - left);
             }
