@@ -150,7 +150,7 @@ struct pb_ctx {
     int est_lean = 1;                    // env PB_EST_LEAN: 0 = the parameter kernel always forms the whole record before the spectra
     int dt_cols_strip = 1;               // env PB_DT_COLS_STRIP: 0 = the domain-transform column pass as two sweeps through global memory (dt_cols_fused_kernel), 2 = strips whose up sweep always forms the weights from J again (dt_cols_up_kernel)
     int dt_cols_coop = 1;                // env PB_DT_COLS_COOP: 0 = never the few-columns form of the column pass (dt_cols_coop_kernel), 2 = always where it applies
-    int dt_rows_reg = 1;                 // env PB_DT_ROWS_REG: 0 = the domain-transform row pass always through global memory (dt_rows_fused_kernel)
+    int dt_rows_reg = 1;                 // env PB_DT_ROWS_REG: 0 = the domain-transform row pass always through global memory (dt_rows_fused_kernel), 2 = registers, one wave per row always, 3 = a row over four waves always (dt_rows_regw_kernel)
     int poly_always = 1;                 // env PB_POLY_ALWAYS: 0 = never PolySpec.always (every polynomial issues all the launches its records might need)
     long side_min_tiles = 12288;         // (PB_SIDE_MIN_TILES until round 6) stencil tiles per launch from which the launches that may find no work go to the side stream
     int main_stream_body = -1;           // (PB_MAIN_STREAM_BODY until round 6) which launch stays on the caller's stream when the others go to the side stream (0 = wave body, 1 = 128 x 128; -1 = by spec)

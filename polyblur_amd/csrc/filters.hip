@@ -583,7 +583,153 @@ __global__ __launch_bounds__(NT, NCH == 32 ? 3 : 1) void dt_rows_reg_kernel(cons
     }
 }
 
+// ---- the register row pass, a row over the four waves of a workgroup (round 6) ---------------------------------------------------
+// One wave per row spends ~0.5 us per 64-sample chunk in the two scans whatever feeds it: a lone 4K image's 2160 rows are 2160
+// waves of 60 chunks each -- 162 us for 200 MB.  The scans of a row's chunks do not depend on one another; only the carry does,
+// and that is one multiply-add per chunk and channel.  Here wave w of the workgroup holds chunks w CPW .. w CPW + CPW - 1 of the
+// row, scans them, leaves the map of each chunk's last sample in LDS, and every wave then walks the carries of the chunks before
+// its own: fmaf(a, carry, b) on the last sample's map is what lane 63's y = fmaf(ma, carry, mb) was in dt_rows_reg_kernel, so
+// the carries, and with them every sample, are the same bits.  The right-to-left pass likewise (chunk k's first weight comes from
+// chunk k + 1: through LDS at the waves' seams).  Rows of up to 256 CPW samples: CPW = 32 takes an 8K row.
+template <typename TIN, int C, int CPW>
+__global__ __launch_bounds__(NT) void dt_rows_regw_kernel(const TIN *in, float *F, int H, int W, float ratio, float log_a) {
+    constexpr int WPR = NT / 64, NCH = WPR * CPW;
+    __shared__ float tail[2][NCH][C + 1];              // [pass][chunk]: the map (a, b[c]) of the chunk's last sample
+    __shared__ float vfirst[NCH + 1];                  // the weight of each chunk's first sample
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, k0 = wv * CPW;
+    const long row_id = blockIdx.x;                    // over B*H: one workgroup = one row, all channels
+    const long b = row_id / H;
+    const int r = (int)(row_id - b * H);
+    const long HW = (long)H * W, off = (b * C * H + r) * (long)W;
+    const TIN *x0 = in + off;
+    float *f = F + off;
+    const int nch = (W + 63) >> 6;
+    float x[CPW][C], v[CPW], ma[CPW];
+    TIN raw[CPW][C], rawl[C];
+    const int klast = nch - 1, lane_last = min(lane, W - 1 - 64 * klast);
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        const int k = k0 + q;
+        const TIN *xk = x0 + 64 * min(k, klast) + (k < klast ? lane : lane_last);      // (chunks past the row: the last chunk again)
+#pragma unroll
+        for (int c = 0; c < C; ++c) raw[q][c] = xk[c * HW];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) rawl[c] = x0[c * HW + min(max(64 * k0 - 1, 0), W - 1)];   // the sample left of this wave's first
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        const int i = 64 * (k0 + q) + lane;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[q][c] = (i < W) ? pb_ld(&raw[q][c]) : 0.f;
+    }
+    // ---- left -> right: the scans
+    float last[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) last[c] = k0 > 0 ? pb_ld(&rawl[c]) : 0.f;
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        const int k = k0 + q, base = 64 * k, i = base + lane;
+        float dx = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last[c]), __float_as_int(x[q][c]), 0x138, 0xf, 0xf, false));
+            last[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[q][c]), 63));
+            if (i < W && i > 0) dx += fabsf(x[q][c] - left);
+        }
+        float vv = 1.f;
+        if (i < W) vv = expf((1.f + ratio * dx) * log_a);
+        v[q] = vv;
+        float a = (i == 0 || i >= W) ? 0.f : vv, mb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) mb[c] = (i == 0 || i >= W) ? x[q][c] : (1.f - vv) * x[q][c];
+        if (i >= W) {
+            a = 1.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) mb[c] = 0.f;
+        }
+        scan_affine<C>(a, mb);
+        ma[q] = a;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[q][c] = mb[c];
+        if (lane == (base + 63 >= W ? max((W - 1) - base, 0) : 63)) {
+            tail[0][k][0] = a;
+#pragma unroll
+            for (int c = 0; c < C; ++c) tail[0][k][1 + c] = mb[c];
+        }
+        if (lane == 0) vfirst[k] = vv;
+    }
+    if (threadIdx.x == 0) vfirst[NCH] = 1.f;
+    __syncthreads();
+    // ... the carries of the chunks before this wave's, then its own samples
+    float carry[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) carry[c] = 0.f;
+    for (int k = 0; k < min(k0, nch); ++k) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) carry[c] = fmaf(tail[0][k][0], carry[c], tail[0][k][1 + c]);
+    }
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        const int base = 64 * (k0 + q);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float y = fmaf(ma[q], carry[c], x[q][c]);
+            x[q][c] = y;
+            carry[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), base + 63 >= W ? max((W - 1) - base, 0) : 63));
+        }
+    }
+    // ---- right -> left, on lane-reversed values: lane l <-> sample i = base + 63 - l; its weight is V[i + 1]
+#pragma unroll
+    for (int q = CPW - 1; q >= 0; --q) {
+        const int k = k0 + q, base = 64 * k, i = base + (63 - lane);
+        float xr[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xr[c] = __shfl(x[q][c], 63 - lane);
+        float vr = __shfl(v[q], (64 - lane) & 63);                           // V[base + 64 - l], l >= 1
+        const float vnext0 = q + 1 < CPW ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[q + 1 < CPW ? q + 1 : q]), 0)) : vfirst[k + 1];
+        if (lane == 0) vr = k + 1 < nch ? vnext0 : 1.f;
+        const float vv = (i + 1 < W) ? vr : 1.f;
+        float a = (i >= W - 1) ? 0.f : vv, mb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) mb[c] = (i >= W - 1) ? xr[c] : (1.f - vv) * xr[c];
+        if (i >= W) {
+            a = 1.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) mb[c] = 0.f;
+        }
+        scan_affine<C>(a, mb);
+        ma[q] = a;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[q][c] = mb[c];
+        if (lane == 63) {
+            tail[1][k][0] = a;
+#pragma unroll
+            for (int c = 0; c < C; ++c) tail[1][k][1 + c] = mb[c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c) carry[c] = 0.f;
+    for (int k = nch - 1; k >= k0 + CPW; --k) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) carry[c] = fmaf(tail[1][k][0], carry[c], tail[1][k][1 + c]);
+    }
+#pragma unroll
+    for (int q = CPW - 1; q >= 0; --q) {
+        const int k = k0 + q, i = 64 * k + (63 - lane);
+        if (k < nch) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float y = fmaf(ma[q], carry[c], x[q][c]);
+                if (i < W) f[c * HW + i] = y;
+                carry[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63));  // sample `base`, the left-most of this chunk
+            }
+        }
+    }
+}
+
 constexpr int DT_UF = 8;
+constexpr long DT_ROWSW_MAX = 8192;                // rows in the batch up to which a row is spread over four waves (tools/bench_dt.py)
 template <typename TJ, int C>
 __global__ __launch_bounds__(NT) void dt_cols_fused_kernel(const TJ *__restrict__ J, float *__restrict__ F, int H, int W,
                                                            float ratio, float log_a, long cols_total) {
@@ -1096,8 +1242,20 @@ static int dt_filter_fused(pb_ctx *ctx, const T *in, const T *J, float *out, int
         const float log_a = std::log(a);
         const dim3 rgrid((unsigned)((rows_total + 3) / 4)), cgrid((unsigned)((cols_total + NT - 1) / NT));
         // (the first iteration of a filter guided by its own input, rows of up to 4096 samples: the row lives in registers)
-        const bool reg_rows = i == 0 && J == in && W <= 4096 && ctx->dt_rows_reg;
-        if (reg_rows && W <= 1024)
+        const bool reg_rows = i == 0 && J == in && W <= 4096 && ctx->dt_rows_reg && ctx->dt_rows_reg != 3;
+        // (few rows: a row over the four waves of a workgroup, dt_rows_regw_kernel -- rows of up to 8192 samples)
+        const bool regw_rows = i == 0 && J == in && W > 256 && W <= 8192 && ctx->dt_rows_reg && ctx->dt_rows_reg != 2 &&
+                               (ctx->dt_rows_reg == 3 || rows_total <= DT_ROWSW_MAX);
+        const dim3 wgrid((unsigned)rows_total);
+        if (regw_rows && W <= 1024)
+            hipLaunchKernelGGL((dt_rows_regw_kernel<T, C, 4>), wgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a);
+        else if (regw_rows && W <= 2048)
+            hipLaunchKernelGGL((dt_rows_regw_kernel<T, C, 8>), wgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a);
+        else if (regw_rows && W <= 4096)
+            hipLaunchKernelGGL((dt_rows_regw_kernel<T, C, 16>), wgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a);
+        else if (regw_rows)
+            hipLaunchKernelGGL((dt_rows_regw_kernel<T, C, 32>), wgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a);
+        else if (reg_rows && W <= 1024)
             hipLaunchKernelGGL((dt_rows_reg_kernel<T, C, 16>), rgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a, rows_total);
         else if (reg_rows && W <= 2048)
             hipLaunchKernelGGL((dt_rows_reg_kernel<T, C, 32>), rgrid, dim3(NT), 0, ctx->stream, in, out, H, W, ratio, log_a, rows_total);

@@ -39,7 +39,7 @@ def _engine(**env):
 @pytest.fixture(scope="module")
 def engines():
     return {"default": _engine(), "full_record": _engine(PB_EST_LEAN=0), "every_launch": _engine(PB_POLY_ALWAYS=0),
-            "dt_global": _engine(PB_DT_ROWS_REG=0), "dt_cols_sweeps": _engine(PB_DT_COLS_STRIP=0, PB_DT_COLS_COOP=0), "dt_cols_reread": _engine(PB_DT_COLS_STRIP=2, PB_DT_COLS_COOP=0), "dt_cols_threads": _engine(PB_DT_COLS_COOP=0), "dt_cols_coop": _engine(PB_DT_COLS_COOP=2), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
+            "dt_global": _engine(PB_DT_ROWS_REG=0), "dt_rows_wave": _engine(PB_DT_ROWS_REG=2), "dt_rows_regw": _engine(PB_DT_ROWS_REG=3), "dt_cols_sweeps": _engine(PB_DT_COLS_STRIP=0, PB_DT_COLS_COOP=0), "dt_cols_reread": _engine(PB_DT_COLS_STRIP=2, PB_DT_COLS_COOP=0), "dt_cols_threads": _engine(PB_DT_COLS_COOP=0), "dt_cols_coop": _engine(PB_DT_COLS_COOP=2), "taper_three_steps": _engine(PB_POLY_PADDED=0), "taper_full_blends": _engine(PB_TAPER_RING=0), "direct_three_steps": _engine(PB_ZERO_RING=0), "direct_ring": _engine(PB_ZERO_RING_MIN_PAIRS=1)}
 
 
 KW = dict(c=0.362, b=0.468, alpha=6.0, beta=1.0)
@@ -108,20 +108,23 @@ def test_wide_rank1_kernels_take_one_pass_too(engines):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 37, 203), (1, 3, 90, 1920), (1, 1, 33, 1024), (3, 3, 5, 2048), (1, 3, 17, 64), (2, 1, 9, 2),
-                                   (1, 3, 21, 3840), (2, 3, 3, 4096), (1, 1, 7, 2500), (1, 3, 4, 4100)])
+                                   (1, 3, 21, 3840), (2, 3, 3, 4096), (1, 1, 7, 2500), (1, 3, 4, 4100), (1, 3, 3, 7680), (1, 1, 2, 8192),
+                                   (2, 3, 5, 257), (1, 3, 6, 1025), (1, 1, 4, 8200)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float16])
 def test_dt_rows_register_form(engines, shape, dtype):
-    """ragged tails, exactly-full chunks, the widest rows the three register forms take (1024, 2048, 4096 -- a 4K row), one row
-    beyond them, two-sample rows; fp32 and fp16"""
+    """the domain transform's row pass with the row in registers (csrc/filters.hip) against the pass through global memory
+    (domain_transform.py:56-85) -- the same bits -- and the oracle: one wave per row (dt_rows_reg_kernel: rows of up to 1024, 2048,
+    4096 samples) and a row over the four waves of a workgroup (dt_rows_regw_kernel: what few rows get; up to 8192 samples) --
+    ragged tails, exactly-full chunks, the widest rows each form takes and one sample beyond, two-sample rows; fp32 and fp16"""
     rng = np.random.default_rng(23)
     x = rng.random(shape, dtype=np.float32).astype(dtype)
-    a = engines["default"].dt_recursive_filter(x, 2.0, 0.8, 1)
-    b = engines["dt_global"].dt_recursive_filter(x, 2.0, 0.8, 1)
-    assert np.array_equal(a, b)
+    want = engines["dt_global"].dt_recursive_filter(x, 2.0, 0.8, 1)
+    want3 = engines["dt_global"].dt_recursive_filter(x, 6.0, 0.4, 3)                    # (later iterations: the in-place pass)
     tol = 5e-6 if dtype == np.float32 else 1e-3
-    assert np.abs(a.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
-    a3 = engines["default"].dt_recursive_filter(x, 6.0, 0.4, 3)                          # (later iterations: the in-place pass)
-    assert np.array_equal(a3, engines["dt_global"].dt_recursive_filter(x, 6.0, 0.4, 3))
+    assert np.abs(want.astype(np.float32) - ref.recursive_filter(x.astype(np.float32), 2.0, 0.8, 1)).max() < tol
+    for form in ("default", "dt_rows_wave", "dt_rows_regw"):
+        assert np.array_equal(want, engines[form].dt_recursive_filter(x, 2.0, 0.8, 1)), form
+        assert np.array_equal(want3, engines[form].dt_recursive_filter(x, 6.0, 0.4, 3)), form
 
 
 @pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 800, 1000), np.float16), ((1, 3, 200, 300), np.float32)])

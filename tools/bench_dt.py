@@ -11,7 +11,7 @@ tdt = torch.float16 if dt == np.float16 else torch.float32
 g = torch.Generator(device="cuda").manual_seed(3)
 x = torch.rand((B, 3, H, W), device="cuda", generator=g).to(tdt).contiguous()
 res, outs = {}, {}
-MODES = {"coop": dict(PB_DT_COLS_COOP=2), "default": {}, "1": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=1), "2": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=2),
+MODES = {"coop": dict(PB_DT_COLS_COOP=2), "rows4w": dict(PB_DT_ROWS_REG=3), "rows1w": dict(PB_DT_ROWS_REG=2), "default": {}, "1": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=1), "2": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=2),
          "0": dict(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=0)}
 for mode, env in MODES.items():
     os.environ.update({k: str(v) for k, v in env.items()})

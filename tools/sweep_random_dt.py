@@ -1,5 +1,5 @@
 """The domain-transform filter on random shapes (python tools/sweep_random_dt.py [first last]): the default engine (register rows,
-strips / stored weights / workgroups of columns as the library chooses), the same with the few-columns form forced, and the forms
+strips / stored weights / workgroups of columns as the library chooses), the same with the few-columns and the four-waves-per-row forms forced, one wave per row and thread per column, and the forms
 through global memory -- the same bits -- against the oracle; and the forced few-columns form twenty times over on one input."""
 import os, sys, numpy as np
 sys.path.insert(0, '.')
@@ -16,13 +16,13 @@ def engine(**env):
 
 
 a, b = (int(v) for v in sys.argv[1:3]) if len(sys.argv) > 2 else (0, 150)
-engs = {"default": engine(), "coop": engine(PB_DT_COLS_COOP=2), "global": engine(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=0, PB_DT_ROWS_REG=0)}
+engs = {"default": engine(), "coop": engine(PB_DT_COLS_COOP=2, PB_DT_ROWS_REG=3), "wave": engine(PB_DT_ROWS_REG=2, PB_DT_COLS_COOP=0), "global": engine(PB_DT_COLS_COOP=0, PB_DT_COLS_STRIP=0, PB_DT_ROWS_REG=0)}
 bad = 0; worst = {np.float32: 0.0, np.float16: 0.0}
 for i in range(a, b):
     rng = np.random.default_rng(9000 + i)
     B, C = int(rng.integers(1, 5)), int(rng.choice([1, 3]))
     H = int(rng.choice([rng.integers(2, 40), rng.integers(40, 500), 96 * int(rng.integers(1, 5)), 96 * int(rng.integers(1, 5)) + 1]))
-    W = int(rng.choice([rng.integers(2, 80), 4 * rng.integers(1, 200), 8 * rng.integers(1, 120), 16 * rng.integers(1, 80), 64 * rng.integers(1, 20), rng.integers(80, 900)]))
+    W = int(rng.choice([rng.integers(2, 80), rng.integers(2000, 8300), 4 * rng.integers(1, 200), 8 * rng.integers(1, 120), 16 * rng.integers(1, 80), 64 * rng.integers(1, 20), rng.integers(80, 900)]))
     dt = rng.choice([np.float32, np.float16])
     N = int(rng.integers(1, 4))
     ss, sr = float(rng.uniform(1.0, 60.0)), float(rng.uniform(0.1, 1.0))
@@ -32,7 +32,7 @@ for i in range(a, b):
     want = ref.recursive_filter(x.astype(np.float32), ss, sr, N, None if jt is None else jt.astype(np.float32))
     err = float(np.abs(outs["default"].astype(np.float32) - want).max())
     tol = 2e-5 if dt == np.float32 else 1e-3
-    same = all(np.array_equal(outs["global"], outs[k]) for k in ("default", "coop"))
+    same = all(np.array_equal(outs["global"], outs[k]) for k in ("default", "coop", "wave"))
     worst[dt] = max(worst[dt], err)
     if not same or err >= tol:
         bad += 1
