@@ -271,6 +271,11 @@ int pb_build_khat(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb
 int pb_build_khat_ring(pb_ctx *ctx, const pb_blur_info *info, int B, float **khat, pb_fft_sel **sel);   // conv_fft.hip: the kernels' OWN spectra, every symmetric kernel on three-step windows, in a second scratch set
 int pb_khat_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel);   // the scratch alone (the estimation fills it itself)
 int pb_khat2_buffers(pb_ctx *ctx, int B, float **khat, pb_fft_sel **sel);  // ... of the second set
+// the spec under which the spectra a pass reads were built: the second set's where the pass reads that set (the polynomial behind
+// an edgetaper, whose FIRST set holds the blends' kernels -- job lists sized from the first set's spec were too short there)
+inline const PolySpec &pb_spec_of_spectra(const pb_ctx *ctx, const void *khat) {
+    return khat && khat == ctx->khat2_buf ? ctx->khat2_spec : ctx->poly_built;
+}
 int pb_cache_records(pb_ctx *ctx, const pb_blur_info *info, int B);        // conv.hip: after the host (re)built these records
 void pb_forget_records(pb_ctx *ctx, const void *info, int B);                 // B records at info are about to be rewritten; nullptr: all
 void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes);            // a host write into device memory

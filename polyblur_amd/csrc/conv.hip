@@ -415,7 +415,7 @@ static int launch_tile_spectrum(pb_ctx *ctx, const ConvPass &p) {
         const int rc = pb_launch_conv_wfft(ctx, p);
         if (rc != PB_ERR_UNSUPPORTED) return rc;
     }
-    if (p.poly != 0 && ctx->poly_built.on >= 2)
+    if (p.poly != 0 && pb_spec_of_spectra(ctx, p.khat).on >= 2)
         return pb_fail(ctx, PB_ERR_UNSUPPORTED, "one-pass polynomial with per-axis halos: the wave form does not take this pass");
     return pb_launch_conv_fft(ctx, p);
 }

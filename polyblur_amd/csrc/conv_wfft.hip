@@ -854,7 +854,7 @@ bool pb_conv_wfft_types(const ConvPass &p) {
 int pb_launch_conv_wfft(pb_ctx *ctx, const ConvPass &p) {
     const long min_jobs = ctx->wave_min_jobs;
     if (!pb_conv_wfft_types(p)) return PB_ERR_UNSUPPORTED;
-    const bool poly2 = p.poly != 0 && ctx->poly_built.on >= 2;
+    const bool poly2 = p.poly != 0 && pb_spec_of_spectra(ctx, p.khat).on >= 2;
     const float min_area = (float)ctx->poly_min_area;      // (the smallest one-pass tile the cost model of khat.h admits)
     WGeom g;
     long per_max = 0, pairs12 = 0;

@@ -127,6 +127,25 @@ def test_dt_rows_register_form(engines, shape, dtype):
         assert np.array_equal(want3, engines[form].dt_recursive_filter(x, 6.0, 0.4, 3)), form
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 189, 68), (1, 3, 189, 80), (2, 3, 300, 72), (1, 1, 240, 76), (1, 3, 68, 189), (3, 3, 189, 90)])
+def test_edgetaper_then_one_pass_on_narrow_images(engines, shape):
+    """edgetaping=True on images a few tiles wide: the polynomial behind the blends reads the SECOND set of spectra (the estimation
+    builds it under the polynomial's own spec, the first set holds the blends' kernels), and the job list of its window launch
+    has to be sized under THAT spec -- sized under the first set's (halos up to 12) it was one pair per row short wherever a
+    halo of 16 makes three tiles of what 12 makes two: widths 65 .. 80 lost their second and third planes (found by
+    tools/sweep_random.py, case 41: 189 x 68).  Against the oracle, and against the call that issues every launch."""
+    B, C, H, W = shape
+    x, _ = synthetic_blurry_batch(B, C, H, W, seed0=787)
+    kw = dict(n_iter=2, edgetaping=True, c=0.31, b=0.43, alpha=6.0, beta=3.0)
+    out, infos = _run(engines["default"], x, **kw)
+    want, winfos = ref.polyblur_deblurring(x, return_info=True, **kw)
+    for ia, iw in zip(infos, winfos):
+        assert np.array_equal(np.asarray(ia["theta"], np.float32).reshape(-1), np.asarray(iw["theta"], np.float32).reshape(-1))
+    assert np.abs(out - want).max() < 2e-5
+    out2, _ = _run(engines["every_launch"], x, **kw)
+    assert np.abs(out - out2).max() < 5e-6
+
+
 @pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 800, 1000), np.float16), ((1, 3, 200, 300), np.float32)])
 def test_edgetaper_copies_and_one_pass(engines, shape, dtype):
     """edgetaping=True: the blends copy every tile pair on which alpha is exactly 1 (edgetaper.py:10-23: everything further than
