@@ -634,11 +634,13 @@ int pb_launch_conv_poly(pb_ctx *ctx, const ConvPass *steps) {
             const int rc = pb_launch_conv(ctx, p);
             if (rc) return rc;
         }
-        if (poly_on && !fold && ctx->poly_built.on && ctx->khat_owner == steps[0].info && ctx->khat_B == B) {
+        if (poly_on && !fold) {
+            // (the spectra the three steps have just used -- the first set's, or the second's behind an edgetaper -- and the spec they
+            // were built under: images with a one-pass record wait for this launch)
             float *k = nullptr; pb_fft_sel *sel = nullptr;
             const int rc = pb_build_khat(ctx, steps[0].info, B, &k, &sel, false);
             if (rc) return rc;
-            return composite(k, sel);
+            if (pb_spec_of_spectra(ctx, k).on) return composite(k, sel);
         }
         return PB_OK;
     }

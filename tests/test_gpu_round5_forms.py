@@ -146,6 +146,21 @@ def test_edgetaper_then_one_pass_on_narrow_images(engines, shape):
     assert np.abs(out - out2).max() < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 189, 72), (2, 3, 400, 600)])
+def test_edgetaper_fp16_output_when_every_launch_is_issued(engines, shape):
+    """fp16 images with edgetaping=True under PB_POLY_ALWAYS=0: the last iteration's polynomial stores fp16 while its first step
+    stores fp32, so the one-pass images wait for a launch of their own behind the three steps (csrc/conv.hip: pb_launch_conv_poly)
+    -- which must follow the set of spectra the steps read (the second, behind an edgetaper), not the first set's spec"""
+    B, C, H, W = shape
+    x, _ = synthetic_blurry_batch(B, C, H, W, seed0=787)
+    x = x.astype(np.float16)
+    kw = dict(n_iter=2, edgetaping=True, c=0.31, b=0.43, alpha=6.0, beta=3.0)
+    want = ref.polyblur_deblurring(x.astype(np.float32), **kw)
+    for name in ("default", "every_launch"):
+        out, _ = _run(engines[name], x, **kw)
+        assert np.abs(out.astype(np.float32) - want).max() < 1e-3, name
+
+
 @pytest.mark.parametrize("shape,dtype", [((1, 3, 720, 1280), np.float32), ((2, 3, 800, 1000), np.float16), ((1, 3, 200, 300), np.float32)])
 def test_edgetaper_copies_and_one_pass(engines, shape, dtype):
     """edgetaping=True: the blends copy every tile pair on which alpha is exactly 1 (edgetaper.py:10-23: everything further than
