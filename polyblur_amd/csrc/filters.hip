@@ -983,13 +983,14 @@ __global__ __launch_bounds__(NT) void dt_cols_up_kernel(const TJ *__restrict__ J
 // One thread per column is B W threads: a single 1080p image is 30 waves, each allowed 63 requests in flight -- 16 KB -- against
 // a latency of ~1.3 us: 0.37 TB/s however the loop is written (measured: down + up sweep 176 + 206 us at B = 1 and at B = 4
 // alike, where the planes' 250 MB would take 50 us).  Here a workgroup owns CG adjacent columns (16 of three channels, 64 of one:
-// 64 bytes per row and channel) and ALL its lanes fetch: blocks of DTC_R rows of F and J straight into LDS (16 bytes per lane,
-// the next block in flight under the present one's arithmetic), all lanes form the block's weights, and one wave -- lane =
-// (channel, column) -- runs the recurrence down the block out of LDS; carries per block; then the blocks bottom-up: the down
-// sweep's values of the block formed again from the carry above it, the up sweep over them in registers, the rows stored 16
-// bytes per lane.  The same operations on the same operands in the same order as dt_cols_fused_kernel: the same bits
+// 64 bytes per row and channel) and ALL its lanes fetch: blocks of DTC_R3 (one channel: DTC_R1) rows of F and J straight into LDS (16 bytes
+// per lane, waves 1 - 3; the next block in flight under the present one's recurrence), all lanes form the block's weights, and wave 0
+// -- lane = (channel, column) -- runs the recurrence down the block out of LDS; carries per block; then the blocks bottom-up: the
+// down sweep's values of the block formed again from the carry above it, the up sweep over them, the rows stored 16 bytes per lane
+// one block late, under the next block's recurrence.  Rows 0 and H - 1 need no case of their own: their weights are 0 and
+// x + 0 (p - x) = x (a sample that is -0 comes out as +0: the only difference in bits there can be).  The same operations on the same operands in the same order as dt_cols_fused_kernel: the same bits
 // (tests/test_gpu_round5_forms.py::test_dt_columns_in_strips).  5 words per sample like the strips; the launch is taken where the
-// per-column form cannot fill the chip (pb_dt_filter: cols_total below DTC_MAX_COLS).
+// per-column form cannot fill the chip (dt_filter_fused: cols_total up to DTC_MAX_COLS).
 typedef __amdgpu_buffer_rsrc_t dt_rsrc;
 typedef __attribute__((address_space(3))) void dt_lds_void;
 constexpr unsigned DTC_NO_ACCESS = 0x80000000u;        // (an image's planes are smaller than 2 GiB: checked on the host)
