@@ -303,6 +303,15 @@ def _patchwise_deblurring(images, patch_size, overlap, batch_size, kwargs, devic
         raise TypeError("tensor dtype must be float32 or float16")
     if kwargs.pop("return_info", False):
         raise TypeError("return_info is not available with patch_decomposition=True (one record set per patch group)")
+    # (the lattice first: a plain error for what the reference's arithmetic leaves without a single patch -- an image shorter than
+    #  patch_size - step along an axis gives new_h < patch_size at deblurring.py:284-285 and an empty I_coords at :294: the
+    #  reference's branch, could it run, would return zeros there)
+    if min(patch_size) < 2 or int(patch_size[0] * (1 - overlap)) < 1 or int(patch_size[1] * (1 - overlap)) < 1:
+        raise ValueError("patch size / overlap incompatible: patches of at least 2x2 with a positive step are needed")
+    g0 = patch_grid(images.shape[-2] // 2 * 2, images.shape[-1] // 2 * 2, patch_size, overlap)
+    if g0["n_i"] < 1 or g0["n_j"] < 1:
+        raise ValueError("image %dx%d is smaller than patch_size - step along an axis: the reference's lattice (deblurring.py:284-295) "
+                         "holds no patch for it -- use a smaller patch_size or patch_decomposition=False" % (images.shape[-2], images.shape[-1]))
     was_cuda = images.is_cuda
     want = _device_index(device)
     if was_cuda:

@@ -114,6 +114,19 @@ def test_patch_lattice_matches_reference_formulas():
         assert np.abs(kaiser_window_periodic(n) - torch.kaiser_window(n, periodic=True, beta=5.0).numpy()).max() < 1e-6
 
 
+def test_patch_lattice_without_a_patch_is_refused():
+    """an image shorter than patch_size - step along an axis: deblurring.py:284-295 gives new_h < patch_size and no patch
+    corner at all (the reference's branch would return zeros); the host says so before anything reaches the GPU"""
+    import torch
+    from polyblur_amd import PolyblurDeblurring
+    from polyblur_amd.deblurring import patch_grid
+    assert patch_grid(100, 298, (400, 400), 0.4)["n_i"] == 0
+    with pytest.raises(ValueError, match="holds no patch"):
+        PolyblurDeblurring(patch_decomposition=True, patch_size=400, patch_overlap=0.4)(torch.zeros(1, 3, 100, 299))
+    with pytest.raises(ValueError, match="positive step"):
+        PolyblurDeblurring(patch_decomposition=True, patch_size=1, patch_overlap=0.5)(torch.zeros(1, 3, 64, 64))
+
+
 def test_comm_shards_match_the_python_layer(lib):
     """pb_comm_shard (csrc/comm.hip) and polyblur_amd.distributed.shard_bounds cut a batch the same way."""
     from polyblur_amd.distributed import shard_bounds
