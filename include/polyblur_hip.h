@@ -230,7 +230,11 @@ int pb_estimate_blur(pb_ctx *ctx, const void *in, int dtype, int B, int C, int H
  * makes the context forget); after a raw copy into them call pb_set_dense_eval, which forgets everything.         */
 int pb_make_kernels(pb_ctx *ctx, int B, const float *host_sigma, const float *host_rho,
                     const float *host_theta_rad, int support, pb_blur_info *dev_info);
-/* Same, but the caller supplies arbitrary 25x25 taps (host, B*625 floats). */
+/* Same, but the caller supplies arbitrary 25x25 taps (host, B*625 floats), in the orientation of the reference's kernel
+ * tensors.  The reference applies such a kernel as a correlation under method='direct' (F.conv2d, filters.py:40-49) and as a
+ * true circular convolution under method='fft' (K = p2o(kernel), filters.py:33-36) -- the same thing for point-symmetric
+ * taps only.  The stage entry points follow it: with PB_ZERO the taps as given, with PB_WRAP -- where they are not
+ * point-symmetric -- their point reflection (a second set of records built on the fly).                                 */
 int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_blur_info *dev_info);
 
 /* method='direct_separable' (pb_options.separable_approx): from B records that hold (sigma, rho, theta) build the two

@@ -228,8 +228,25 @@ int pb_malloc(pb_ctx *ctx, void **dptr, size_t bytes) {
     return PB_OK;
 }
 int pb_free(pb_ctx *ctx, void *dptr) {
-    if (ctx) pb_forget_records(ctx, nullptr, 0);
     if (!ctx) return PB_ERR_BADARG;
+    {
+        // what the context has cached about records is a hint and goes wholesale; which caller-supplied record sets hold taps that
+        // are not point-symmetric is not (common.h: FlipSet): only the sets inside the allocation being freed are dropped
+        auto keep = std::move(ctx->flip_sets);
+        pb_forget_records(ctx, nullptr, 0);
+        hipDeviceptr_t base = nullptr; size_t size = 0;
+        if (dptr && hipMemGetAddressRange(&base, &size, dptr) == hipSuccess) {
+            const char *lo = static_cast<const char *>(static_cast<void *>(base)), *hi = lo + size;
+            for (auto it = keep.begin(); it != keep.end();) {
+                const char *a = static_cast<const char *>(it->first);
+                if (a >= lo && a < hi) it = keep.erase(it); else ++it;
+            }
+        } else {
+            (void)hipGetLastError();
+            keep.erase(dptr);
+        }
+        ctx->flip_sets = std::move(keep);
+    }
     PB_HIP(hipStreamSynchronize(ctx->stream));
     PB_HIP(hipFree(dptr));
     return PB_OK;
@@ -565,8 +582,48 @@ int pb_set_kernels(pb_ctx *ctx, int B, const float *host_taps, int support, pb_b
     for (int i = 0; i < B; ++i) memcpy(h[i].kernel, host_taps + (size_t)i * PB_KSIZE * PB_KSIZE, sizeof(float) * PB_KSIZE * PB_KSIZE);
     PB_HIP(hipMemcpyAsync(dev_info, h.data(), sizeof(pb_blur_info) * B, hipMemcpyHostToDevice, ctx->stream));
     PB_HIP(hipStreamSynchronize(ctx->stream));
-    const int rc = pb_make_kernels_dev(ctx, B, dev_info, support, 1);
-    return rc ? rc : pb_cache_records(ctx, dev_info, B);
+    int rc = pb_make_kernels_dev(ctx, B, dev_info, support, 1);
+    if (!rc) rc = pb_cache_records(ctx, dev_info, B);             // (forgets what was known about these records, flip set included)
+    if (rc) return rc;
+    // taps that are not point-symmetric: keep their reflection for the wrap boundary's passes (common.h: FlipSet)
+    bool asym = false;
+    for (int i = 0; i < B && !asym; ++i) {
+        const float *k = host_taps + (size_t)i * PB_KSIZE * PB_KSIZE;
+        for (int e = 0; e < PB_KSIZE * PB_KSIZE / 2 && !asym; ++e) asym = k[e] != k[PB_KSIZE * PB_KSIZE - 1 - e];
+    }
+    if (asym) {
+        pb_ctx::FlipSet f;
+        f.B = B; f.support = support;
+        f.taps.resize((size_t)B * PB_KSIZE * PB_KSIZE);
+        for (int i = 0; i < B; ++i)
+            for (int e = 0; e < PB_KSIZE * PB_KSIZE; ++e)
+                f.taps[(size_t)i * PB_KSIZE * PB_KSIZE + e] = host_taps[(size_t)i * PB_KSIZE * PB_KSIZE + (PB_KSIZE * PB_KSIZE - 1 - e)];
+        ctx->flip_sets[dev_info] = std::move(f);
+    }
+    return PB_OK;
+}
+
+// The records a wrap-boundary pass runs with: the caller's, or -- caller-supplied taps that are not point-symmetric -- a copy built
+// from the reflected taps (the reference's method='fft' convolves, filters.py:33-36; the records hold correlation taps).
+static int wrap_records(pb_ctx *ctx, const pb_blur_info *dev_info, int B, int boundary, const pb_blur_info **use) {
+    *use = dev_info;
+    if (boundary != PB_WRAP) return PB_OK;
+    const auto it = ctx->flip_sets.find(dev_info);
+    if (it == ctx->flip_sets.end() || it->second.B < B) return PB_OK;
+    pb_blur_info *flipped = static_cast<pb_blur_info *>(pb_scratch(ctx, "conv.flipinfo", sizeof(pb_blur_info) * (size_t)B));
+    if (!flipped) return PB_ERR_NOMEM;
+    std::vector<pb_blur_info> h(B);
+    memset(h.data(), 0, sizeof(pb_blur_info) * B);
+    for (int i = 0; i < B; ++i) memcpy(h[i].kernel, it->second.taps.data() + (size_t)i * PB_KSIZE * PB_KSIZE, sizeof(float) * PB_KSIZE * PB_KSIZE);
+    const int support = it->second.support;
+    pb_forget_records(ctx, flipped, B);
+    PB_HIP(hipMemcpyAsync(flipped, h.data(), sizeof(pb_blur_info) * B, hipMemcpyHostToDevice, ctx->stream));
+    PB_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = pb_make_kernels_dev(ctx, B, flipped, support, 1);
+    if (!rc) rc = pb_cache_records(ctx, flipped, B);
+    if (rc) return rc;
+    *use = flipped;
+    return PB_OK;
 }
 
 int pb_fourier_gradients(pb_ctx *ctx, const float *planes, int P, int H, int W, float *gx, float *gy) {
@@ -591,7 +648,10 @@ int pb_inverse_filter(pb_ctx *ctx, const void *in, void *out, int dtype, int B, 
         rc = pb_grad_energy(ctx, grad0_x, grad0_y, nM, g.P, g.HW);
         if (rc) return rc;
     }
-    return inverse_filter(ctx, g, in, dtype, out, dtype, dev_info, alpha, beta, boundary, edgetaping, remove_halo, grad0_x,
+    const pb_blur_info *recs = nullptr;
+    rc = wrap_records(ctx, dev_info, B, boundary, &recs);
+    if (rc) return rc;
+    return inverse_filter(ctx, g, in, dtype, out, dtype, recs, alpha, beta, boundary, edgetaping, remove_halo, grad0_x,
                           grad0_y, nM, 1);
 }
 
@@ -602,7 +662,10 @@ int pb_convolve2d(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp
     // The given image IS the padded domain: address it as a padded source with pitch Wp.
     Geometry g = geometry(B, C, Hp - 2 * PB_KRAD, Wp - 2 * PB_KRAD);
     g.pp = Wp; g.pplane = (long)Hp * Wp;
-    ConvPass p = base_pass(g, dev_info, boundary);
+    const pb_blur_info *recs = nullptr;
+    const int rcw = wrap_records(ctx, dev_info, B, boundary, &recs);
+    if (rcw) return rcw;
+    ConvPass p = base_pass(g, recs, boundary);
     set_in_padded(p, g, in); set_x_padded(p, g, in); set_out_padded(p, g, out);
     p.scale = 1.f; p.coef = 0.f;
     return pb_launch_conv(ctx, p);
@@ -616,7 +679,10 @@ int pb_edgetaper(pb_ctx *ctx, const float *in, float *out, int B, int C, int Hp,
     g.pp = Wp; g.pplane = (long)Hp * Wp;
     float *tmp = static_cast<float *>(pb_scratch(ctx, "taper.tmp", sizeof(float) * g.P * g.pplane));
     if (!tmp) return PB_ERR_NOMEM;
-    ConvPass p = base_pass(g, dev_info, boundary);
+    const pb_blur_info *recs = nullptr;
+    const int rcw = wrap_records(ctx, dev_info, B, boundary, &recs);
+    if (rcw) return rcw;
+    ConvPass p = base_pass(g, recs, boundary);
     p.epilogue = EPI_TAPER;
     set_in_padded(p, g, in); set_x_padded(p, g, in); set_out_padded(p, g, out);
     int rc = pb_launch_conv(ctx, p);

@@ -101,6 +101,13 @@ struct pb_ctx {
     struct BodyFlags { bool any_fft = false, any_other = false, any_strip = false, any_tile = false, any_fft3 = false; };
     struct RecFlags { int B; BodyFlags plain; bool poly_valid; PolySpec spec; BodyFlags poly; std::vector<pb_fft_sel> sel; };
     std::map<const void *, RecFlags> rec_cache;
+    // Caller-supplied taps that are not point-symmetric (pb_set_kernels): the records hold them as CORRELATION taps -- what
+    // F.conv2d applies, filters.py:40-49, method='direct' --, while the reference's method='fft' is a true circular convolution
+    // (filters.py:33-36: K = p2o(kernel)), i.e. the point-reflected taps.  The wrap-boundary stage entry points run such records
+    // through a reflected copy (api.hip: wrap_records); the host keeps the reflected taps for that.  (The pipeline's own kernels
+    // are point-symmetric, or -- even ker_size -- placed per method by the parameter kernel: nothing to reflect there.)
+    struct FlipSet { int B; int support; std::vector<float> taps; };
+    std::map<const void *, FlipSet> flip_sets;
     int sel_slot = 0, sel_last = 0, sel_B = 0;           // "conv.fftsel" holds PB_SEL_SLOTS runs of sel_B records: the slot passes write to / read from
     const std::vector<pb_fft_sel> *known_sel = nullptr;   // the records of the pass being launched, where the host has them (sizes its job grid)
     const void *khat_owner = nullptr;    // record set whose spectra "conv.khat" holds (nullptr: unknown)

@@ -710,6 +710,10 @@ void pb_forget_range(pb_ctx *ctx, const void *dst, size_t bytes) {
             it = ctx->rec_cache.erase(it);
         } else ++it;
     }
+    for (auto it = ctx->flip_sets.begin(); it != ctx->flip_sets.end();) {
+        const char *a = static_cast<const char *>(it->first), *b = a + sizeof(pb_blur_info) * (size_t)it->second.B;
+        if (a < hi && lo < b) it = ctx->flip_sets.erase(it); else ++it;
+    }
 }
 void pb_forget_records(pb_ctx *ctx, const void *info, int B) {
     if (info) {
@@ -725,6 +729,7 @@ void pb_forget_records(pb_ctx *ctx, const void *info, int B) {
         return;
     }
     ctx->rec_cache.clear();
+    ctx->flip_sets.clear();
     ctx->khat2_owner = nullptr; ctx->khat2_B = 0;
     ctx->khat_owner = nullptr;
     ctx->khat_B = 0;

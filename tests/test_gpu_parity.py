@@ -142,6 +142,47 @@ def test_convolve2d(eng, golden, name, boundary, key):
     assert maxabs(out, g[key]) < 2e-6
 
 
+def _odd_kernels():
+    """caller-supplied taps that are NOT point-symmetric: a shifted delta pair, a one-sided motion streak, an off-centre blob"""
+    K = capi.PB_KSIZE; c = K // 2
+    k = np.zeros((3, K, K), np.float64)
+    k[0, c + 3, c - 2] = 0.8; k[0, c, c] = 0.2
+    for t in range(9): k[1, c - t // 2, c + t] += 1.0 + 0.1 * t
+    yy, xx = np.mgrid[-c:c + 1, -c:c + 1].astype(np.float64)
+    k[2] = np.exp(-0.5 * ((xx - 2.5) ** 2 / 4.0 + (yy + 1.5) ** 2 / 1.5)) * (1.0 + 0.05 * xx).clip(0.1)
+    return (k / k.sum(axis=(1, 2), keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("method,boundary", [("fft", capi.PB_WRAP), ("direct", capi.PB_ZERO)])
+def test_caller_kernels_that_are_not_point_symmetric(eng, method, boundary):
+    """the reference CORRELATES under method='direct' (F.conv2d, filters.py:40-49) and CONVOLVES under method='fft'
+    (K = p2o(kernel), filters.py:33-36): for taps that are not point-symmetric the two differ by a reflection, and the stage
+    entry points follow the reference in both (found by tools/sweep_random_kernels.py: the wrap boundary correlated too).
+    convolve2d, the edgetaper, the inverse filter with and without the edgetaper, a batch that mixes such kernels with a
+    Gaussian -- against the oracle, which is pinned to the reference on exactly this (tests/test_oracle_golden.py)"""
+    # (a smaller call with a point-symmetric kernel first: the buffers that grow for the next call are freed in between, and which
+    #  record sets hold taps that are not point-symmetric has to outlive that -- it is not one of the context's disposable hints)
+    g1 = np.asarray(ref.gaussian_kernel_2d(np.float32([0.3]), np.float32([1.5]), np.float32([1.0])), np.float32).reshape(1, capi.PB_KSIZE, capi.PB_KSIZE)
+    x1, _ = synthetic_blurry_batch(1, 3, 96, 128, seed0=40)
+    xp1 = ref.replicate_pad(x1, capi.PB_KSIZE // 2)
+    assert maxabs(eng.convolve2d(xp1, eng.set_kernels(g1), boundary), ref.convolve2d(xp1, g1[:, None], method=method)) < 2e-6
+    ks = np.concatenate([_odd_kernels(), np.asarray(ref.gaussian_kernel_2d(np.float32([0.7]), np.float32([2.0]), np.float32([1.0])), np.float32).reshape(1, capi.PB_KSIZE, capi.PB_KSIZE)])
+    B = ks.shape[0]
+    x, _ = synthetic_blurry_batch(B, 3, 150, 210, seed0=41)
+    buf = eng.set_kernels(ks)
+    xp = ref.replicate_pad(x, capi.PB_KSIZE // 2)
+    assert maxabs(eng.convolve2d(xp, buf, boundary), ref.convolve2d(xp, ks[:, None], method=method)) < 2e-6
+    assert maxabs(eng.edgetaper(xp, buf, boundary), ref.edgetaper(xp, ks[:, None], method=method)) < 4e-6
+    for taper in (False, True):
+        got = eng.inverse_filter(x, buf, 6.0, 1.0, boundary, edgetaping=taper)
+        assert maxabs(got, ref.inverse_filtering_rank3(x, ks[:, None], 6.0, 1.0, do_edgetaper=taper, method=method)) < 2e-5
+    # the records themselves are untouched: the other boundary model right after, and the first again
+    other = capi.PB_ZERO if boundary == capi.PB_WRAP else capi.PB_WRAP
+    om = "direct" if method == "fft" else "fft"
+    assert maxabs(eng.convolve2d(xp, buf, other), ref.convolve2d(xp, ks[:, None], method=om)) < 2e-6
+    assert maxabs(eng.convolve2d(xp, buf, boundary), ref.convolve2d(xp, ks[:, None], method=method)) < 2e-6
+
+
 @pytest.mark.parametrize("name", ["stages_A.npz", "stages_B.npz", "stages_C.npz"])
 @pytest.mark.parametrize("kname", ["kest", "kwide"])
 def test_inverse_filter_fft(eng, golden, name, kname):
