@@ -1,6 +1,6 @@
 """ONE engine, a random SEQUENCE of different calls on different shapes (whole calls with options, caller kernels through the stage
 entry points, Gaussian records, the filters, the gradients): every result against the oracle -- what a context remembers between
-calls (records' facts, spectra, selections, scratch, reflected taps) must never leak into the next.  python tools/sweep_random_sequence.py [steps seed]"""
+calls (records' facts, spectra, selections, scratch, reflected taps) must never leak into the next.  python tools/sweep_random_sequence.py [steps seed [mid]]"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tools')
 from oracle import polyblur_ref as ref
@@ -11,6 +11,7 @@ from test_gpu_parity import _random_case
 exec(open('tools/sweep_random_kernels.py').read().split("a, b = (int(v)")[0].split('"""', 2)[2])      # kernel(rng)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MID = len(sys.argv) > 3 and sys.argv[3] == "mid"
 eng = get_engine(0)
 K = capi.PB_KSIZE
 bad = 0; count = {}
@@ -18,10 +19,14 @@ for t in range(steps):
     act = str(rng.choice(["call", "call", "kernels", "gauss", "dt", "grad", "bilateral"]))
     B, C = int(rng.integers(1, 4)), int(rng.choice([1, 3]))
     H, W = int(rng.integers(30, 220)), int(rng.integers(30, 300))
+    if MID and rng.random() < 0.5: H, W = int(rng.integers(220, 700)), int(rng.integers(300, 1000))
     x, _ = synthetic_blurry_batch(B, C, H, W, seed0=int(rng.integers(0, 10 ** 6)))
     err, tol, what = 0.0, 1.0, act
     if act == "call":
         _, kw, coef = _random_case(int(rng.integers(0, 10 ** 6)))
+        if rng.random() < 0.35:                          # other kernel sizes (even ones off-centre, above 25 the large-kernel pass), the adaptive support
+            kw["ker_size"] = int(rng.choice([7, 11, 12, 17, 24, 31, 40]))
+            if min(H, W) < 2 * kw["ker_size"] + 2: kw.pop("ker_size")
         got, gi = polyblur_deblurring(torch.from_numpy(x).cuda(), return_info=True, **kw, **coef)
         want, wi = ref.polyblur_deblurring(x, return_info=True, **kw, **coef)
         same = all(np.array_equal(p["theta"], q["theta"]) for p, q in zip(gi, wi))
